@@ -1,0 +1,276 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates ``tests/golden/*.npz`` by running the UNMODIFIED
+reference (``/root/reference``) in the build container on small seeded inputs.
+
+    cd /root/repo && python oracle/gen_golden.py
+
+The reference itself never travels: only the inputs and the arrays it produced are
+committed.  The reference classes are instantiated with ``object.__new__`` and the
+attributes their ``__init__`` would set (this avoids ``.h5`` files / libigl, which the
+image lacks); every *method* that runs is the reference's own.
+Selected-vertex indices are observed by wrapping the ``argmax`` name inside the
+reference module's namespace (a recording pass-through), SPLOCS internals by
+instance-level pass-through wrappers around ``prox_l1l2`` / ``project_weight``.
+"""
+import contextlib
+import hashlib
+import io
+import os
+import struct
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import asb_oracle as orc          # only for the seeded *input* generators
+from oracle.ref_import import import_reference
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _param(**kw):
+    base = dict(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                q_support="global", vertPos_numComponents=4, store_vertPos_PCA_sing_val=True,
+                vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25,
+                splocs_max_itrs=3, splocs_admm_num_itrs=4, splocs_lambda=2.0, splocs_rho=10.0,
+                vertPos_rest_shape="first", name="golden", vertPos_output_directory=".")
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def run_reference_pos(ref, verts, tris, param, mass=None, workdir="."):
+    """Drives reference posSnapshots + posComponents on in-memory data."""
+    posSnapshots, posComponents = ref["posSnapshots"], ref["posComponents"]
+    import snapbases.posComponents as pc_mod
+
+    snap = object.__new__(posSnapshots)
+    snap.input_animation_file = snap.input_test_animation_file = None
+    snap.rest_shape = param.vertPos_rest_shape
+    snap.verts = verts.astype(float)
+    snap.test_verts = None
+    snap.tris = tris
+    snap.test_tris = None
+    snap.frs, snap.nVerts = verts.shape[0], verts.shape[1]
+    snap.mean = None
+    snap.pre_scale_factor = 1
+    snap.mass = snap.massL = snap.invMassL = None
+    snap.snapTensor = None
+    snap.compute_geodesic_distance = None
+    snap.tet_mesh = None
+    snap.massesFile = os.path.join(workdir, "mass.bin")
+    if mass is not None:
+        with open(snap.massesFile, "wb") as fh:
+            fh.write(struct.pack("<ii", len(mass), 1))
+            fh.write(np.asarray(mass, "<f8").tobytes())
+    snap.read = lambda: None                      # data is already in memory (no h5py here)
+    snap.do_snapshots_precomputations(param.q_standarize, param.q_massWeight)
+
+    comp = object.__new__(posComponents)
+    comp.basesType = param.vertPos_bases_type
+    comp.pos_snapshots = snap
+    comp.numComp = param.vertPos_numComponents
+    comp.support = param.q_support
+    comp.storeSingVal = param.store_vertPos_PCA_sing_val
+    comp.comps = comp.weigs = comp.ortho_comps = None
+    comp.smooth_min_dist = param.vertPos_smooth_min_dist
+    comp.smooth_max_dist = param.vertPos_smooth_max_dist
+    comp.output_components_file = "components.h5"
+    comp.measures_at_largeDeforVerts = None
+    comp.fileNameBases = "q_pos_"
+    comp.param = param
+
+    out = dict(snapTensor=snap.snapTensor.copy(), mean=snap.mean.copy(),
+               pre_scale_factor=np.float64(snap.pre_scale_factor))
+    if mass is not None:
+        out.update(mass=snap.mass.copy(), massL=np.array(snap.massL), invMassL=np.array(snap.invMassL))
+
+    # --- observers (pass-through) ---
+    picked = []
+    real_argmax = pc_mod.argmax
+
+    def rec_argmax(a, *args, **kw):
+        r = real_argmax(a, *args, **kw)
+        picked.append(int(r))
+        return r
+
+    geo_calls = []
+    real_geo = snap.compute_geodesic_distance
+
+    def rec_geo(idx):
+        phi = real_geo(idx)
+        geo_calls.append((int(idx), phi.copy()))
+        return phi
+
+    snap.compute_geodesic_distance = rec_geo
+    prox_calls, pw_calls = [], []
+    if param.vertPos_bases_type == "SPLOCS":
+        real_prox, real_pw = posComponents.prox_l1l2, posComponents.project_weight
+
+        def rec_prox(Lambda, x, beta):
+            z = real_prox(Lambda, x, beta)
+            prox_calls.append((Lambda.copy(), z.copy()))
+            return z
+
+        comp.prox_l1l2 = rec_prox
+    pc_mod.argmax = rec_argmax
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            comp.compute_components_store_singvalues()
+    finally:
+        pc_mod.argmax = real_argmax
+    K = param.vertPos_numComponents
+    out.update(comps=comp.comps.copy(), weigs=comp.weigs.copy(),
+               measures=comp.measures_at_largeDeforVerts.copy(),
+               idx=np.array(picked[:K], dtype=np.int64))
+    csv_path = os.path.join(param.vertPos_output_directory,
+                            param.name + "_posBases_pcaExtraction_singValues_errorNorm.csv")
+    if param.store_vertPos_PCA_sing_val:
+        out["csv_text"] = np.array(open(csv_path).read())
+    if param.q_support == "local" or param.vertPos_bases_type == "SPLOCS":
+        out["geo_idx"] = np.array([g[0] for g in geo_calls], dtype=np.int64)
+        out["geo_phi_first"] = geo_calls[0][1]
+        out["geo_phi_deflation"] = np.array([g[1] for g in geo_calls[:K]]) if param.q_support == "local" else np.zeros(0)
+    if param.vertPos_bases_type == "SPLOCS":
+        trace = []
+        for line in buf.getvalue().splitlines():
+            if line.startswith("itr "):
+                parts = line.replace(",", " ").replace("=", " ").split()
+                trace.append([float(parts[3]), float(parts[5])])
+        out["splocs_trace"] = np.array(trace)
+        admm = param.splocs_admm_num_itrs
+        out["splocs_C_final"] = prox_calls[-1][1]
+        out["splocs_Lambda_final"] = prox_calls[-1][0]
+        out["splocs_C_per_iter"] = np.array([prox_calls[(i + 1) * admm - 1][1] for i in range(param.splocs_max_itrs)])
+        out["splocs_centres"] = out["geo_idx"][K:].reshape(param.splocs_max_itrs, K)
+
+    # post-processing (every flag combination asked for by the case) and storage
+    with contextlib.redirect_stdout(io.StringIO()):
+        comp.post_process_components()
+    out["comps_post"] = comp.comps.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        out["bases_sing_vals"] = comp.test_basesSingVals()
+        comp.store_components_to_files(K, K, 1, ".bin")
+        comp.store_components_to_files(K, K, 1, ".npy")
+    bin_path = os.path.join(param.vertPos_output_directory, "q_pos_F%dK%d.bin" % (snap.frs, K))
+    npy_path = os.path.join(param.vertPos_output_directory, "q_pos_%dK%d.npy" % (snap.frs, K))
+    raw = open(bin_path, "rb").read()
+    out["bin_bytes"] = np.frombuffer(raw, dtype=np.uint8)
+    out["bin_sha256"] = np.array(hashlib.sha256(raw).hexdigest())
+    assert np.array_equal(np.load(npy_path), comp.comps)
+    out["bin_name"] = np.array(os.path.basename(bin_path))
+    out["npy_name"] = np.array(os.path.basename(npy_path))
+    return out
+
+
+def run_reference_constraints(ref, frames, K, rest_shape, standarize, orthogonal, p, workdir):
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    param = types.SimpleNamespace(constProj_standarize=standarize, constProj_massWeight=False,
+                                  constProj_orthogonal=orthogonal, deim_desired_num_components=K,
+                                  constProj_output_directory=workdir)
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param = param
+    ns.rest_shape = rest_shape
+    ns.dim = 3
+    ns.frs = frames.shape[0]
+    ns.constraintsSize = p
+    ns.num_constained_elements = frames.shape[1] // p
+    ns.snapTensor = frames.astype(float).copy()
+    ns.mean = None
+    ns.pre_scale_factor = 1
+    ns.massL = ns.invMassL = None
+    if standarize:
+        ns.standarize()
+    cc = object.__new__(constraintsComponents)
+    cc.param = param
+    cc.nonlinearSnapshots = ns
+    cc.numComp = 0
+    cc.comps = None
+    cc.geom_interpol_verts = []
+    out = dict(snapTensor=ns.snapTensor.copy(),
+               mean=ns.mean.copy() if ns.mean is not None else np.zeros(0),
+               pre_scale_factor=np.float64(ns.pre_scale_factor))
+    rows = []
+    writer = types.SimpleNamespace(writerow=lambda r: rows.append(list(r)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_pod_for_vectorized_nonlinear_snapshots_tensor(writer)
+    out["S"] = np.array([r[1] for r in rows])
+    out["comps"] = cc.comps.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.post_process_components()
+    out["comps_post"] = cc.comps.copy()
+    out["snapTensor_post"] = ns.snapTensor.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.deim()
+    out["Pt"] = np.asarray(cc.geom_Pt, dtype=np.int64)
+    out["alpha"] = np.asarray(cc.geom_alpha, dtype=np.int64)
+    out["alpha_ranges"] = np.asarray(cc.geom_alpha_ranges, dtype=np.int64)
+    return out
+
+
+CASES = {
+    # name: (rings, segs, F, rank, kind, seed, param overrides, with_mass)
+    "pca_global_small": (8, 12, 40, 5, "iid", 1, dict(vertPos_numComponents=6), False),
+    "pca_global_avg_mass_orth": (8, 12, 36, 6, "iid", 2,
+                                 dict(vertPos_numComponents=5, vertPos_rest_shape="average", q_massWeight=True,
+                                      q_orthogonal=True), True),
+    "pca_global_nostd": (6, 10, 24, 4, "iid", 3, dict(vertPos_numComponents=4, q_standarize=False), False),
+    "pca_global_medium": (16, 30, 64, 12, "iid", 4, dict(vertPos_numComponents=16), False),
+    "pca_local_small": (10, 16, 30, 5, "bumps", 5,
+                        dict(vertPos_numComponents=5, q_support="local", vertPos_smooth_min_dist=0.1,
+                             vertPos_smooth_max_dist=0.35), False),
+    "splocs_small": (10, 16, 30, 5, "bumps", 6,
+                     dict(vertPos_numComponents=5, q_support="local", vertPos_bases_type="SPLOCS",
+                          vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.35,
+                          splocs_max_itrs=3, splocs_admm_num_itrs=4), False),
+}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as work:
+        os.chdir(work)                             # log_time writes function_timings.txt into cwd
+        try:
+            for name, (rings, segs, F, rank, kind, seed, over, with_mass) in CASES.items():
+                rest, tris = orc.synth_mesh(rings, segs, seed=seed)
+                noise = 1e-4 if "nostd" not in name else 1e-3
+                verts = orc.synth_snapshots(rest, F, rank=rank, noise=noise, seed=seed, kind=kind)
+                mass = None
+                if with_mass:
+                    mass = np.random.default_rng(seed + 100).uniform(0.5, 2.0, size=rest.shape[0])
+                    mass = mass / mass.sum() * 2
+                param = _param(vertPos_output_directory=work, **over)
+                res = run_reference_pos(ref, verts, tris, param, mass=mass, workdir=work)
+                if "medium" in name:
+                    res.pop("snapTensor")          # keep the fixture small; it is recomputed from verts
+                meta = dict(rings=rings, segs=segs, F=F, rank=rank, seed=seed, noise=noise)
+                np.savez_compressed(os.path.join(OUT, name + ".npz"), verts=verts, tris=tris,
+                                    kind=np.array(kind),
+                                    **{"meta_" + k: np.array(v) for k, v in meta.items()},
+                                    **{"param_" + k: np.array(v) for k, v in vars(param).items()
+                                       if k != "vertPos_output_directory"},
+                                    **res)
+                print("wrote", name, "idx", res["idx"].tolist())
+            # config-5 style: POD + DEIM on constraint-projection snapshots
+            rng = np.random.default_rng(11)
+            ep, F, K = 120, 24, 8
+            modes = rng.normal(size=(10, ep, 3))
+            coef = rng.normal(size=(F, 10)) * (0.6 ** np.arange(10))[None]
+            frames = 0.3 + np.tensordot(coef, modes, (1, 0)) + 1e-5 * rng.normal(size=(F, ep, 3))
+            for nm, orth in (("pod_deim_small", False), ("pod_deim_small_qr", True)):
+                res = run_reference_constraints(ref, frames, K, "first", True, orth, 1, work)
+                np.savez_compressed(os.path.join(OUT, nm + ".npz"), frames=frames, K=np.array(K),
+                                    p=np.array(1), orthogonal=np.array(orth), **res)
+                print("wrote", nm, "Pt", res["Pt"].tolist())
+        finally:
+            os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()
