@@ -1,0 +1,92 @@
+"""ctypes binding of ``libasb_hip.so`` (C ABI declared in ``include/asb.h``).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 GPU is usable,
+``load()`` / ``HipContext()`` raise ``AsbLibraryError`` loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasb_hip.so")
+
+c_dp = ctypes.c_void_p          # double* / generic pointers are passed as integers
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+
+ASB_OK = 0
+DEFLATE_RESIDUAL, DEFLATE_PROJECT = 0, 1
+
+# name -> (restype, argtypes): must list every symbol of include/asb.h
+PROTOTYPES = {
+    "asb_abi_version": (c_int, []),
+    "asb_create": (c_int, [c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "asb_destroy": (None, [ctypes.c_void_p]),
+    "asb_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "asb_sync": (c_int, [ctypes.c_void_p]),
+    "asb_prof_reset": (c_int, [ctypes.c_void_p, c_int]),
+    "asb_prof_get": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+    "asb_snapshots_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_i64, c_i64, c_dp]),
+    "asb_snapshots_adopt_dev": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp]),
+    "asb_snapshots_center": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(c_dbl)]),
+    "asb_snapshots_sqdev": (c_int, [ctypes.c_void_p, c_dbl, ctypes.POINTER(c_dbl)]),
+    "asb_snapshots_scale": (c_int, [ctypes.c_void_p, c_dbl]),
+    "asb_snapshots_get_mean": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_snapshots_download": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_deflate_begin": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int]),
+    "asb_deflate_xchg_len": (c_i64, [ctypes.c_void_p]),
+    "asb_deflate_local_best": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
+    "asb_deflate_pick": (c_int, [ctypes.c_void_p, c_i64, c_dp, c_i64]),
+    "asb_deflate_get_pick": (c_int, [ctypes.c_void_p, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+    "asb_deflate_apply": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
+    "asb_deflate_run_global": (c_int, [ctypes.c_void_p, c_i64, c_i64]),
+    "asb_deflate_results": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_components_post": (c_int, [ctypes.c_void_p, c_int, c_dbl, c_dp, c_dp]),
+    "asb_test_eig3": (None, [c_dp, c_dp]),
+}
+
+
+class AsbLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library and binds every entry point of include/asb.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsbLibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C animsnapbases_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise AsbLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise AsbLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous float64/int64 array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

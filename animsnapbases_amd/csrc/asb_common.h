@@ -1,0 +1,125 @@
+// Internal definitions shared by the translation units of libasb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "asb.h"
+
+struct asb_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::map<void*, size_t> alloc_bytes;   // capacity of each context-owned buffer
+
+    // ---- snapshot shard, vertex-major: row r = 3*v + d, Fp doubles per row ----
+    int64_t F = 0, Fp = 0, n_loc = 0, v0 = 0, N_glob = 0;
+    double* X = nullptr;      // (3*n_loc, Fp)   prepared snapshots (snapTensor)
+    double* mean = nullptr;   // (3*n_loc)
+    bool have_mean = false;
+
+    // ---- reduction scratch ----
+    int nblk_cap = 0;
+    double* pmax = nullptr;
+    long long* pidx = nullptr;
+    double* psum = nullptr;
+    double* scalar_dev = nullptr;   // a few doubles for device-side scalars
+    double* s_dev = nullptr;        // (n_loc) support factor
+
+    // ---- deflation state ----
+    int64_t K = 0;
+    int mode = 0, local = 0;
+    int64_t k_done = 0;
+    int nblk = 0;               // partial records written by the last streaming pass
+    double* R = nullptr;        // (3*n_loc, Fp) residual (mode RESIDUAL)
+    double* energy = nullptr;   // (n_loc)
+    double* W = nullptr;        // (K, Fp)
+    double* comps = nullptr;    // (K, 3*n_loc)
+    double* scal = nullptr;     // (K+1, 4): sigma, |w|^2, idx bits, local ||R||^2 after comp k
+    double* xrec = nullptr;     // one exchange record
+
+    // ---- profiling of the dominant streaming kernel ----
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+#define ASB_FAIL(ctx, code, ...)                                   \
+    do {                                                           \
+        char _b[512];                                              \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                     \
+        (ctx)->err = _b;                                           \
+        return (code);                                             \
+    } while (0)
+
+#define ASB_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess)                                                                \
+            ASB_FAIL(ctx, ASB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define ASB_CHECK_LAUNCH(ctx) ASB_HIP(ctx, hipGetLastError())
+
+// (Re)allocates *p to hold `count` elements; an existing allocation that is already large
+// enough (and not more than 2x too large) is kept, so repeated runs on one context do not
+// pay hipMalloc/hipFree inside a timed region.
+template <typename T>
+static inline int asb_alloc(asb_ctx* ctx, T** p, size_t count) {
+    const size_t want = count * sizeof(T);
+    auto it = ctx->alloc_bytes.find((void*)p);
+    if (*p && it != ctx->alloc_bytes.end() && it->second >= want && it->second <= 2 * want + 4096) return ASB_OK;
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+        ctx->alloc_bytes.erase((void*)p);
+    }
+    if (count == 0) return ASB_OK;
+    ASB_HIP(ctx, hipMalloc((void**)p, want));
+    ctx->alloc_bytes[(void*)p] = want;
+    return ASB_OK;
+}
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum of NV values per thread; result valid in every thread.
+// scratch: at least NV * (blockDim.x/64) doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (nw == 1) return;
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < NV; ++i) scratch[wid * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0;
+        for (int w = 0; w < nw; ++w) s += scratch[w * NV + i];
+        v[i] = s;
+    }
+}
+
+// "better" for arg-max with NumPy's first-max tie-break: larger value, then lower index.
+__device__ __forceinline__ bool am_better(double e, long long i, double be, long long bi) {
+    return (e > be) || (e == be && i < bi);
+}

@@ -1,0 +1,346 @@
+// Context management + snapshot preparation kernels -- posSnapshots, the reference's
+// snapbases/posSnapshots.py:64-105 (do_snapshots_precomputations) and :163-172 (standarize).
+// gfx950 (MI355X) only.
+#include "asb_common.h"
+
+#include <cstring>
+
+// --------------------------------------------------------------------------------------
+// Tiled transpose (F, C) <-> (C, Fp) through LDS; optional scaling of column c by
+// colscale[c/3] (mass weighting, posSnapshots.py:82).  32x32 tiles, 256 threads.
+//   out[c * ld_out + r] = in[r * ld_in + c] * scale(c)      r < rows_in, c < cols_in
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in, long long rows_in,
+                                                   long long cols_in, long long ld_in,
+                                                   double* __restrict__ out, long long ld_out,
+                                                   const double* __restrict__ colscale, int scale_on_in_col) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long r = r0 + ty + i * 8, c = c0 + tx;
+        double v = 0.0;
+        if (r < rows_in && c < cols_in) {
+            v = in[r * ld_in + c];
+            if (colscale && scale_on_in_col) v *= colscale[c / 3];
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < rows_in && c < cols_in) out[c * ld_out + r] = tile[tx][ty + i * 8];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// One wave per row of the vertex-major tensor.
+// k_center: mean[r] = row[0] (rest_shape 0) or mean_f row (1); optionally row -= mean;
+//           block partial of sum(row) afterwards.
+// k_sqdev : block partial of sum (row - mu)^2.
+// k_scale : row *= a.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_center(double* __restrict__ X, long long nrows, int F, int Fp,
+                                                int rest_shape, int subtract, double* __restrict__ mean,
+                                                double* __restrict__ psum) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (long long r = (long long)blockIdx.x * 4 + wid; r < nrows; r += (long long)gridDim.x * 4) {
+        double* row = X + r * Fp;
+        double m;
+        if (rest_shape == 0) {
+            m = row[0];
+        } else {
+            double s = 0.0;
+            for (int f = lane; f < F; f += 64) s += row[f];
+            m = wave_sum(s) / (double)F;
+        }
+        double s2 = 0.0;
+        for (int f = lane; f < F; f += 64) {
+            double v = row[f];
+            if (subtract) {
+                v -= m;
+                row[f] = v;
+            }
+            s2 += v;
+        }
+        acc += wave_sum(s2);
+        if (lane == 0) mean[r] = m;
+    }
+    if (lane == 0) sh[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) psum[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sqdev(const double* __restrict__ X, long long nrows, int F, int Fp,
+                                               double mu, double* __restrict__ psum) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (long long r = (long long)blockIdx.x * 4 + wid; r < nrows; r += (long long)gridDim.x * 4) {
+        const double* row = X + r * Fp;
+        double s = 0.0;
+        for (int f = lane; f < F; f += 64) {
+            const double d = row[f] - mu;
+            s += d * d;
+        }
+        acc += wave_sum(s);
+    }
+    if (lane == 0) sh[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) psum[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void k_scale(double* __restrict__ X, long long n2, double a) {
+    double2* p = reinterpret_cast<double2*>(X);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += (long long)gridDim.x * blockDim.x) {
+        double2 v = p[i];
+        v.x *= a;
+        v.y *= a;
+        p[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, int n, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v[0] += in[i];
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) out[0] = v[0];
+}
+
+// --------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------
+extern "C" int asb_abi_version(void) { return ASB_ABI_VERSION; }
+
+extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
+    if (!out) return ASB_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id || device_id < 0) return ASB_ERR_NODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ASB_ERR_NODEV;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ASB_ERR_NODEV;   // kernels are built for gfx950 only
+    asb_ctx* ctx = new asb_ctx();
+    ctx->dev = device_id;
+    *out = ctx;
+    ASB_HIP(ctx, hipSetDevice(device_id));
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    ctx->nblk_cap = prop.multiProcessorCount * 8;   // grid cap for streaming passes (guide: G11)
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pmax, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pidx, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->psum, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)16))) return rc;
+    return ASB_OK;
+}
+
+extern "C" void asb_destroy(asb_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipStreamSynchronize(ctx->stream);
+    double** bufs[] = {&ctx->X, &ctx->mean, &ctx->pmax, &ctx->psum, &ctx->scalar_dev, &ctx->s_dev, &ctx->R,
+                       &ctx->energy, &ctx->W, &ctx->comps, &ctx->scal, &ctx->xrec};
+    for (auto b : bufs)
+        if (*b) (void)hipFree(*b);
+    if (ctx->pidx) (void)hipFree(ctx->pidx);
+    for (auto& e : ctx->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* asb_last_error(const asb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int asb_sync(asb_ctx* ctx) {
+    if (!ctx) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+extern "C" int asb_prof_reset(asb_ctx* ctx, int enable) {
+    if (!ctx) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ev_used = 0;
+    ctx->prof = enable != 0;
+    return ASB_OK;
+}
+
+extern "C" int asb_prof_get(asb_ctx* ctx, int64_t* launches, double* total_ms) {
+    if (!ctx) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.f;
+        ASB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        tot += ms;
+    }
+    if (launches) *launches = (int64_t)ctx->ev_used;
+    if (total_ms) *total_ms = tot;
+    return ASB_OK;
+}
+
+static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_t n_loc) {
+    if (F < 1 || n_loc < 1 || v0 < 0 || v0 + n_loc > N_glob)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "bad snapshot shape F=%lld N=%lld v0=%lld n_loc=%lld", (long long)F,
+                 (long long)N_glob, (long long)v0, (long long)n_loc);
+    if (F > 32768) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F = %lld exceeds the 32768-frame limit of the streaming kernels", (long long)F);
+    ctx->F = F;
+    ctx->Fp = (F + 7) / 8 * 8;
+    ctx->N_glob = N_glob;
+    ctx->v0 = v0;
+    ctx->n_loc = n_loc;
+    ctx->have_mean = false;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->X, (size_t)n_loc * 3 * ctx->Fp))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->mean, (size_t)n_loc * 3))) return rc;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->X, 0, (size_t)n_loc * 3 * ctx->Fp * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(ctx->mean, 0, (size_t)n_loc * 3 * sizeof(double), ctx->stream));
+    return ASB_OK;
+}
+
+static int transpose_in(asb_ctx* ctx, const double* stage_dev, const double* massL_dev) {
+    const long long C = ctx->n_loc * 3;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((ctx->F + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, stage_dev, (long long)ctx->F, C, C, ctx->X,
+                       (long long)ctx->Fp, massL_dev, 1);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+extern "C" int asb_snapshots_upload(asb_ctx* ctx, const double* X, int64_t F, int64_t N_glob, int64_t v0,
+                                    int64_t n_loc, const double* massL) {
+    if (!ctx || !X) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));
+    int rc = set_shape(ctx, F, N_glob, v0, n_loc);
+    if (rc) return rc;
+    double* stage = nullptr;
+    double* mdev = nullptr;
+    const size_t C = (size_t)n_loc * 3;
+    ASB_HIP(ctx, hipMalloc((void**)&stage, (size_t)F * C * sizeof(double)));
+    hipError_t e = hipMemcpy2DAsync(stage, C * sizeof(double), X + v0 * 3, (size_t)N_glob * 3 * sizeof(double),
+                                    C * sizeof(double), (size_t)F, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && massL) {
+        e = hipMalloc((void**)&mdev, (size_t)n_loc * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(mdev, massL + v0, (size_t)n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        rc = transpose_in(ctx, stage, mdev);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(stage);
+    if (mdev) (void)hipFree(mdev);
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_snapshots_upload: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc,
+                                       const double* massL_loc) {
+    if (!ctx || !X_dev) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));
+    int rc = set_shape(ctx, F, n_loc, 0, n_loc);
+    if (rc) return rc;
+    double* mdev = nullptr;
+    if (massL_loc) {
+        ASB_HIP(ctx, hipMalloc((void**)&mdev, (size_t)n_loc * sizeof(double)));
+        ASB_HIP(ctx, hipMemcpyAsync(mdev, massL_loc, (size_t)n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = transpose_in(ctx, X_dev, mdev);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (mdev) (void)hipFree(mdev);
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_snapshots_adopt_dev: %s", hipGetErrorString(e));
+    return rc;
+}
+
+static int finish_sum(asb_ctx* ctx, int nblk, double* out_host) {
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, ctx->stream, ctx->psum, nblk, ctx->scalar_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(out_host, ctx->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+static int row_grid(const asb_ctx* ctx) {
+    long long want = (ctx->n_loc * 3 + 3) / 4;
+    return (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
+}
+
+extern "C" int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, double* local_sum) {
+    if (!ctx || !ctx->X) return ASB_ERR_ARG;
+    if (rest_shape != 0 && rest_shape != 1) ASB_FAIL(ctx, ASB_ERR_ARG, "unknown rest shape code %d", rest_shape);
+    const int grid = row_grid(ctx);
+    hipLaunchKernelGGL(k_center, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc * 3,
+                       (int)ctx->F, (int)ctx->Fp, rest_shape, subtract, ctx->mean, ctx->psum);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->have_mean = true;
+    double tmp;
+    return finish_sum(ctx, grid, local_sum ? local_sum : &tmp);
+}
+
+extern "C" int asb_snapshots_sqdev(asb_ctx* ctx, double mu, double* local_sqdev) {
+    if (!ctx || !ctx->X || !local_sqdev) return ASB_ERR_ARG;
+    const int grid = row_grid(ctx);
+    hipLaunchKernelGGL(k_sqdev, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc * 3,
+                       (int)ctx->F, (int)ctx->Fp, mu, ctx->psum);
+    ASB_CHECK_LAUNCH(ctx);
+    return finish_sum(ctx, grid, local_sqdev);
+}
+
+extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
+    if (!ctx || !ctx->X) return ASB_ERR_ARG;
+    const long long n2 = ctx->n_loc * 3 * ctx->Fp / 2;
+    long long want = (n2 + 255) / 256;
+    const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, n2, a);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+extern "C" int asb_snapshots_get_mean(asb_ctx* ctx, double* mean_out) {
+    if (!ctx || !ctx->X || !mean_out) return ASB_ERR_ARG;
+    if (!ctx->have_mean) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_snapshots_get_mean before asb_snapshots_center");
+    ASB_HIP(ctx, hipMemcpyAsync(mean_out, ctx->mean, (size_t)ctx->n_loc * 3 * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// (C, Fp) vertex-major device tensor -> host (F, C)
+int asb_download_vertex_major(asb_ctx* ctx, const double* src, double* out) {
+    const long long C = ctx->n_loc * 3;
+    double* stage = nullptr;
+    ASB_HIP(ctx, hipMalloc((void**)&stage, (size_t)ctx->F * C * sizeof(double)));
+    dim3 grid((unsigned)((ctx->F + 31) / 32), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, src, C, (long long)ctx->F, (long long)ctx->Fp,
+                       stage, C, (const double*)nullptr, 0);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, stage, (size_t)ctx->F * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "download: %s", hipGetErrorString(e));
+    return ASB_OK;
+}
+
+extern "C" int asb_snapshots_download(asb_ctx* ctx, double* out) {
+    if (!ctx || !ctx->X || !out) return ASB_ERR_ARG;
+    return asb_download_vertex_major(ctx, ctx->X, out);
+}
+
+extern "C" int asb_deflate_download_residual(asb_ctx* ctx, double* out) {
+    if (!ctx || !ctx->R || !out) return ASB_ERR_ARG;
+    return asb_download_vertex_major(ctx, ctx->R, out);
+}

@@ -1,0 +1,101 @@
+"""Vertex-row sharding over the GPUs of one node.
+
+One process per GPU.  ``Comm`` wraps ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests); with no process group it degenerates to a
+single rank and never imports torch.
+
+What crosses ranks on the deflation path is tiny and latency-bound: per component one
+all-gather of ``[energy, idx, 3 x F slab]`` records (<= 48 KB at F = 2000), plus scalar
+all-reduces during standardisation and one all-reduce of the K residual norms at the end.
+The snapshot tensor itself never moves.
+"""
+import numpy as np
+
+
+def partition(N, world):
+    """Contiguous vertex ranges: the first ``N % world`` ranks get one extra vertex.
+    Returns the list of (v0, n_loc)."""
+    base, extra = divmod(int(N), int(world))
+    out, v0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((v0, n))
+        v0 += n
+    return out
+
+
+class Comm(object):
+    def __init__(self, group=None, force_single=False):
+        self.group = group
+        self.dist = None
+        self.rank, self.world = 0, 1
+        if not force_single:
+            try:
+                import torch.distributed as dist
+            except Exception:          # torch absent: single rank
+                dist = None
+            if dist is not None and dist.is_available() and dist.is_initialized():
+                self.dist = dist
+                self.rank = dist.get_rank(group)
+                self.world = dist.get_world_size(group)
+        self._torch = None
+        self._dev = None
+        if self.world > 1:
+            import torch
+
+            self._torch = torch
+            backend = self.dist.get_backend(group)
+            self._dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    # ------------------------------------------------------------ partition
+    def shards(self, N):
+        return partition(N, self.world)
+
+    def my_shard(self, N):
+        return self.shards(N)[self.rank]
+
+    # ------------------------------------------------------------ collectives
+    def allreduce_sum(self, values):
+        """Sum of a small float64 vector over ranks (returned as ndarray)."""
+        a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
+        if self.world == 1:
+            return a
+        t = self._torch.from_numpy(a).to(self._dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def new_records(self, xlen, on_device):
+        """(rec, recs): one exchange record and the gathered (world, xlen) buffer."""
+        torch = self._torch
+        dev = self._dev if on_device else torch.device("cpu")
+        rec = torch.zeros(xlen, dtype=torch.float64, device=dev)
+        recs = torch.zeros(self.world * xlen, dtype=torch.float64, device=dev)
+        return rec, recs
+
+    def all_gather_records(self, rec, recs):
+        if rec.device.type != self._dev.type:      # e.g. CPU records with an nccl group (not used by the product)
+            r, rs = rec.to(self._dev), recs.to(self._dev)
+            self.dist.all_gather_into_tensor(rs, r, group=self.group)
+            recs.copy_(rs)
+            return
+        self.dist.all_gather_into_tensor(recs, rec, group=self.group)
+
+    def all_gather_rows(self, local, N, axis):
+        """Concatenates per-rank blocks along ``axis`` (block sizes follow ``partition``)."""
+        if self.world == 1:
+            return local
+        torch = self._torch
+        shards = self.shards(N)
+        nmax = max(n for _, n in shards)
+        loc = np.moveaxis(np.ascontiguousarray(local), axis, 0)
+        pad = np.zeros((nmax,) + loc.shape[1:], dtype=loc.dtype)
+        pad[:loc.shape[0]] = loc
+        t = torch.from_numpy(pad).to(self._dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t, group=self.group)
+        parts = [o.cpu().numpy()[:n] for o, (_, n) in zip(outs, shards)]
+        return np.moveaxis(np.concatenate(parts, axis=0), 0, axis)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier(group=self.group)

@@ -1,0 +1,156 @@
+"""One-shard device engine: an object wrapper over the C ABI of ``libasb_hip.so``.
+
+``HipEngine`` is the ONLY compute engine of the product.  The host classes
+(``posSnapshots`` / ``posComponents``) talk to it through the small method set below, so
+the multi-rank host logic can be exercised on CPU by a test double that lives in
+``tests/`` (never in this package).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import AsbLibraryError, ptr
+
+
+class HipEngine(object):
+    """Owns one ``asb_ctx`` = one GPU, one HIP stream, one vertex shard."""
+
+    device_exchange = True      # exchange records live in device memory (torch tensors)
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = _lib.load()
+        if self.lib.asb_abi_version() != 1:
+            raise AsbLibraryError("libasb_hip.so ABI version mismatch")
+        h = ctypes.c_void_p()
+        rc = self.lib.asb_create(int(device_id), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.asb_last_error(h).decode() if h else ""
+            if h:
+                self.lib.asb_destroy(h)
+            raise AsbLibraryError("asb_create(device %d) failed with status %d %s -- a gfx950 (MI355X) GPU is "
+                                  "required; there is no CPU fallback" % (device_id, rc, msg))
+        self.h = h
+        self.device_id = int(device_id)
+        self.F = self.n_loc = self.v0 = self.N_glob = self.K = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("libasb_hip: status %d: %s" % (rc, self.lib.asb_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.asb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._ck(self.lib.asb_sync(self.h))
+
+    def prof_reset(self, enable=True):
+        self._ck(self.lib.asb_prof_reset(self.h, int(bool(enable))))
+
+    def prof_get(self):
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_prof_get(self.h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    # ------------------------------------------------------------------ snapshots
+    def upload(self, X, v0, n_loc, massL=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        F, N, three = X.shape
+        assert three == 3
+        if massL is not None:
+            massL = np.ascontiguousarray(massL, dtype=np.float64)
+            assert massL.shape == (N,)
+        self._ck(self.lib.asb_snapshots_upload(self.h, ptr(X), F, N, int(v0), int(n_loc), ptr(massL)))
+        self.F, self.N_glob, self.v0, self.n_loc = F, N, int(v0), int(n_loc)
+
+    def adopt_device(self, dev_ptr, F, n_loc, massL_loc=None):
+        """dev_ptr: device address of an (F, n_loc, 3) float64 tensor (reference layout)."""
+        if massL_loc is not None:
+            massL_loc = np.ascontiguousarray(massL_loc, dtype=np.float64)
+        self._ck(self.lib.asb_snapshots_adopt_dev(self.h, ctypes.c_void_p(dev_ptr), int(F), int(n_loc), ptr(massL_loc)))
+        self.F, self.N_glob, self.v0, self.n_loc = int(F), int(n_loc), 0, int(n_loc)
+
+    def center(self, rest_shape_code, subtract):
+        s = ctypes.c_double()
+        self._ck(self.lib.asb_snapshots_center(self.h, int(rest_shape_code), int(bool(subtract)), ctypes.byref(s)))
+        return s.value
+
+    def sqdev(self, mu):
+        s = ctypes.c_double()
+        self._ck(self.lib.asb_snapshots_sqdev(self.h, float(mu), ctypes.byref(s)))
+        return s.value
+
+    def scale(self, a):
+        self._ck(self.lib.asb_snapshots_scale(self.h, float(a)))
+
+    def get_mean(self):
+        out = np.empty((self.n_loc, 3))
+        self._ck(self.lib.asb_snapshots_get_mean(self.h, ptr(out)))
+        return out
+
+    def download_snapshots(self):
+        out = np.empty((self.F, self.n_loc, 3))
+        self._ck(self.lib.asb_snapshots_download(self.h, ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ deflation
+    def deflate_begin(self, K, local_support, mode=_lib.DEFLATE_RESIDUAL):
+        self._ck(self.lib.asb_deflate_begin(self.h, int(K), int(mode), int(bool(local_support))))
+        self.K = int(K)
+
+    def xchg_len(self):
+        return int(self.lib.asb_deflate_xchg_len(self.h))
+
+    def local_best(self, k, rec_dev_ptr):
+        self._ck(self.lib.asb_deflate_local_best(self.h, int(k), ctypes.c_void_p(rec_dev_ptr)))
+
+    def pick(self, k, recs_dev_ptr=None, n_rec=0):
+        self._ck(self.lib.asb_deflate_pick(self.h, int(k), ctypes.c_void_p(recs_dev_ptr) if recs_dev_ptr else None,
+                                           int(n_rec)))
+
+    def get_pick(self, k):
+        i, s = ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_deflate_get_pick(self.h, int(k), ctypes.byref(i), ctypes.byref(s)))
+        return i.value, s.value
+
+    def apply(self, k, s_loc=None):
+        if s_loc is not None:
+            s_loc = np.ascontiguousarray(s_loc, dtype=np.float64)
+            assert s_loc.shape == (self.n_loc,)
+        self._ck(self.lib.asb_deflate_apply(self.h, int(k), ptr(s_loc)))
+
+    def run_global(self, k0, k1):
+        self._ck(self.lib.asb_deflate_run_global(self.h, int(k0), int(k1)))
+
+    def results(self, want_comps=True, want_weigs=True):
+        K = self.K
+        comps = np.empty((K, self.n_loc, 3)) if want_comps else None
+        weigs = np.empty((self.F, K)) if want_weigs else None
+        idx = np.empty(K, dtype=np.int64)
+        sigma = np.empty(K)
+        nr2 = np.empty(K)
+        self._ck(self.lib.asb_deflate_results(self.h, ptr(comps), ptr(weigs), ptr(idx), ptr(sigma), ptr(nr2)))
+        return dict(comps=comps, weigs=weigs, idx=idx, sigma=sigma, normR2_local=nr2)
+
+    def download_residual(self):
+        out = np.empty((self.F, self.n_loc, 3))
+        self._ck(self.lib.asb_deflate_download_residual(self.h, ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ post-processing
+    def components_post(self, unscale, pre_scale_factor, invMassL_loc=None):
+        out = np.empty((self.K, self.n_loc, 3))
+        if invMassL_loc is not None:
+            invMassL_loc = np.ascontiguousarray(invMassL_loc, dtype=np.float64)
+        self._ck(self.lib.asb_components_post(self.h, int(bool(unscale)), float(pre_scale_factor), ptr(invMassL_loc),
+                                              ptr(out)))
+        return out

@@ -1,0 +1,114 @@
+"""Heat-method geodesic distances on the HOST (SciPy SuperLU) -- the support maps of
+``support='local'`` and SPLOCS.
+
+Follows the formulas of the reference's ``GeodesicDistanceComputation``
+(utils/support.py:139-208; cotan Laplacian :81-136; m = 10, t = m*h^2), but is organised
+differently: the per-triangle gradient and the per-vertex divergence are assembled ONCE as
+sparse matrices G (3M x N) and D (N x 3M), so one query is two SuperLU solves and two
+sparse mat-vecs, and ``solve_many`` answers K queries with multi-right-hand-side solves
+(what one SPLOCS outer iteration needs, posComponents.py:158-165).
+
+SURVEY.md 8(f)-3 ranks a device PCG as a later row; until then this host stage is the
+Amdahl term of the local / SPLOCS modes and is reported as such.
+"""
+import numpy as np
+from scipy import sparse
+from scipy.sparse.linalg import splu
+
+
+def _vlen(v):
+    return np.sqrt((v * v).sum(axis=-1))
+
+
+def _unit(v):
+    return v / _vlen(v)[..., None]
+
+
+def cotan_laplacian(verts, tris):
+    """L (negative semi-definite cotan Laplacian, rows sum to 0) and the lumped vertex
+    areas (utils/support.py:81-136)."""
+    n = verts.shape[0]
+    I, J, Wv = [], [], []
+    for a, b, c in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+        pa, pb, pc = verts[tris[:, a]], verts[tris[:, b]], verts[tris[:, c]]
+        u, v = pb - pa, pc - pa
+        w = 0.5 * (u * v).sum(axis=1) / _vlen(np.cross(u, v))
+        I += [tris[:, b], tris[:, c]]
+        J += [tris[:, c], tris[:, b]]
+        Wv += [w, w]
+    Wm = sparse.csr_matrix((np.concatenate(Wv), (np.concatenate(I), np.concatenate(J))), shape=(n, n))
+    L = (Wm - sparse.diags(np.asarray(Wm.sum(axis=1)).ravel())).tocsr()
+    tri_area = 0.5 * _vlen(np.cross(verts[tris[:, 1]] - verts[tris[:, 0]], verts[tris[:, 2]] - verts[tris[:, 0]]))
+    area = np.zeros(n)
+    for i in range(3):
+        area += np.bincount(tris[:, i], tri_area / 3, minlength=n)
+    return L, area
+
+
+class GeodesicDistanceComputation(object):
+    """Callable: ``phi = geo(idx)`` -> (N,) geodesic distance from vertex ``idx``
+    (shifted so that min(phi) == 0, utils/support.py:206)."""
+
+    def __init__(self, verts, tris, m=10.0):
+        verts = np.asarray(verts, dtype=np.float64)
+        tris = np.asarray(tris, dtype=np.int64)
+        n, M = verts.shape[0], tris.shape[0]
+        self.n = n
+        p0, p1, p2 = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
+        e01, e12, e20 = p1 - p0, p2 - p1, p0 - p2
+        area = 0.5 * _vlen(np.cross(e01, e12))
+        nrm = _unit(np.cross(_unit(e01), _unit(e12)))
+        # gradient: grad u = 1/(2A) * sum_i u[v_i] * (n x e_opposite(i))   (:184-188)
+        g_for = {2: np.cross(nrm, e01), 0: np.cross(nrm, e12), 1: np.cross(nrm, e20)}
+        rows, cols, vals = [], [], []
+        tri_ids = np.arange(M)
+        for corner, vec in g_for.items():
+            coef = vec / (2 * area)[:, None]
+            for d in range(3):
+                rows.append(3 * tri_ids + d)
+                cols.append(tris[:, corner])
+                vals.append(coef[:, d])
+        self.G = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                                   shape=(3 * M, n))
+        # divergence: div[v1] += 0.5*(cot1*(e1.X) + cot2*(e2.X))               (:192-204)
+        rows, cols, vals = [], [], []
+        for a, b, c in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+            pa, pb, pc = verts[tris[:, a]], verts[tris[:, b]], verts[tris[:, c]]
+            e1, e2, eo = pb - pa, pc - pa, pc - pb
+            cot1 = 1 / np.tan(np.arccos((_unit(-e2) * _unit(-eo)).sum(axis=1)))
+            cot2 = 1 / np.tan(np.arccos((_unit(-e1) * _unit(eo)).sum(axis=1)))
+            coef = 0.5 * (cot1[:, None] * e1 + cot2[:, None] * e2)
+            for d in range(3):
+                rows.append(tris[:, a])
+                cols.append(3 * tri_ids + d)
+                vals.append(coef[:, d])
+        self.D = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                                   shape=(n, 3 * M))
+        h = np.mean([_vlen(e01), _vlen(e12), _vlen(e20)])
+        t = m * h ** 2
+        L, vert_area = cotan_laplacian(verts, tris)
+        self._heat = splu((sparse.diags(vert_area) - t * L).tocsc())
+        self._poisson = splu(L.tocsc())
+
+    def _field(self, U):
+        """U: (n,) or (n,k) heat solutions -> distances, same shape."""
+        g = self.G @ U
+        g3 = g.reshape((-1, 3) + g.shape[1:])
+        Xf = -g3 / np.sqrt((g3 * g3).sum(axis=1, keepdims=True))
+        phi = self._poisson.solve(np.ascontiguousarray(self.D @ Xf.reshape(g.shape)))
+        return phi - phi.min(axis=0)
+
+    def __call__(self, idx):
+        u0 = np.zeros(self.n)
+        u0[idx] = 1.0
+        return self._field(self._heat.solve(u0))
+
+    def solve_many(self, idxs):
+        """Distances from each vertex in ``idxs``: (len(idxs), n).  One multi-RHS solve per
+        distinct vertex set (repeated indices are solved once)."""
+        idxs = np.asarray(idxs, dtype=np.int64)
+        uniq, inv = np.unique(idxs, return_inverse=True)
+        E = np.zeros((self.n, uniq.size))
+        E[uniq, np.arange(uniq.size)] = 1.0
+        phi = self._field(self._heat.solve(E))
+        return np.ascontiguousarray(phi.T[inv])

@@ -1,0 +1,263 @@
+"""``posComponents`` -- drop-in mirror of the reference class (snapbases/posComponents.py)
+for the snapshot-reduction hot path, computing on the MI355X through ``libasb_hip.so``.
+
+Same constructor (``posComponents(param)``), attribute and method names as the reference
+(:19-49 and the methods listed in SURVEY.md 8b).  ``param`` is any object exposing the
+attributes of the reference's ``Config_parameters`` that this path reads.
+
+There is no CPU path: without the HIP library / a gfx950 GPU construction fails.
+"""
+import csv
+import os
+
+import numpy as np
+from numpy import maximum, clip, sqrt, errstate, newaxis, empty, eye, allclose, dot, zeros, tensordot
+from scipy.linalg import norm, svd, orth
+
+from .distributed import Comm
+from .posSnapshots import posSnapshots
+from .utils import log_time, store_components, testSparsity, test_linear_dependency
+
+
+class posComponents:  # Components == bases
+    def __init__(self, param, pos_snapshots=None):
+        self.basesType = param.vertPos_bases_type
+        assert self.basesType == 'PCA' or self.basesType == 'SPLOCS'
+
+        if pos_snapshots is None:
+            train = os.path.join(param.aligned_snapshots_directory, param.train_aligned_snapshots_animation_file)
+            test = os.path.join(param.aligned_snapshots_directory, param.test_aligned_snapshots_animation_file)
+            pos_snapshots = posSnapshots(train, test, param.vertPos_rest_shape, param.vertPos_masses_file,
+                                         param.tet_mesh_file, param.q_standarize, param.q_massWeight)
+        self.pos_snapshots = pos_snapshots
+
+        self.numComp = param.vertPos_numComponents
+        self.support = param.q_support              # 'local' | 'global'
+        self.storeSingVal = param.store_vertPos_PCA_sing_val
+
+        self._comps = None
+        self._comps_stale = False
+        self.weigs = None
+        self.ortho_comps = None
+        self.smooth_min_dist = param.vertPos_smooth_min_dist
+        self.smooth_max_dist = param.vertPos_smooth_max_dist
+        self.output_components_file = "components.h5"
+
+        self.measures_at_largeDeforVerts = None
+        self.fileNameBases = "q_pos_"
+        self.param = param
+
+        # extras (not in the reference): the selected vertices, and per-phase wall times
+        self.selected_vertices = None
+
+    # ------------------------------------------------------------------ comps: device-resident, lazy download
+    @property
+    def comps(self):
+        if self._comps is None and self._comps_stale:
+            eng, comm = self.pos_snapshots._engine, self.pos_snapshots._comm
+            loc = eng.results(want_comps=True, want_weigs=False)["comps"]
+            self._comps = comm.all_gather_rows(loc, self.pos_snapshots.nVerts, axis=1)
+            self._comps_stale = False
+        return self._comps
+
+    @comps.setter
+    def comps(self, value):
+        self._comps = value
+        self._comps_stale = False
+
+    # ------------------------------------------------------------------ statics (same as the reference)
+    @staticmethod
+    def project_weight(x):
+        """posComponents.py:52-58."""
+        x = maximum(0., x)
+        max_x = x.max()
+        if max_x == 0:
+            return x
+        else:
+            return x / max_x
+
+    @staticmethod
+    def compute_support_map(idx, geodesics, min_dist, max_dist):
+        """posComponents.py:61-64."""
+        phi = geodesics(idx)
+        return (clip(phi, min_dist, max_dist) - min_dist) / (max_dist - min_dist)
+
+    @staticmethod
+    def prox_l1l2(Lambda, x, beta):
+        """posComponents.py:252-256."""
+        xlen = sqrt((x ** 2).sum(axis=-1))
+        with errstate(divide='ignore'):
+            shrinkage = maximum(0.0, 1 - beta * Lambda / xlen)
+        return x * shrinkage[..., newaxis]
+
+    # ------------------------------------------------------------------ the hot path
+    @log_time("")
+    def extract_k_components(self, writer, num_iters_max=20, num_admm_iterations=10):
+        """posComponents.py:67-129 on the GPU.
+
+        support='global' on one rank runs all K components back to back on the device;
+        support='local' (host geodesic support map between select and apply) and multi-rank
+        runs step through select -> [all-gather] -> pick -> apply per component.
+        """
+        snaps = self.pos_snapshots
+        eng, comm = snaps._engine, snaps._comm
+        K = self.numComp
+        local = self.support == 'local'
+        if local and snaps.compute_geodesic_distance is None:
+            raise ValueError("support='local' needs the mesh triangles (geodesic support maps)")
+        eng.deflate_begin(K, local)
+        v0, n_loc = snaps._shards[comm.rank]
+
+        if comm.world == 1 and not local:
+            eng.run_global(0, K)
+        else:
+            rec = recs = None
+            if comm.world > 1:
+                rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
+            for k in range(K):
+                if comm.world > 1:
+                    eng.local_best(k, rec.data_ptr())
+                    comm.all_gather_records(rec, recs)
+                    eng.pick(k, recs.data_ptr(), comm.world)
+                else:
+                    eng.pick(k)
+                s_loc = None
+                if local:
+                    idx, _ = eng.get_pick(k)
+                    s = 1 - self.compute_support_map(idx, snaps.compute_geodesic_distance,
+                                                     self.smooth_min_dist, self.smooth_max_dist)      # (N,)
+                    s_loc = s[v0:v0 + n_loc]
+                eng.apply(k, s_loc)
+
+        res = eng.results(want_comps=False, want_weigs=True)
+        normR = np.sqrt(comm.allreduce_sum(res["normR2_local"]))
+        self.weigs = res["weigs"]
+        self.selected_vertices = res["idx"]
+        self._comps, self._comps_stale = None, True
+        self.measures_at_largeDeforVerts = np.column_stack([np.arange(K, dtype=np.float64), res["sigma"], normR])
+        if self.storeSingVal and writer is not None:
+            for k in range(K):
+                writer.writerow([k, float(res["sigma"][k]), float(normR[k])])
+
+        if self.basesType == 'SPLOCS':
+            self.splocs_glob_optimization(self.param.splocs_max_itrs, self.param.splocs_admm_num_itrs,
+                                          None, snaps.compute_geodesic_distance)
+        print("Computed '", self.basesType, "' bases size ", (K, snaps.nVerts, 3))
+
+    @log_time("")
+    def splocs_glob_optimization(self, num_iters_max, num_admm_iterations, R, compute_geodesic_distance):
+        """posComponents.py:131-189 -- device implementation pending."""
+        raise NotImplementedError("SPLOCS refinement on the GPU is not built yet; there is no CPU fallback")
+
+    @log_time("")
+    def compute_components_store_singvalues(self):
+        """posComponents.py:258-272."""
+        headerSing = ['component', 'singVal', 'norm_R']
+        file_name = os.path.join(self.param.vertPos_output_directory,
+                                 self.param.name + "_posBases_pcaExtraction_singValues_errorNorm")
+        if self.storeSingVal:
+            if self.pos_snapshots._comm.rank == 0:
+                with open(file_name + '.csv', 'w', encoding='UTF8') as singFile:
+                    writer = csv.writer(singFile)
+                    writer.writerow(headerSing)
+                    self.extract_k_components(writer)
+            else:
+                self.extract_k_components(None)
+        else:
+            self.extract_k_components(None)
+
+    @log_time("")
+    def post_process_components(self):
+        """posComponents.py:274-302."""
+        print("Post-processing pos components ...")
+        snaps = self.pos_snapshots
+        eng, comm = snaps._engine, snaps._comm
+        v0, n_loc = snaps._shards[comm.rank]
+        inv = None
+        if self.param.q_massWeight and not self.param.q_orthogonal:
+            assert snaps.nVerts == snaps.invMassL.shape[0]
+            inv = snaps.invMassL[v0:v0 + n_loc]
+        if self._comps is not None and not self._comps_stale:
+            raise NotImplementedError("post-processing host-assigned comps is not supported; "
+                                      "run extract_k_components first")
+        loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, inv)
+        self._comps = comm.all_gather_rows(loc, snaps.nVerts, axis=1)
+        self._comps_stale = False
+        if self.param.q_orthogonal:
+            raise NotImplementedError("q_orthogonal: device orthogonalisation is not built yet (SURVEY.md 8f-1)")
+
+        testSparsity(self.comps)
+        test_linear_dependency(self.comps, 3, self.numComp)
+        print("... Volkwein (" + str(self.param.q_massWeight) + ")... standerized (" + str(self.param.q_standarize) +
+              ")... support (" + str(self.support) + "), orthogonalized (" + str(self.param.q_orthogonal) + ").")
+
+    @log_time("")
+    def is_utmu_orthogonal(self):
+        """posComponents.py:304-313."""
+        print('... testing M orthogonality, U^T M U = I (K x K) ...', end='', flush=True)
+        for l in range(self.comps.shape[2]):
+            Mu_l = self.comps[:, :, l].T * self.pos_snapshots.mass[:, None]
+            utMu_l = dot(self.comps[:, :, l], Mu_l)
+            assert allclose(utMu_l, eye(self.comps.shape[0]))
+        print('(True).')
+
+    @log_time("")
+    def store_components_to_files(self, start, end, step, fileType):
+        """posComponents.py:315-327; fileType '.bin' or '.npy'."""
+        print('Storing bases ...', end='', flush=True)
+        numframes, numverts = self.pos_snapshots.frs, self.pos_snapshots.nVerts
+        basesFile = os.path.join(self.param.vertPos_output_directory, self.fileNameBases)
+        for k in range(start, end + 1, step):
+            store_components(basesFile, numframes, k, numverts, 3, self.comps[:k, :, :], fileType, 'K')
+        print('done.')
+
+    @log_time("")
+    def store_animations(self, output_bases_dir):
+        """posComponents.py:329-341 (needs h5py, like the reference)."""
+        import h5py
+        output_components = os.path.join(output_bases_dir, self.output_components_file)
+        with h5py.File(output_components, 'w') as f:
+            f['default'] = self.pos_snapshots.verts[0]
+            f['tris'] = self.pos_snapshots.tris
+            for i, c in enumerate(self.comps):
+                f['comp%03d' % i] = c
+
+    @log_time("")
+    def test_basesSingVals(self):
+        """posComponents.py:343-356."""
+        bases = self.comps.copy()
+        s = empty((bases.shape[0], 3))
+        for i in range(3):
+            sing = svd(bases[:, :, i], full_matrices=False, compute_uv=False)
+            s[:, i] = sing / sing.max()
+        return s
+
+    @log_time("")
+    def test_convergence(self, start, end, step, writer=None):
+        """posComponents.py:191-214."""
+        snapshots = self.pos_snapshots.snapTensor.copy()
+        fro_err, rel_err_x, rel_err_y, rel_err_z, max_err = [], [], [], [], []
+        for k in range(start, end + 1, step):
+            reconstructed = tensordot(self.weigs[:, :k], self.comps[:k, :, :], axes=([1], [0]))
+            fro_err.append(self.frobenius_error(snapshots, reconstructed))
+            rel_err = self.relative_error_per_component(snapshots, reconstructed)
+            rel_err_x.append(rel_err[0])
+            rel_err_y.append(rel_err[1])
+            rel_err_z.append(rel_err[2])
+            max_err.append(self.max_pointwise_error(snapshots, reconstructed))
+        return fro_err, max_err, rel_err_x, rel_err_y, rel_err_z
+
+    @staticmethod
+    def frobenius_error(f, f_reconstructed):
+        """posComponents.py:217-223."""
+        return norm(f - f_reconstructed)
+
+    @staticmethod
+    def relative_error_per_component(f, f_reconstructed):
+        """posComponents.py:225-237."""
+        return [norm(f[:, :, i] - f_reconstructed[:, :, i]) / norm(f[:, :, i]) for i in range(3)]
+
+    @staticmethod
+    def max_pointwise_error(f, f_reconstructed):
+        """posComponents.py:239-249."""
+        return np.max(np.abs(f - f_reconstructed)) / np.max(f)

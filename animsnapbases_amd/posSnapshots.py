@@ -1,0 +1,199 @@
+"""``posSnapshots`` -- drop-in mirror of the reference class (snapbases/posSnapshots.py)
+whose tensor work runs on the MI355X through ``libasb_hip.so``.
+
+Same constructor, attributes and method names as the reference (:33-61); the prepared
+snapshot tensor lives in HBM in the vertex-major layout and is only copied
+back when ``snapTensor`` is read.  With ``torch.distributed`` initialised the vertices are
+sharded over the ranks (one GPU each): standardisation then needs two scalar all-reduces.
+"""
+import os
+import sys
+
+import numpy as np
+
+from . import utils as _u
+from .distributed import Comm
+from .engine import HipEngine
+from .geodesic import GeodesicDistanceComputation
+from .utils import log_time
+
+
+class posSnapshots:
+    """Position snapshots: reads aligned ``(F, N, 3)`` frames, optionally mass-weights and
+    standardises them (posSnapshots.py:26-31)."""
+
+    def __init__(self, input_train_animation_file, input_test_animation_file, rest_shape, masses_file,
+                 tet_mesh_file, standarize=True, massWeight=True, *, verts=None, tris=None, test_verts=None,
+                 test_tris=None, engine=None, comm=None, device_data=None):
+        self.input_animation_file = input_train_animation_file
+        self.input_test_animation_file = input_test_animation_file
+        self.rest_shape = rest_shape            # "first" | "average"
+
+        self.verts = verts
+        self.test_verts = test_verts
+        self.tris = tris
+        self.test_tris = test_tris
+        self.frs = 0
+        self.nVerts = 0
+
+        self.mean = None
+        self.pre_scale_factor = 1
+        self.massesFile = masses_file
+
+        self.mass = None
+        self.massL = None
+        self.invMassL = None
+
+        self._snapTensor = None
+        self.compute_geodesic_distance = None
+        self.tet_mesh = tet_mesh_file
+
+        # ---- device side ----
+        self._comm = comm if comm is not None else Comm()
+        self._engine = engine
+        self._device_data = device_data         # (dev_ptr, F, N): synthetic data already in HBM (bench)
+        self._in_memory = verts is not None or device_data is not None
+        self.do_snapshots_precomputations(standarize, massWeight)
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_arrays(cls, verts, tris, rest_shape="first", masses_file="", standarize=True, massWeight=False,
+                    engine=None, comm=None, mass=None):
+        """In-memory construction (no animation files): ``verts`` (F,N,3), ``tris`` (M,3) or None."""
+        self = cls.__new__(cls)
+        self._preset_mass = mass
+        cls.__init__(self, None, None, rest_shape, masses_file, None, standarize, massWeight,
+                     verts=np.asarray(verts), tris=tris, engine=engine, comm=comm)
+        return self
+
+    @classmethod
+    def from_device(cls, dev_ptr, F, N, rest_shape="first", standarize=True, engine=None, comm=None, keepalive=None):
+        """Adopts an ``(F, N, 3)`` float64 tensor that already sits in this rank's HBM (e.g. a
+        torch tensor's ``data_ptr()``): this rank's shard of a larger problem, or all of it."""
+        self = cls.__new__(cls)
+        self._keepalive = keepalive
+        cls.__init__(self, None, None, rest_shape, "", None, standarize, False, engine=engine, comm=comm,
+                     device_data=(int(dev_ptr), int(F), int(N)))
+        return self
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def snapTensor(self):
+        """The prepared tensor in the reference layout (F, N, 3); downloaded on first use."""
+        if self._snapTensor is None and self._engine is not None and self._engine.n_loc:
+            loc = self._engine.download_snapshots()
+            self._snapTensor = self._comm.all_gather_rows(loc, self.nVerts, axis=1)
+        return self._snapTensor
+
+    @snapTensor.setter
+    def snapTensor(self, value):
+        self._snapTensor = value
+
+    # ------------------------------------------------------------------ reference methods
+    @log_time("")
+    def do_snapshots_precomputations(self, standarize, massWeight):
+        """posSnapshots.py:64-105."""
+        self.read()
+        if self._engine is None:
+            dev, stream = 0, None
+            if self._comm.world > 1:
+                import torch
+                dev = torch.cuda.current_device()
+                stream = torch.cuda.current_stream().cuda_stream
+            self._engine = HipEngine(dev, stream)
+        eng, comm = self._engine, self._comm
+
+        massL = None
+        if massWeight:
+            self.read_factorize_masses()
+            assert self.nVerts == self.massL.shape[0]
+            massL = self.massL
+
+        if self.rest_shape not in ("first", "average"):
+            print('Error! unknown rest shape: ', self.rest_shape)
+            sys.exit(1)
+
+        if self._device_data is not None:
+            ptr_, F, N = self._device_data
+            # the adopted tensor IS this rank's shard; global N is the sum over ranks
+            eng.adopt_device(ptr_, F, N, None)
+            counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * N) if comm.world > 1 else np.array([N])
+            self._shards = []
+            v0 = 0
+            for n in counts.astype(np.int64):
+                self._shards.append((v0, int(n)))
+                v0 += int(n)
+            self.nVerts = int(counts.sum())
+            eng.v0 = self._shards[comm.rank][0]
+            eng.N_glob = self.nVerts
+            self.frs = F
+        else:
+            v0, n_loc = comm.my_shard(self.nVerts)
+            self._shards = comm.shards(self.nVerts)
+            eng.upload(self.verts, v0, n_loc, massL)      # (:73, :82) copy + M^{1/2} X, vertex-major
+
+        # rest shape (:85-89); the mean row is subtracted only when standardising (:168)
+        code = 0 if self.rest_shape == "first" else 1
+        local_sum = eng.center(code, standarize)
+        self.mean = comm.all_gather_rows(eng.get_mean(), self.nVerts, axis=0)
+
+        # geodesics on the NON-weighted shape (:96-99); host SciPy
+        if self.tris is not None and self.verts is not None:
+            shape0 = self.verts[0] if self.rest_shape == "first" else np.mean(self.verts, axis=0)
+            self.compute_geodesic_distance = GeodesicDistanceComputation(shape0, self.tris)
+
+        if standarize:
+            self.standarize(_local_sum=local_sum)
+        print('Snapshots ready... Volkwein (' + str(massWeight) + '), standarized (' + str(standarize) + ').')
+
+    @log_time("")
+    def read(self):
+        """posSnapshots.py:108-121."""
+        if self._device_data is not None:
+            return
+        if not self._in_memory:
+            self.verts, self.tris = _u.read_animation(self.input_animation_file)
+        self.verts = np.asarray(self.verts).astype(float)
+        self.frs, self.nVerts, _ = self.verts.shape
+        print("Vertices: ", self.nVerts)
+        print("Faces: ", 0 if self.tris is None else self.tris.shape[0])
+        print("Frames: ", self.frs)
+        if not self._in_memory and self.input_test_animation_file:
+            self.test_verts, self.test_tris = _u.read_animation(self.input_test_animation_file)
+
+    @log_time("")
+    def read_factorize_masses(self, mass_on_tet_mesh=False):
+        """posSnapshots.py:124-160.  The reference factorises the dense N x N ``diag(mass)``
+        (Cholesky + inverse, O(N^3)); for a diagonal matrix that is sqrt / reciprocal."""
+        N = self.nVerts
+        preset = getattr(self, "_preset_mass", None)
+        if preset is not None:
+            Mass_mat = np.asarray(preset, dtype=np.float64).copy()
+        elif not self.massesFile or not os.path.exists(self.massesFile):
+            if mass_on_tet_mesh:
+                raise NotImplementedError("tet-mesh masses need libigl (out of scope, SURVEY.md section 2 #2)")
+            Mass_mat = _u.voronoi_vertex_masses(self.verts[0], self.tris)
+            Mass_mat = Mass_mat / Mass_mat.sum() * 2
+        else:
+            Mass_mat = np.zeros(N)
+            try:
+                Mass_mat = _u.read_mass_bin(self.massesFile, N)
+            except IOError:
+                print(self.massesFile + " could not be read")
+        self.mass = Mass_mat.copy()
+        self.massL = np.sqrt(Mass_mat)
+        self.invMassL = 1.0 / self.massL
+
+    @log_time("")
+    def standarize(self, _local_sum=None):
+        """posSnapshots.py:163-172: after the mean row is gone, divide by the population
+        standard deviation of ALL entries (np.std: two passes)."""
+        eng, comm = self._engine, self._comm
+        if _local_sum is None:
+            _local_sum = eng.center(0 if self.rest_shape == "first" else 1, True)
+        count = float(self.frs) * float(self.nVerts) * 3.0
+        mu = comm.allreduce_sum(_local_sum)[0] / count
+        var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
+        self.pre_scale_factor = 1 / np.sqrt(var)
+        eng.scale(self.pre_scale_factor)
+        self._snapTensor = None

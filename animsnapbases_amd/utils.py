@@ -1,0 +1,153 @@
+"""Host-side helpers on the hot path: file formats, the timing log, printed checks.
+
+Mirrors (same names, argument meaning, file bytes and printed text) the few functions of
+the reference's ``utils/utils.py`` that ``posSnapshots`` / ``posComponents`` call:
+``store_components`` :14-38, ``testSparsity`` :41-57, ``test_linear_dependency`` :60-74,
+``log_time`` :209-237.  Nothing here touches the GPU.
+"""
+import functools
+import os
+import struct
+import time
+
+import numpy as np
+from numpy.linalg import matrix_rank
+
+
+# ------------------------------------------------------------------ timing log
+_has_written = False
+
+
+def log_time(filePath):
+    """Decorator: prints and logs ``Function '<name>' executed in X.XXXX seconds.`` to
+    ``<filePath>function_timings.txt`` (first call of the process truncates, later calls
+    append) -- the format of utils/utils.py:209-237, which main.py:81 later moves to
+    ``<out>/time_logs.txt``."""
+
+    def decorator(func):
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            global _has_written
+            mode = "a" if _has_written else "w"
+            _has_written = True
+            t0 = time.time()
+            result = func(*args, **kwargs)
+            dt = time.time() - t0
+            line = "Function '%s' executed in %.4f seconds." % (func.__name__, dt)
+            print(line)
+            try:
+                with open(filePath + "function_timings.txt", mode) as fh:
+                    fh.write(line + "\n")
+            except OSError:
+                pass        # a read-only cwd must not break the computation
+            return result
+
+        return wrapper
+
+    return decorator
+
+
+# ------------------------------------------------------------------ component files
+def components_bin_bytes(basesTensor):
+    """The exact byte image the reference writes with a Python triple loop
+    (utils/utils.py:26-35): ``<i N><i 3K>`` then x-block, y-block, z-block, each K columns
+    of N little-endian doubles (column-major N x 3K)."""
+    K, N, dim = basesTensor.shape
+    body = np.ascontiguousarray(np.transpose(basesTensor, (2, 0, 1)), dtype="<f8")
+    return struct.pack("<i", N) + struct.pack("<i", dim * K) + body.tobytes()
+
+
+def store_components(fileName, F, K, N, dim, basesTensor, extension='.bin', colName='K'):
+    """utils/utils.py:14-38 (same names / files; the .bin body is written in one call)."""
+    assert basesTensor.shape == (K, N, dim)
+    if extension == '.bin':
+        with open(fileName + 'F' + str(F) + colName + str(K) + extension, 'wb') as doc0:
+            doc0.write(components_bin_bytes(basesTensor))
+    if extension == '.npy':
+        np.save(fileName + str(F) + 'K' + str(K), basesTensor)
+
+
+def read_components_bin(path):
+    """Inverse of ``store_components`` ('.bin'): returns (K, N, 3)."""
+    with open(path, "rb") as fh:
+        N, cols = struct.unpack("<ii", fh.read(8))
+        body = np.frombuffer(fh.read(), dtype="<f8")
+    K = cols // 3
+    return np.ascontiguousarray(body.reshape(3, K, N).transpose(1, 2, 0))
+
+
+# ------------------------------------------------------------------ printed checks
+def testSparsity(mat):
+    """utils/utils.py:41-57."""
+    assert mat.shape[2] == 3
+    spar = [1 - (np.count_nonzero(mat[:, :, l]) / mat[:, :, l].size) for l in range(3)]
+    if min(spar) > 0.5:
+        print("sparse, min %" + str(100 * min(spar)) + " zero entries.")
+    else:
+        print("... not sparse.")
+
+
+def test_linear_dependency(mat, test_dim_range, expected_rank):
+    """utils/utils.py:60-74."""
+    assert mat.shape[2] == 3
+    for j in range(test_dim_range):
+        rk = matrix_rank(mat[:, :, j])
+        if rk == expected_rank:
+            print(".. linear independent.")
+        else:
+            print("... not linear independent, with rank: " + str(rk) + " != " + str(expected_rank) + ".")
+
+
+# ------------------------------------------------------------------ masses
+def read_mass_bin(fileName, N):
+    """snapbases/posSnapshots.py:142-149: ``<i n><i m>`` + n doubles."""
+    with open(fileName, "rb") as fh:
+        ni, _mi = struct.unpack("<ii", fh.read(8))
+        assert ni == N
+        return np.frombuffer(fh.read(8 * N), dtype="<f8").astype(np.float64)
+
+
+def write_mass_bin(fileName, mass):
+    with open(fileName, "wb") as fh:
+        fh.write(struct.pack("<ii", len(mass), 1))
+        fh.write(np.asarray(mass, dtype="<f8").tobytes())
+
+
+def voronoi_vertex_masses(verts, tris):
+    """Mixed-Voronoi lumped vertex areas (what libigl's MASSMATRIX_TYPE_VORONOI computes,
+    used by snapbases/posSnapshots.py:137 when no mass file exists): circumcentric cells
+    for non-obtuse triangles; an obtuse triangle gives half its area to the obtuse corner
+    and a quarter to the other two.  libigl is not in this image, so this branch is pinned
+    only by its definition."""
+    verts = np.asarray(verts, dtype=np.float64)
+    n = verts.shape[0]
+    p = [verts[tris[:, i]] for i in range(3)]
+    l2 = [((p[(i + 1) % 3] - p[(i + 2) % 3]) ** 2).sum(axis=1) for i in range(3)]   # opposite edge^2
+    area = 0.5 * np.sqrt((np.cross(p[1] - p[0], p[2] - p[0]) ** 2).sum(axis=1))
+    cot = [(l2[(i + 1) % 3] + l2[(i + 2) % 3] - l2[i]) / (4 * area) for i in range(3)]
+    obtuse = [c < 0 for c in cot]
+    any_obtuse = obtuse[0] | obtuse[1] | obtuse[2]
+    mass = np.zeros(n)
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        vor = (l2[j] * cot[j] + l2[k] * cot[k]) / 8
+        mixed = np.where(obtuse[i], area / 2, area / 4)
+        mass += np.bincount(tris[:, i], np.where(any_obtuse, mixed, vor), minlength=n)
+    return mass
+
+
+# ------------------------------------------------------------------ animation files
+def read_animation(path):
+    """``verts`` (F,N,3) and ``tris`` (M,3) from ``.h5`` (reference format,
+    snapbases/posSnapshots.py:109-111; needs h5py) or ``.npz`` with the same keys."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npz":
+        with np.load(path) as d:
+            return d["verts"].astype(float), d["tris"]
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("reading %s needs h5py (not installed); store the animation as .npz with keys "
+                          "'verts' (F,N,3) and 'tris' (M,3) instead" % path) from e
+    with h5py.File(path, "r") as f:
+        return f["verts"][()].astype(float), f["tris"][()]

@@ -1,0 +1,138 @@
+/*
+ * asb.h -- C ABI of libasb_hip.so: the MI355X (gfx950) implementation of the
+ * animSnapBases snapshot-reduction hot path.
+ *
+ * The reference (ShMonem/animSnapBases) is pure Python and has NO FFI / plugin
+ * interface for this path: the drop-in boundary is the Python class
+ * API (posSnapshots / posComponents), mirrored in animsnapbases_amd/.  This header is
+ * the thin C ABI underneath it; every entry point names the reference lines whose
+ * arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: pointers, int64_t sizes, doubles.  No torch / numpy types.
+ *   - return 0 on success, a negative asb_status otherwise; text via asb_last_error().
+ *   - host buffers are caller-owned, C-contiguous, float64 / int64.
+ *   - pointers named *_dev are DEVICE pointers owned by the caller (e.g. the storage of
+ *     a torch tensor used for an RCCL collective); all other device memory belongs to
+ *     the context.
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe.
+ *   - all work is enqueued on the context's stream; calls that return host data
+ *     synchronise that stream, all others are asynchronous.
+ *
+ * Device layout ("vertex-major"): the (F, N, 3) snapshot tensor of the reference is held
+ * as rows r = 3*v + d of Fp = roundup(F, 8) doubles, row r at byte offset r*Fp*8, so that
+ * a vertex's 3 x F trajectory is one contiguous 24*Fp-byte run.  Padding entries are 0.
+ * Multi-GPU: each context owns the contiguous vertex range [v0, v0 + n_loc).
+ */
+#ifndef ASB_H
+#define ASB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASB_ABI_VERSION 1
+
+typedef struct asb_ctx asb_ctx;
+
+typedef enum asb_status {
+    ASB_OK = 0,
+    ASB_ERR_ARG = -1,      /* bad argument / wrong call order            */
+    ASB_ERR_HIP = -2,      /* HIP runtime error (text has the HIP string) */
+    ASB_ERR_NODEV = -3,    /* no usable gfx950 device                     */
+    ASB_ERR_LIMIT = -4,    /* size outside what the kernels are built for */
+    ASB_ERR_NUMERIC = -5   /* numerical breakdown (e.g. Cholesky pivot)   */
+} asb_status;
+
+/* ---------------------------------------------------------------- context ---- */
+int asb_abi_version(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream so that RCCL
+ * collectives issued by torch.distributed are ordered with the kernels), or NULL for a
+ * private stream. */
+int asb_create(int device_id, void* hip_stream, asb_ctx** out);
+void asb_destroy(asb_ctx* ctx);
+const char* asb_last_error(const asb_ctx* ctx);
+int asb_sync(asb_ctx* ctx);
+/* number of launches of the dominant streaming kernel and their total HIP-event time
+ * (ms) since the last reset; used by bench.py for the roofline figure. */
+int asb_prof_reset(asb_ctx* ctx, int enable);
+int asb_prof_get(asb_ctx* ctx, int64_t* launches, double* total_ms);
+
+/* ------------------------------------------------- snapshot preparation ------ */
+/* posSnapshots.do_snapshots_precomputations, snapbases/posSnapshots.py:64-105.
+ * X: host (F, N_glob, 3).  Uploads vertices [v0, v0+n_loc), multiplies row v by
+ * massL[v0+v] when massL != NULL (:82) and stores the vertex-major layout. */
+int asb_snapshots_upload(asb_ctx* ctx, const double* X, int64_t F, int64_t N_glob,
+                         int64_t v0, int64_t n_loc, const double* massL);
+/* Same, but X_dev is already in device memory in the reference layout (F, n_loc, 3)
+ * (synthetic benchmark inputs generated on the GPU). */
+int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc,
+                            const double* massL_loc);
+/* :85-89 + posSnapshots.standarize :168 -- mean = frame 0 (rest_shape 0) or the frame
+ * average (1); when subtract != 0 the mean row is subtracted.  local_sum = sum of all
+ * entries of the shard afterwards (for the global mean of np.std). */
+int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, double* local_sum);
+/* sum over the shard of (x - mu)^2 -- second pass of np.std, :171 */
+int asb_snapshots_sqdev(asb_ctx* ctx, double mu, double* local_sqdev);
+/* snapTensor *= pre_scale_factor, :172 */
+int asb_snapshots_scale(asb_ctx* ctx, double pre_scale_factor);
+int asb_snapshots_get_mean(asb_ctx* ctx, double* mean_out /* (n_loc,3) */);
+/* the prepared tensor back in the reference layout, out: (F, n_loc, 3) */
+int asb_snapshots_download(asb_ctx* ctx, double* out);
+
+/* ------------------------------------- greedy deflation ("PCA") -------------- */
+/* posComponents.extract_k_components, snapbases/posComponents.py:67-122.
+ *
+ * mode ASB_DEFLATE_RESIDUAL keeps the residual tensor R in HBM and updates it per
+ * component exactly as the reference does (needed for support='local').
+ * mode ASB_DEFLATE_PROJECT is the residual-free form valid for support='global':
+ * the weights w_k are mutually orthogonal there, so c_k = X^T w_k / |w_k|^2 and X is
+ * only ever READ. */
+#define ASB_DEFLATE_RESIDUAL 0
+#define ASB_DEFLATE_PROJECT 1
+int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_support);
+/* number of doubles of one exchange record: [energy, idx (int64 bits), slab 3*Fp] */
+int64_t asb_deflate_xchg_len(const asb_ctx* ctx);
+/* :78-80 on this shard: best local vertex (max residual energy, first on ties) and
+ * its 3 x F residual slab -> rec_dev (one record). */
+int asb_deflate_local_best(asb_ctx* ctx, int64_t k, double* rec_dev);
+/* :79-96: winner over n_rec records (max energy, lowest global index), rank-1 SVD of
+ * its 3 x F slab, w_k = sigma_1 * Vt[0]; with local_support also the +-projection
+ * test :90-94.  recs_dev == NULL: single rank, reads the shard directly. */
+int asb_deflate_pick(asb_ctx* ctx, int64_t k, const double* recs_dev, int64_t n_rec);
+/* selected vertex (global index) and sigma_1 of component k (synchronises) */
+int asb_deflate_get_pick(asb_ctx* ctx, int64_t k, int64_t* idx, double* sigma);
+/* :101-111: c_k = (w_k . R)[* s] / |w_k|^2, R -= w_k (x) c_k, new energies.
+ * s: host (n_loc) support factor 1 - support_map (:95), or NULL for global. */
+int asb_deflate_apply(asb_ctx* ctx, int64_t k, const double* s);
+/* components k0 .. k1-1 back to back on one rank with global support (no host round
+ * trips inside). */
+int asb_deflate_run_global(asb_ctx* ctx, int64_t k0, int64_t k1);
+/* outputs.  comps (K, n_loc, 3); weigs (F, K); idx (K) global indices; sigma (K);
+ * normR2_local (K): this shard's ||R||_F^2 after each component (:113, summed over
+ * shards and square-rooted by the caller). Any pointer may be NULL. */
+int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx,
+                        double* sigma, double* normR2_local);
+/* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
+int asb_deflate_download_residual(asb_ctx* ctx, double* out);
+
+/* ------------------------------------------------ post-processing ------------ */
+/* posComponents.post_process_components, snapbases/posComponents.py:277-292, the
+ * element-wise part, in place on the device-resident components:
+ *   unscale != 0:  comps /= pre_scale_factor; comps += mean        (:279-282)
+ *   invMassL != NULL (host, n_loc entries of this shard): comps *= invMassL[:,None] (:292)
+ * comps_out (K, n_loc, 3) may be NULL. */
+int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
+                        const double* invMassL_loc, double* comps_out);
+
+/* ------------------------------------------------ host-side probes ----------- */
+/* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
+ * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */
+void asb_test_eig3(const double* a6, double* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASB_H */

@@ -1,0 +1,191 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI behind the posSnapshots /
+posComponents mirror, against (a) golden vectors produced by the unmodified reference and
+(b) the NumPy oracle on seeded inputs.
+
+Bars (BASELINE.json north_star): selected-vertex index sequence bit-exact; basis / weights
+/ singular values within 1e-5 relative Frobenius error -- the tests hold the HIP path to
+1e-9, far inside that.  Global-support components carry LAPACK's arbitrary SVD sign and are
+compared after per-component sign alignment.
+"""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import align_signs, load_golden, relerr
+from oracle import asb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _param(g=None, **over):
+    base = dict(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                q_support="global", vertPos_numComponents=4, store_vertPos_PCA_sing_val=False,
+                vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25, vertPos_rest_shape="first",
+                name="t", vertPos_output_directory=".")
+    if g is not None:
+        for k in list(base):
+            if "param_" + k in g:
+                v = g["param_" + k]
+                base[k] = v.item() if v.ndim == 0 else v
+                if isinstance(base[k], (np.str_, bytes)):
+                    base[k] = str(base[k])
+    base.update(over)
+    return types.SimpleNamespace(**base)
+
+
+def _run(verts, tris, param, mass=None):
+    from animsnapbases_amd import posComponents, posSnapshots
+    snaps = posSnapshots.from_arrays(verts, tris, param.vertPos_rest_shape, standarize=param.q_standarize,
+                                     massWeight=param.q_massWeight, mass=mass)
+    comp = posComponents(param, snaps)
+    comp.compute_components_store_singvalues()
+    return snaps, comp
+
+
+def test_library_is_the_hip_one():
+    from animsnapbases_amd import HipEngine
+    e = HipEngine(0)
+    assert e.lib.asb_abi_version() == 1
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["pca_global_small", "pca_global_nostd", "pca_global_medium",
+                                  "pca_global_avg_mass_orth"])
+def test_global_deflation_vs_reference_golden(name, tmp_path):
+    g = load_golden(name)
+    param = _param(g, q_orthogonal=False, store_vertPos_PCA_sing_val=True, vertPos_output_directory=str(tmp_path))
+    mass = g["mass"] if bool(g["param_q_massWeight"]) else None
+    snaps, comp = _run(g["verts"], g["tris"], param, mass)
+    assert relerr(snaps.mean, g["mean"]) < 1e-13
+    assert abs(snaps.pre_scale_factor - float(g["pre_scale_factor"])) < 1e-12 * float(g["pre_scale_factor"])
+    if "snapTensor" in g:
+        assert relerr(snaps.snapTensor, g["snapTensor"]) < 1e-13
+    assert comp.selected_vertices.tolist() == g["idx"].tolist()          # bit-exact index selection
+    comps, weigs = align_signs(comp.comps, comp.weigs, g["comps"])
+    assert relerr(comps, g["comps"]) < TOL
+    assert relerr(weigs, g["weigs"]) < TOL
+    assert relerr(comp.measures_at_largeDeforVerts, g["measures"]) < TOL
+    # CSV: same header and rows as the reference's file
+    lines = open(str(tmp_path / "t_posBases_pcaExtraction_singValues_errorNorm.csv")).read().splitlines()
+    assert lines[0] == "component,singVal,norm_R"
+    rows = np.array([[float(x) for x in ln.split(",")] for ln in lines[1:] if ln])
+    assert relerr(rows, g["measures"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["pca_global_small", "pca_global_nostd"])
+def test_post_process_and_bin_vs_reference_golden(name, tmp_path):
+    g = load_golden(name)
+    param = _param(g, vertPos_output_directory=str(tmp_path))
+    snaps, comp = _run(g["verts"], g["tris"], param)
+    signs = np.array([1.0 if np.vdot(comp.comps[k], g["comps"][k]) >= 0 else -1.0 for k in range(comp.numComp)])
+    comp.post_process_components()
+    # a sign flip of comps[k] before "+ mean" is not a flip afterwards: undo it in the standardised space
+    std = bool(g["param_q_standarize"])
+    got = comp.comps.copy()
+    if std:
+        got = (got - snaps.mean[None]) * signs[:, None, None] + snaps.mean[None]
+    else:
+        got = got * signs[:, None, None]
+    assert relerr(got, g["comps_post"]) < TOL
+    K = comp.numComp
+    comp.store_components_to_files(K, K, 1, ".bin")
+    from animsnapbases_amd.utils import read_components_bin
+    back = read_components_bin(str(tmp_path / str(g["bin_name"])))
+    assert np.array_equal(back, comp.comps)
+
+
+def test_local_support_vs_reference_golden():
+    g = load_golden("pca_local_small")
+    param = _param(g)
+    snaps, comp = _run(g["verts"], g["tris"], param)
+    assert comp.selected_vertices.tolist() == g["idx"].tolist()
+    # local support canonicalises the sign through the +-projection test: no alignment
+    assert relerr(comp.weigs, g["weigs"]) < TOL
+    assert relerr(comp.comps, g["comps"]) < 1e-8
+    assert relerr(comp.measures_at_largeDeforVerts, g["measures"]) < 1e-8
+    assert (comp.weigs >= 0).all() and np.allclose(comp.weigs.max(axis=0), 1.0)
+
+
+@pytest.mark.parametrize("rings,segs,F,K,rest,seed", [
+    (5, 7, 13, 3, "first", 0),        # ragged: N = 37, F = 13 (not multiples of anything)
+    (9, 11, 200, 8, "average", 1),    # F = 200 -> one wave per vertex
+    (4, 6, 1000, 6, "first", 2),      # F = 1000 -> 128 threads per vertex
+    (3, 5, 2000, 5, "first", 3),      # F = 2000 -> 256 threads per vertex (config-4 row length)
+    (3, 4, 4100, 4, "first", 4),      # 1024 threads per vertex
+    (2, 3, 9000, 3, "first", 5),      # E2 = 8 variant
+])
+def test_global_deflation_vs_oracle_shapes(rings, segs, F, K, rest, seed):
+    rest_v, tris = orc.synth_mesh(rings, segs, seed=seed)
+    verts = orc.synth_snapshots(rest_v, F, rank=6, seed=seed)
+    param = _param(vertPos_numComponents=K, vertPos_rest_shape=rest)
+    snaps, comp = _run(verts, tris, param)
+    pre = orc.prepare_snapshots(verts, rest, True)
+    ref = orc.extract_k_components(pre["snapTensor"], K)
+    assert relerr(snaps.snapTensor, pre["snapTensor"]) < 1e-12
+    assert comp.selected_vertices.tolist() == ref["idx"].tolist()
+    comps, weigs = align_signs(comp.comps, comp.weigs, ref["comps"])
+    assert relerr(comps, ref["comps"]) < TOL
+    assert relerr(weigs, ref["weigs"]) < TOL
+    assert relerr(comp.measures_at_largeDeforVerts, ref["measures"]) < TOL
+    # residual after K components equals the oracle's
+    R = snaps._engine.download_residual()
+    assert relerr(R, ref["R"]) < 1e-8
+
+
+def test_stepwise_equals_fused_and_ties_pick_first():
+    """pick/apply step by step == run_global; and with exactly tied energies the FIRST vertex wins
+    (NumPy argmax tie-break, posComponents.py:79)."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(5)
+    F, N = 24, 50
+    X = rng.normal(size=(F, N, 3))
+    X[:, 31] = X[:, 7]          # identical trajectories -> identical energies: vertex 7 must win over 31
+    X[:, 7] *= 3
+    X[:, 31] *= 3
+    outs = []
+    for fused in (True, False):
+        e = HipEngine(0)
+        e.upload(X, 0, N)
+        e.deflate_begin(4, False)
+        if fused:
+            e.run_global(0, 4)
+        else:
+            for k in range(4):
+                e.pick(k)
+                e.apply(k)
+        outs.append(e.results())
+        e.close()
+    assert outs[0]["idx"].tolist() == outs[1]["idx"].tolist()
+    assert np.array_equal(outs[0]["comps"], outs[1]["comps"])
+    assert outs[0]["idx"][0] == 7
+    ref = orc.extract_k_components(X, 4)
+    assert outs[0]["idx"].tolist() == ref["idx"].tolist()
+
+
+def test_global_properties_full_row_length():
+    """Size-independent properties at a config-4-like row length (F = 2000) on a mid-size shard:
+    W columns mutually orthogonal, X = W C^T + R, ||R|| as recorded, energies non-increasing."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(11)
+    F, N, K = 2000, 3000, 12
+    X = rng.uniform(-1, 1, size=(F, N, 3))
+    e = HipEngine(0)
+    e.upload(X, 0, N)
+    e.deflate_begin(K, False)
+    e.run_global(0, K)
+    r = e.results()
+    R = e.download_residual()
+    e.close()
+    W, C = r["weigs"], r["comps"]
+    G = W.T @ W
+    off = G - np.diag(np.diag(G))
+    assert np.abs(off).max() < 1e-9 * np.diag(G).min()
+    rec = np.tensordot(W, C, (1, 0)) + R
+    assert relerr(rec, X) < 1e-13
+    assert abs(np.sqrt(r["normR2_local"][-1]) - np.linalg.norm(R)) < 1e-10 * np.linalg.norm(R)
+    assert (np.diff(r["normR2_local"]) <= 0).all()
+    # the selected vertex really had the largest residual energy at step 0
+    assert r["idx"][0] == int(np.argmax((X ** 2).sum(axis=(0, 2))))
+    assert len(set(r["idx"].tolist())) == K

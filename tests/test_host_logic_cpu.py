@@ -1,0 +1,73 @@
+"""CPU: host-side logic of the product that does not need the GPU -- file formats,
+geodesics, partitioning -- against the golden vectors / the oracle."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from animsnapbases_amd import GeodesicDistanceComputation, partition
+from animsnapbases_amd import utils as U
+from animsnapbases_amd.posComponents import posComponents
+from oracle import asb_oracle as orc
+
+
+@pytest.mark.parametrize("name", ["pca_global_small", "pca_global_avg_mass_orth", "pca_local_small"])
+def test_bin_bytes_match_reference(name, tmp_path):
+    g = load_golden(name)
+    comps = g["comps_post"]
+    K, N, _ = comps.shape
+    F = g["verts"].shape[0]
+    prefix = str(tmp_path / "q_pos_")
+    U.store_components(prefix, F, K, N, 3, comps, ".bin", "K")
+    U.store_components(prefix, F, K, N, 3, comps, ".npy", "K")
+    raw = open(str(tmp_path / str(g["bin_name"])), "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == str(g["bin_sha256"])
+    assert np.array_equal(np.load(str(tmp_path / str(g["npy_name"]))), comps)
+    assert np.array_equal(U.read_components_bin(str(tmp_path / str(g["bin_name"]))), comps)
+
+
+def test_geodesics_match_reference_and_oracle():
+    g = load_golden("pca_local_small")
+    geo = GeodesicDistanceComputation(g["verts"][0], g["tris"])
+    phis = g["geo_phi_deflation"]
+    for i, idx in enumerate(g["geo_idx"][:phis.shape[0]]):
+        assert relerr(geo(int(idx)), phis[i]) < 1e-9
+    many = geo.solve_many(g["geo_idx"][:phis.shape[0]])
+    assert relerr(many, phis) < 1e-9
+    o = orc.Geodesics(g["verts"][0], g["tris"])
+    assert relerr(geo(7), o(7)) < 1e-9
+
+
+def test_statics_match_oracle():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=50)
+    assert np.array_equal(posComponents.project_weight(x), orc.project_weight(x))
+    assert np.array_equal(posComponents.project_weight(-np.abs(x)), np.zeros(50))
+    Lam = rng.uniform(0, 2, size=(4, 9))
+    c = rng.normal(size=(4, 9, 3))
+    c[1, 2] = 0.0          # zero-length group: shrink * 0 stays 0, no NaN
+    assert np.array_equal(posComponents.prox_l1l2(Lam, c, 0.1), orc.prox_l1l2(Lam, c, 0.1))
+
+
+def test_partition():
+    assert partition(10, 1) == [(0, 10)]
+    assert partition(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    sh = partition(100000, 8)
+    assert sum(n for _, n in sh) == 100000 and all(sh[i][0] + sh[i][1] == sh[i + 1][0] for i in range(7))
+
+
+def test_mass_bin_roundtrip(tmp_path):
+    m = np.random.default_rng(0).uniform(0.1, 1, 17)
+    p = str(tmp_path / "m.bin")
+    U.write_mass_bin(p, m)
+    assert np.array_equal(U.read_mass_bin(p, 17), m)
+    assert np.array_equal(orc.read_mass_bin(p, 17), m)
+
+
+def test_voronoi_masses_sum_to_area():
+    V, T = orc.synth_mesh(8, 12, seed=0)
+    m = U.voronoi_vertex_masses(V, T)
+    area = 0.5 * np.linalg.norm(np.cross(V[T[:, 1]] - V[T[:, 0]], V[T[:, 2]] - V[T[:, 0]]), axis=1).sum()
+    assert abs(m.sum() - area) < 1e-12 * area and (m > 0).all()
