@@ -35,8 +35,8 @@ class posComponents:  # Components == bases
         self.support = param.q_support              # 'local' | 'global'
         self.storeSingVal = param.store_vertPos_PCA_sing_val
 
-        self._comps = None
-        self._comps_stale = False
+        self._comps = None            # host copy (cache of the device-resident basis, or user-assigned)
+        self._comps_on_device = False  # True: the authoritative (K, n_loc, 3) basis is in HBM
         self.weigs = None
         self.ortho_comps = None
         self.smooth_min_dist = param.vertPos_smooth_min_dist
@@ -53,17 +53,16 @@ class posComponents:  # Components == bases
     # ------------------------------------------------------------------ comps: device-resident, lazy download
     @property
     def comps(self):
-        if self._comps is None and self._comps_stale:
+        if self._comps is None and self._comps_on_device:
             eng, comm = self.pos_snapshots._engine, self.pos_snapshots._comm
             loc = eng.results(want_comps=True, want_weigs=False)["comps"]
             self._comps = comm.all_gather_rows(loc, self.pos_snapshots.nVerts, axis=1)
-            self._comps_stale = False
         return self._comps
 
     @comps.setter
     def comps(self, value):
         self._comps = value
-        self._comps_stale = False
+        self._comps_on_device = False
 
     # ------------------------------------------------------------------ statics (same as the reference)
     @staticmethod
@@ -133,7 +132,7 @@ class posComponents:  # Components == bases
         normR = np.sqrt(comm.allreduce_sum(res["normR2_local"]))
         self.weigs = res["weigs"]
         self.selected_vertices = res["idx"]
-        self._comps, self._comps_stale = None, True
+        self._comps, self._comps_on_device = None, True
         self.measures_at_largeDeforVerts = np.column_stack([np.arange(K, dtype=np.float64), res["sigma"], normR])
         if self.storeSingVal and writer is not None:
             for k in range(K):
@@ -177,12 +176,11 @@ class posComponents:  # Components == bases
         if self.param.q_massWeight and not self.param.q_orthogonal:
             assert snaps.nVerts == snaps.invMassL.shape[0]
             inv = snaps.invMassL[v0:v0 + n_loc]
-        if self._comps is not None and not self._comps_stale:
+        if not self._comps_on_device:
             raise NotImplementedError("post-processing host-assigned comps is not supported; "
                                       "run extract_k_components first")
         loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, inv)
         self._comps = comm.all_gather_rows(loc, snaps.nVerts, axis=1)
-        self._comps_stale = False
         if self.param.q_orthogonal:
             raise NotImplementedError("q_orthogonal: device orthogonalisation is not built yet (SURVEY.md 8f-1)")
 

@@ -68,7 +68,7 @@ def test_global_deflation_vs_reference_golden(name, tmp_path):
     assert relerr(weigs, g["weigs"]) < TOL
     assert relerr(comp.measures_at_largeDeforVerts, g["measures"]) < TOL
     # CSV: same header and rows as the reference's file
-    lines = open(str(tmp_path / "t_posBases_pcaExtraction_singValues_errorNorm.csv")).read().splitlines()
+    lines = open(str(tmp_path / (param.name + "_posBases_pcaExtraction_singValues_errorNorm.csv"))).read().splitlines()
     assert lines[0] == "component,singVal,norm_R"
     rows = np.array([[float(x) for x in ln.split(",")] for ln in lines[1:] if ln])
     assert relerr(rows, g["measures"]) < TOL
