@@ -41,7 +41,7 @@ def cpu_baseline(F, N, K, budget_s=20.0):
     from oracle import asb_oracle as orc
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_s = max(256, min(N, N // 20))
+    n_s = max(256, min(N, N // 5))
     k_s = 2
     rng = np.random.default_rng(7)
     X = rng.uniform(-1, 1, size=(F, n_s, 3))
@@ -49,7 +49,7 @@ def cpu_baseline(F, N, K, budget_s=20.0):
     t0 = time.perf_counter()
     orc.extract_k_components(X, 1)                 # warm-up (BLAS threads, page faults)
     t_one = time.perf_counter() - t0
-    k_s = int(max(2, min(8, budget_s / max(t_one, 1e-3))))
+    k_s = int(max(2, min(K, budget_s / max(t_one, 1e-3))))
     t0 = time.perf_counter()
     orc.extract_k_components(X, k_s)
     dt = time.perf_counter() - t0
