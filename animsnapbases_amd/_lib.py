@@ -43,6 +43,7 @@ PROTOTYPES = {
     "asb_deflate_apply": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_deflate_run_global": (c_int, [ctypes.c_void_p, c_i64, c_i64]),
     "asb_deflate_results": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_post": (c_int, [ctypes.c_void_p, c_int, c_dbl, c_dp, c_dp]),
     "asb_test_eig3": (None, [c_dp, c_dp]),

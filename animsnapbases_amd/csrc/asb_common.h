@@ -11,6 +11,20 @@
 
 #include "asb.h"
 
+// Device-resident state of one panel of the projection path (asb_project.hip).
+struct PanelState {
+    double theta;          // upper bound on the energy of every NON-candidate vertex
+    double margin;         // absolute safety margin on that bound (rounding of the energy recurrence)
+    long long done;        // set when the best candidate can no longer be proven to be the global arg-max
+    long long committed;   // components committed in this panel
+    long long n_cand;
+    long long pad;
+};
+
+struct StreamCfg {
+    int T, E2, block, vpb;
+};
+
 struct asb_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -44,11 +58,35 @@ struct asb_ctx {
     double* scal = nullptr;     // (K+1, 4): sigma, |w|^2, idx bits, local ||R||^2 after comp k
     double* xrec = nullptr;     // one exchange record
 
+    // ---- projection (panel) path, asb_project.hip ----
+    int n_cu = 256;
+    StreamCfg cfg{};
+    int64_t m_target = 0, m_cap = 0;   // candidate-set size aimed for / capacity
+    double* Wt = nullptr;        // (Fp, 16) panel weights, frame-major (MFMA B operand order)
+    double* wn2t = nullptr;      // (16) |w_t|^2 of the panel
+    double* candR = nullptr;     // (m_cap, 3, Fp) exact residual rows of the candidates
+    double* cand_e = nullptr;    // (m_cap)
+    double* cand_c = nullptr;    // (m_cap, 3) scratch
+    long long* cand_idx = nullptr;
+    double* cpmax = nullptr;     // partial records of passes over the candidate buffer
+    long long* cpidx = nullptr;
+    double* cpsum = nullptr;
+    int cnblk = 0;
+    double* colpart = nullptr;   // (blocks, 16)
+    int* hist = nullptr;
+    PanelState* pstate = nullptr;
+    int64_t n_panels = 0, n_refresh = 0;
+
     // ---- profiling of the dominant streaming kernel ----
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
 };
+
+// projection path entry points (asb_project.hip), dispatched on ctx->mode
+int asb_project_begin(asb_ctx* ctx, int64_t K);
+int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
+int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local);
 
 #define ASB_FAIL(ctx, code, ...)                                   \
     do {                                                           \

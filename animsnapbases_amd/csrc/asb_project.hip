@@ -1,0 +1,652 @@
+// Residual-free "panel" form of the greedy deflation for support='global' --
+// posComponents.extract_k_components, snapbases/posComponents.py:67-122.  gfx950 only.
+//
+// With global support every deflation is an orthogonal projection, the weights w_k are
+// mutually orthogonal and
+//       c_k = X^T w_k / |w_k|^2,     R_k = X - sum_{j<k} w_j (x) c_j,
+//       energy_k[v] = |X_v|^2 - sum_{j<k} |w_j|^2 |c_j[v]|^2          (non-increasing in k)
+// so X is never modified.  The K strictly sequential arg-max / SVD steps only ever need
+// the residual rows of the few vertices that can still win.  Per panel:
+//   1. threshold tau such that ~M vertices have energy > tau          (k_hist / k_tau)
+//   2. those candidates' residual rows are rebuilt EXACTLY in a compact buffer
+//      (X_v - sum_j c_j[v] w_j), everyone else is bounded by tau      (k_compact / k_gather)
+//   3. up to 16 greedy steps run on the compact buffer alone (the same k_pick / k_stream
+//      kernels as the residual path); a step is committed only while the best candidate's
+//      exact energy beats tau + margin, i.e. while it is provably the global arg-max
+//   4. ONE pass over X projects every vertex on the panel's new weights with f64 MFMA
+//      (Y = X . W_panel, 16 columns): c_k for all vertices, energies -= |w|^2 |c|^2
+//                                                                     (k_project_mfma)
+// HBM traffic: one read of X per PANEL instead of a read + write of R per COMPONENT.
+#include "asb_kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define ASB_NBINS 2048
+#define ASB_PANEL_COLS 16
+
+// layout of ctx->scalar_dev (doubles)
+enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7 };
+
+// --------------------------------------------------------------------------------------
+// k_gather: item s -> vertex v = idx_map[s] - v0 (or s); rebuilds its residual row
+//   R_v = X_v - sum_{j<k0} w_j (x) c_j[v]   exactly, optionally stores it (dst) and
+// always returns its energy (+ per-block max / first index / sum).
+// --------------------------------------------------------------------------------------
+template <int T, int E2>
+__global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
+    const double* __restrict__ X, const long long* __restrict__ idx_map, long long v0, long long n_items,
+    const PanelState* __restrict__ panel, const double* __restrict__ comps, long long comp_stride,
+    const double* __restrict__ W, int k0, int F2, double* __restrict__ dst, double* __restrict__ energy_out,
+    double* __restrict__ pmax, long long* __restrict__ pidx, double* __restrict__ psum) {
+    constexpr int BLOCK = (T >= 256 ? T : 256);
+    constexpr int VPB = BLOCK / T;
+    constexpr int NW = T / 64;
+    const int tid = threadIdx.x, g = tid / T, t = tid % T, wig = t >> 6, lane = tid & 63;
+    __shared__ double red[VPB][NW];
+    __shared__ double lead_e[VPB];
+    __shared__ long long lead_i[VPB];
+    __shared__ double lead_s[VPB];
+    if (panel != nullptr && panel->n_cand < n_items) n_items = panel->n_cand;
+    double bmax = -1.0, bsum = 0.0;
+    long long bidx = 0x7fffffffffffffffLL;
+    for (long long base = (long long)blockIdx.x * VPB; base < n_items; base += (long long)gridDim.x * VPB) {
+        const long long s = base + g;
+        const bool valid = s < n_items;
+        const long long v = valid ? (idx_map ? idx_map[s] - v0 : s) : 0;
+        const double2* row = reinterpret_cast<const double2*>(X) + v * 3 * (long long)F2;
+        double2 x[3][E2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int i = 0; i < E2; ++i) {
+                const int j = t + i * T;
+                x[d][i] = (valid && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
+            }
+        for (int q = 0; q < k0; ++q) {
+            const double* cq = comps + (long long)q * comp_stride + v * 3;
+            const double c0 = cq[0], c1 = cq[1], c2 = cq[2];
+            const double2* wq = reinterpret_cast<const double2*>(W) + (long long)q * F2;
+#pragma unroll
+            for (int i = 0; i < E2; ++i) {
+                const int j = t + i * T;
+                const double2 w = (j < F2) ? wq[j] : make_double2(0.0, 0.0);
+                x[0][i].x -= w.x * c0; x[0][i].y -= w.y * c0;
+                x[1][i].x -= w.x * c1; x[1][i].y -= w.y * c1;
+                x[2][i].x -= w.x * c2; x[2][i].y -= w.y * c2;
+            }
+        }
+        double e = 0.0;
+        double2* out = dst ? reinterpret_cast<double2*>(dst) + s * 3 * (long long)F2 : nullptr;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int i = 0; i < E2; ++i) {
+                const int j = t + i * T;
+                if (out && valid && j < F2) out[(long long)d * F2 + j] = x[d][i];
+                e += x[d][i].x * x[d][i].x + x[d][i].y * x[d][i].y;
+            }
+        e = wave_sum(e);
+        if (NW > 1) {
+            __syncthreads();
+            if (lane == 0) red[g][wig] = e;
+            __syncthreads();
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) sum += red[g][q];
+            e = sum;
+        }
+        if (t == 0 && valid) {
+            energy_out[s] = e;
+            bsum += e;
+            if (am_better(e, s, bmax, bidx)) { bmax = e; bidx = s; }
+        }
+    }
+    if (t == 0) { lead_e[g] = bmax; lead_i[g] = bidx; lead_s[g] = bsum; }
+    __syncthreads();
+    if (tid == 0) {
+        double be = lead_e[0], bs = lead_s[0];
+        long long bi = lead_i[0];
+#pragma unroll
+        for (int q = 1; q < VPB; ++q) {
+            bs += lead_s[q];
+            if (am_better(lead_e[q], lead_i[q], be, bi)) { be = lead_e[q]; bi = lead_i[q]; }
+        }
+        pmax[blockIdx.x] = be; pidx[blockIdx.x] = bi; psum[blockIdx.x] = bs;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// threshold selection: two-level histogram of the energies, all on the device
+// --------------------------------------------------------------------------------------
+// reduces the per-block maxima of the last pass: sc[SC_EMAX]; level-1 range [0, Emax];
+// first = 1 also records the initial maximum and the total (|X|^2).
+__global__ __launch_bounds__(256) void k_range_init(const double* pmax, const long long* pidx, const double* psum,
+                                                    int nblk, double* __restrict__ sc, int first) {
+    __shared__ double sh_d[512];
+    __shared__ long long sh_i[256];
+    double be, bs;
+    long long bi;
+    reduce_partials(pmax, pidx, psum, nblk, sh_d, sh_i, be, bi, bs);
+    if (threadIdx.x == 0) {
+        sc[SC_EMAX] = be;
+        sc[SC_LO] = 0.0;
+        sc[SC_HI] = be;
+        sc[SC_ABOVE] = 0.0;
+        if (first) { sc[SC_NORMX2] = bs; sc[SC_E0MAX] = be; }
+    }
+}
+
+// hist[b] = #{ lo <= e < hi falling in bin b }, the top edge is inclusive at level 1
+__global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long long n, const double* __restrict__ sc,
+                                              int* __restrict__ hist, int top_inclusive) {
+    __shared__ int lh[ASB_NBINS];
+    for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const double lo = sc[SC_LO], hi = sc[SC_HI];
+    const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double e = E[i];
+        if (e < lo || e > hi || (!top_inclusive && e >= hi)) continue;
+        int b = (int)((e - lo) * scale);
+        if (b > ASB_NBINS - 1) b = ASB_NBINS - 1;
+        atomicAdd(&lh[b], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// level 1: find the bin where the count from the top reaches m_target -> next range.
+// level 2: final tau (lower edge of the crossing bin; upper edge if that overflows m_cap).
+__global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, double* __restrict__ sc, int level,
+                                             long long m_target, long long m_cap) {
+    __shared__ int lh[ASB_NBINS];
+    for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = hist[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double lo = sc[SC_LO], hi = sc[SC_HI];
+    const double width = (hi - lo) / (double)ASB_NBINS;
+    long long acc = (long long)sc[SC_ABOVE];
+    int b = ASB_NBINS - 1;
+    for (; b >= 0; --b) {
+        if (acc + lh[b] >= m_target) break;
+        acc += lh[b];
+    }
+    if (b < 0) {                       // fewer than m_target vertices in range: take them all
+        sc[SC_TAU] = (level == 1) ? -1.0 : lo;
+        if (level == 1) { sc[SC_LO] = 0.0; sc[SC_HI] = 0.0; sc[SC_ABOVE] = (double)acc; sc[SC_TAU] = -1.0; }
+        return;
+    }
+    const double edge_lo = lo + b * width, edge_hi = (b == ASB_NBINS - 1) ? hi : lo + (b + 1) * width;
+    if (level == 1) {
+        sc[SC_LO] = edge_lo;
+        sc[SC_HI] = edge_hi;
+        sc[SC_ABOVE] = (double)acc;
+        sc[SC_TAU] = edge_lo;          // provisional
+    } else {
+        // candidates are E > tau.  Lower edge keeps the crossing bin (>= m_target candidates).
+        double tau = edge_lo;
+        if (acc + lh[b] > m_cap && acc > 0) tau = edge_hi;
+        // strict '>' in the compaction: nudge below the edge so that e == edge_lo is kept
+        sc[SC_TAU] = nextafter(tau, -1.0e300);
+    }
+}
+
+// ordered compaction (one block): cand_idx = global ids of { v : E[v] > tau } in increasing
+// order, at most m_cap of them; initialises the panel state.
+__global__ __launch_bounds__(1024) void k_compact(const double* __restrict__ E, long long n, long long v0,
+                                                  const double* __restrict__ sc, int take_all, long long m_cap,
+                                                  long long* __restrict__ cand_idx, PanelState* __restrict__ panel,
+                                                  double margin_rel) {
+    __shared__ long long cnt[1024];
+    const int tid = threadIdx.x;
+    const double tau = take_all ? -1.0e300 : sc[SC_TAU];
+    const long long seg = (n + 1023) / 1024;
+    const long long a = tid * seg, b = (a + seg < n) ? a + seg : n;
+    long long c = 0;
+    for (long long i = a; i < b; ++i) c += (E[i] > tau);
+    cnt[tid] = c;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele)
+    for (int o = 1; o < 1024; o <<= 1) {
+        long long add = (tid >= o) ? cnt[tid - o] : 0;
+        __syncthreads();
+        cnt[tid] += add;
+        __syncthreads();
+    }
+    long long pos = cnt[tid] - c;
+    const long long total = cnt[1023];
+    for (long long i = a; i < b; ++i)
+        if (E[i] > tau) {
+            if (pos < m_cap) cand_idx[pos] = v0 + i;
+            ++pos;
+        }
+    if (tid == 0) {
+        const bool overflow = total > m_cap;
+        panel->n_cand = overflow ? m_cap : total;
+        // every non-candidate has E <= tau; with dropped candidates nothing can be proven
+        panel->theta = overflow ? 1.0e300 : ((take_all || total >= n) ? -1.0e300 : tau);
+        panel->margin = margin_rel * sc[SC_E0MAX];
+        panel->done = 0;
+        panel->committed = 0;
+    }
+}
+
+// forced single step (degenerate ties): the only candidate is the first arg-max of E.
+__global__ __launch_bounds__(256) void k_force_single(const double* pmax, const long long* pidx, const double* psum,
+                                                      int nblk, long long v0, long long* __restrict__ cand_idx,
+                                                      PanelState* __restrict__ panel) {
+    __shared__ double sh_d[512];
+    __shared__ long long sh_i[256];
+    double be, bs;
+    long long bi;
+    reduce_partials(pmax, pidx, psum, nblk, sh_d, sh_i, be, bi, bs);
+    if (threadIdx.x == 0) {
+        cand_idx[0] = v0 + bi;
+        panel->n_cand = 1;
+        panel->theta = -1.0e300;
+        panel->margin = 0.0;
+        panel->done = 0;
+        panel->committed = 0;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// panel weights in B-operand order: Wt[f][t] (Fp x 16), zero columns beyond ncols
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_wt(const double* __restrict__ W, const double* __restrict__ scal,
+                                                  long long k0, int ncols, int Fp, double* __restrict__ Wt,
+                                                  double* __restrict__ wn2) {
+    const long long total = (long long)Fp * ASB_PANEL_COLS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ASB_PANEL_COLS);
+        const long long f = i / ASB_PANEL_COLS;
+        Wt[i] = (t < ncols) ? W[(k0 + t) * Fp + f] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS)
+        wn2[threadIdx.x] = (threadIdx.x < ncols) ? scal[(k0 + threadIdx.x) * 4 + 1] : 1.0;
+}
+
+// --------------------------------------------------------------------------------------
+// k_project_mfma: Y = X (rows x Fp) . Wt (Fp x 16) with v_mfma_f64_16x16x4_f64.
+//
+// Block = NWV waves; wave w owns the frame chunks [w*CPW, (w+1)*CPW) (16 frames = one
+// 128-byte line per row each) and keeps its slice of Wt in registers for the whole kernel
+// (4 doubles per chunk: lane (i = l&15, g = l>>4) holds Wt[16*chunk + 4g + j][i]).
+// Per group of 48 rows (16 vertices): each lane loads 32 B = frames 4g..4g+3 of row i
+// straight into the A-operand position (k slot g <-> frame 16*chunk + 4g + j for MFMA j),
+// 3 row tiles x CPW chunks x 4 MFMAs, then the NWV partial 48x16 tiles are summed
+// through LDS and the epilogue writes c = y / |w|^2 and E[v] -= sum y^2 / |w|^2.
+// --------------------------------------------------------------------------------------
+template <int NWV, int CPW>
+__global__ __launch_bounds__(NWV * 64) void k_project_mfma(
+    const double* __restrict__ X, long long rows, long long n_vert, int Fp, int NC, const double* __restrict__ Wt,
+    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride,
+    double* __restrict__ E, double* __restrict__ pmax, long long* __restrict__ pidx, double* __restrict__ psum,
+    double* __restrict__ colpart) {
+    constexpr int NT = NWV * 64;
+    __shared__ double red[NWV * 768];
+    __shared__ double ysh[768];
+    __shared__ double vmax_e[16];
+    __shared__ long long vmax_i[16];
+    __shared__ double vsum[16];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, g = l >> 4;
+
+    // super-chunks: NWV*CPW chunks (of 16 frames) are covered per sweep; F <= 2048 needs one sweep
+    // and the B registers are loaded once for the whole kernel, longer rows reload them per sweep
+    // (Wt stays L2-resident).
+    const int nsweep = (NC + NWV * CPW - 1) / (NWV * CPW);
+    double breg[CPW][4];
+    auto load_b = [&](int sweep) {
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int chunk = (sweep * NWV + w) * CPW + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                breg[c][j] = (chunk < NC) ? Wt[((long long)chunk * 16 + 4 * g + j) * ASB_PANEL_COLS + i] : 0.0;
+        }
+    };
+    if (nsweep == 1) load_b(0);
+    // epilogue roles: threads [0,256) write components, 16 threads own the group's vertices
+    // (energies), 16 threads own the panel's columns (norm sums); on 512+-thread blocks these
+    // sit in different waves and overlap.
+    constexpr int VBASE = (NT >= 512) ? 256 : 0, CBASE = (NT >= 512) ? 320 : 64;
+    double run_max = -1.0, run_sum = 0.0, col_acc = 0.0;
+    long long run_idx = 0x7fffffffffffffffLL;
+
+    const long long ngroups = (rows + 47) / 48;
+    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long long row0 = grp * 48;
+        d4 acc[3];
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) acc[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int sweep = 0; sweep < nsweep; ++sweep) {
+            if (nsweep > 1) load_b(sweep);
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                long long r = row0 + 16 * rt + i;
+                if (r >= rows) r = rows - 1;
+                const double* xr = X + r * Fp + 4 * g;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) {
+                    const int chunk = (sweep * NWV + w) * CPW + c;
+                    if (chunk < NC) {
+                        const double4 x = *reinterpret_cast<const double4*>(xr + (long long)chunk * 16);
+                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, breg[c][0], acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, breg[c][1], acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.z, breg[c][2], acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.w, breg[c][3], acc[rt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // C/D layout of the f64 MFMA: row = g + 4*reg, col = i
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[w * 768 + (16 * rt + g + 4 * q) * 16 + i] = acc[rt][q];
+        __syncthreads();
+        for (int o = tid; o < 768; o += NT) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) s += red[q * 768 + o];
+            ysh[o] = s;
+        }
+        __syncthreads();
+        // components: thread (col, vl) writes c[col][3v .. 3v+2]
+        if (tid < 256) {
+            const int col = tid >> 4, vl = tid & 15;
+            const long long v = grp * 16 + vl;
+            if (col < ncols && v < n_vert) {
+                const double inv = wn2[col];
+                double* dst = comps + (long long)col * comp_stride + v * 3;
+                dst[0] = ysh[(3 * vl + 0) * 16 + col] / inv;
+                dst[1] = ysh[(3 * vl + 1) * 16 + col] / inv;
+                dst[2] = ysh[(3 * vl + 2) * 16 + col] / inv;
+            }
+        }
+        if (tid >= VBASE && tid < VBASE + 16) {      // energies: E[v] -= sum_t |w_t|^2 |c_t[v]|^2
+            const int vt = tid - VBASE;
+            const long long v = grp * 16 + vt;
+            if (v < n_vert) {
+                double loss = 0.0;
+                for (int col = 0; col < ncols; ++col) {
+                    const double y0 = ysh[(3 * vt + 0) * 16 + col], y1 = ysh[(3 * vt + 1) * 16 + col],
+                                 y2 = ysh[(3 * vt + 2) * 16 + col];
+                    loss += (y0 * y0 + y1 * y1 + y2 * y2) / wn2[col];
+                }
+                double e = E[v] - loss;
+                if (e < 0.0) e = 0.0;
+                E[v] = e;
+                run_sum += e;
+                if (am_better(e, v, run_max, run_idx)) { run_max = e; run_idx = v; }
+            }
+        }
+        if (tid >= CBASE && tid < CBASE + 16) {      // per-column |w|^2 |c|_F^2 of this shard
+            const int col = tid - CBASE;
+            if (col < ncols) {
+                long long nr = rows - row0;
+                if (nr > 48) nr = 48;
+                double sq = 0.0;
+                for (int r = 0; r < (int)nr; ++r) { const double y = ysh[r * 16 + col]; sq += y * y; }
+                col_acc += sq / wn2[col];
+            }
+        }
+        __syncthreads();
+    }
+    // block partials
+    if (tid >= VBASE && tid < VBASE + 16) {
+        vmax_e[tid - VBASE] = run_max;
+        vmax_i[tid - VBASE] = run_idx;
+        vsum[tid - VBASE] = run_sum;
+    }
+    if (tid >= CBASE && tid < CBASE + 16) colpart[(long long)blockIdx.x * 16 + (tid - CBASE)] = col_acc;
+    __syncthreads();
+    if (tid == 0) {
+        double be = vmax_e[0], bs = vsum[0];
+        long long bi = vmax_i[0];
+        for (int q = 1; q < 16; ++q) {
+            bs += vsum[q];
+            if (am_better(vmax_e[q], vmax_i[q], be, bi)) { be = vmax_e[q]; bi = vmax_i[q]; }
+        }
+        pmax[blockIdx.x] = be; pidx[blockIdx.x] = bi; psum[blockIdx.x] = bs;
+    }
+}
+
+// scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
+__global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
+                                                double* __restrict__ scal) {
+    __shared__ double sh[4];
+    for (int t = 0; t < ncols; ++t) {
+        double v[1] = {0.0};
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) v[0] += colpart[(long long)b * 16 + t];
+        block_sum<1>(v, sh);
+        if (threadIdx.x == 0) scal[(k0 + t) * 4 + 3] = v[0];
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+template <int T, int E2>
+static void launch_gather_te(asb_ctx* ctx, int grid, const long long* idx_map, long long n_items, const PanelState* panel,
+                             int k0, double* dst, double* e_out, double* pm, long long* pi, double* ps) {
+    constexpr int BLOCK = (T >= 256 ? T : 256);
+    hipLaunchKernelGGL((k_gather<T, E2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->X, idx_map, (long long)ctx->v0,
+                       n_items, panel, ctx->comps, (long long)(3 * ctx->n_loc), ctx->W, k0, (int)(ctx->Fp / 2), dst,
+                       e_out, pm, pi, ps);
+}
+template <int E2>
+static void launch_gather_e(asb_ctx* ctx, int T, int grid, const long long* idx_map, long long n_items,
+                            const PanelState* panel, int k0, double* dst, double* e_out, double* pm, long long* pi,
+                            double* ps) {
+    switch (T) {
+        case 64: launch_gather_te<64, E2>(ctx, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        case 128: launch_gather_te<128, E2>(ctx, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        case 256: launch_gather_te<256, E2>(ctx, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        case 512: launch_gather_te<512, E2>(ctx, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        default: launch_gather_te<1024, E2>(ctx, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+    }
+}
+static void launch_gather(asb_ctx* ctx, const StreamCfg& c, int grid, const long long* idx_map, long long n_items,
+                          const PanelState* panel, int k0, double* dst, double* e_out, double* pm, long long* pi,
+                          double* ps) {
+    switch (c.E2) {
+        case 4: launch_gather_e<4>(ctx, c.T, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        case 8: launch_gather_e<8>(ctx, c.T, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+        default: launch_gather_e<16>(ctx, c.T, grid, idx_map, n_items, panel, k0, dst, e_out, pm, pi, ps); break;
+    }
+}
+
+template <int NWV, int CPW>
+static void launch_project_t(asb_ctx* ctx, int grid, int ncols, long long k0) {
+    hipLaunchKernelGGL((k_project_mfma<NWV, CPW>), dim3(grid), dim3(NWV * 64), 0, ctx->stream, ctx->X,
+                       (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)ctx->Fp, (int)(ctx->Fp / 16), ctx->Wt,
+                       ctx->wn2t, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc),
+                       ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart);
+}
+
+// one projection pass for components [k0, k0+ncols)
+static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
+    const int NC = (int)(ctx->Fp / 16);
+    const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
+    int grid = ctx->n_cu * ((NC <= 16) ? 2 : 1);     // persistent blocks: 1 per CU (2 for the 256-thread variant)
+    if (grid > nwg) grid = nwg;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_build_wt, dim3(64), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, k0, ncols, (int)ctx->Fp,
+                       ctx->Wt, ctx->wn2t);
+    ASB_CHECK_LAUNCH(ctx);
+    size_t slot;
+    int rc = prof_begin(ctx, slot);
+    if (rc) return rc;
+    if (NC <= 16) launch_project_t<4, 4>(ctx, grid, ncols, k0);
+    else if (NC <= 64) launch_project_t<8, 8>(ctx, grid, ncols, k0);
+    else launch_project_t<8, 16>(ctx, grid, ncols, k0);      // F > 2048: several sweeps per row group
+    ASB_CHECK_LAUNCH(ctx);
+    rc = prof_end(ctx, slot);
+    if (rc) return rc;
+    ctx->nblk = grid;
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+int asb_project_begin(asb_ctx* ctx, int64_t K) {
+    const size_t rows = (size_t)ctx->n_loc * 3;
+    int rc;
+    ctx->m_target = ctx->n_loc < 1024 ? ctx->n_loc : 1024;
+    ctx->m_cap = ctx->n_loc < 2048 ? ctx->n_loc : 2048;
+    if ((rc = asb_alloc(ctx, &ctx->energy, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->W, (size_t)K * ctx->Fp))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * rows))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scal, (size_t)(K + 1) * 4))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->xrec, (size_t)(2 + 3 * ctx->Fp)))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt, (size_t)ctx->Fp * ASB_PANEL_COLS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t, (size_t)ASB_PANEL_COLS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->candR, (size_t)ctx->m_cap * 3 * ctx->Fp))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cand_e, (size_t)ctx->m_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cand_idx, (size_t)ctx->m_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cpmax, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cpidx, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cpsum, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->colpart, (size_t)ctx->nblk_cap * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
+    // initial energies straight from X (read-only pass)
+    StreamCfg c;
+    if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    const int grid = stream_grid(ctx, c, ctx->n_loc);
+    StreamArgs a{ctx->X, nullptr, nullptr, nullptr, nullptr, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
+                 (long long)ctx->n_loc, nullptr};
+    launch_stream(ctx, c, false, grid, a);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->nblk = grid;
+    hipLaunchKernelGGL(k_range_init, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
+                       ctx->scalar_dev, 1);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// candidate selection for one panel; mode 0 normal, 1 forced single candidate
+static int panel_select(asb_ctx* ctx, long long k, int forced) {
+    const StreamCfg c = ctx->cfg;
+    const long long n = ctx->n_loc;
+    if (forced) {
+        hipLaunchKernelGGL(k_force_single, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
+                           (long long)ctx->v0, ctx->cand_idx, ctx->pstate);
+        ASB_CHECK_LAUNCH(ctx);
+    } else {
+        const int take_all = n <= ctx->m_cap;
+        if (!take_all) {
+            const int hgrid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+            hipLaunchKernelGGL(k_range_init, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
+                               ctx->scalar_dev, 0);
+            for (int level = 1; level <= 2; ++level) {
+                ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->energy, n, ctx->scalar_dev, ctx->hist,
+                                   level == 1 ? 1 : 0);
+                hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level,
+                                   (long long)ctx->m_target, (long long)ctx->m_cap);
+            }
+            ASB_CHECK_LAUNCH(ctx);
+        }
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0, ctx->scalar_dev,
+                           take_all, (long long)ctx->m_cap, ctx->cand_idx, ctx->pstate, 1.0e-11);
+        ASB_CHECK_LAUNCH(ctx);
+    }
+    // exact residual rows of the candidates
+    const int ggrid = stream_grid(ctx, c, ctx->m_cap);
+    launch_gather(ctx, c, ggrid, ctx->cand_idx, (long long)ctx->m_cap, ctx->pstate, (int)k, ctx->candR, ctx->cand_e,
+                  ctx->cpmax, ctx->cpidx, ctx->cpsum);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->cnblk = ggrid;
+    return ASB_OK;
+}
+
+// up to `steps` greedy steps on the candidate buffer; returns the number committed
+static int panel_steps(asb_ctx* ctx, long long k0, int steps, long long* committed) {
+    const StreamCfg c = ctx->cfg;
+    for (int t = 0; t < steps; ++t) {
+        const long long k = k0 + t;
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, ctx->stream, ctx->candR, ctx->cpmax, ctx->cpidx, ctx->cpsum,
+                           ctx->cnblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
+                           (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k, (long long)ctx->K, 0, ctx->pstate,
+                           ctx->cand_idx, k0);
+        const int grid = stream_grid(ctx, c, ctx->m_cap);
+        StreamArgs a{ctx->candR, ctx->W + k * ctx->Fp, ctx->scal + k * 4, nullptr, ctx->cand_c, ctx->cand_e,
+                     ctx->cpmax, ctx->cpidx, ctx->cpsum, (long long)ctx->m_cap, ctx->pstate};
+        launch_stream(ctx, c, true, grid, a);
+        ctx->cnblk = grid;
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    PanelState h;
+    ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *committed = h.committed;
+    return ASB_OK;
+}
+
+int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
+    if (!pick_cfg(ctx->Fp, ctx->cfg)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ctx->m_cap * 3))) return rc;
+    long long k = k0;
+    int stalled = 0;
+    while (k < k1) {
+        if ((rc = panel_select(ctx, k, stalled >= 2))) return rc;
+        int steps = (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
+        long long done = 0;
+        if ((rc = panel_steps(ctx, k, steps, &done))) return rc;
+        ctx->n_panels++;
+        if (done == 0) {
+            // the energy recurrence could not prove any candidate: refresh ALL energies exactly, retry;
+            // a second failure (massive exact ties) forces the first arg-max as the only candidate
+            ++stalled;
+            if (stalled > 3) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "deflation made no progress at component %lld", k);
+            const int ggrid = stream_grid(ctx, ctx->cfg, ctx->n_loc);
+            launch_gather(ctx, ctx->cfg, ggrid, nullptr, (long long)ctx->n_loc, nullptr, (int)k, nullptr, ctx->energy,
+                          ctx->pmax, ctx->pidx, ctx->psum);
+            ASB_CHECK_LAUNCH(ctx);
+            ctx->nblk = ggrid;
+            ctx->n_refresh++;
+            continue;
+        }
+        stalled = 0;
+        if ((rc = project_pass(ctx, k, (int)done))) return rc;
+        k += done;
+        ctx->k_done = k;
+    }
+    return ASB_OK;
+}
+
+int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local) {
+    const int64_t K = ctx->K;
+    std::vector<double> h((size_t)(K + 1) * 4);
+    double sc[8];
+    ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+    if (comps)
+        ASB_HIP(ctx, hipMemcpyAsync(comps, ctx->comps, (size_t)K * 3 * ctx->n_loc * sizeof(double), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    std::vector<double> hw;
+    if (weigs) {
+        hw.resize((size_t)K * ctx->Fp);
+        ASB_HIP(ctx, hipMemcpyAsync(hw.data(), ctx->W, hw.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double r2 = sc[SC_NORMX2];
+    for (int64_t k = 0; k < K; ++k) {
+        if (sigma) sigma[k] = h[k * 4 + 0];
+        if (idx) memcpy(&idx[k], &h[k * 4 + 2], 8);
+        r2 -= h[k * 4 + 3];                       // |R_k|^2 = |R_{k-1}|^2 - |w_k|^2 |c_k|^2
+        if (normR2_local) normR2_local[k] = r2;
+    }
+    if (weigs)
+        for (int64_t f = 0; f < ctx->F; ++f)
+            for (int64_t k = 0; k < K; ++k) weigs[f * K + k] = hw[(size_t)k * ctx->Fp + f];
+    return ASB_OK;
+}

@@ -136,6 +136,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
         ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    ctx->n_cu = prop.multiProcessorCount;
     ctx->nblk_cap = prop.multiProcessorCount * 8;   // grid cap for streaming passes (guide: G11)
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->pmax, (size_t)ctx->nblk_cap))) return rc;
@@ -149,11 +150,11 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
-    double** bufs[] = {&ctx->X, &ctx->mean, &ctx->pmax, &ctx->psum, &ctx->scalar_dev, &ctx->s_dev, &ctx->R,
-                       &ctx->energy, &ctx->W, &ctx->comps, &ctx->scal, &ctx->xrec};
-    for (auto b : bufs)
-        if (*b) (void)hipFree(*b);
-    if (ctx->pidx) (void)hipFree(ctx->pidx);
+    for (auto& kv : ctx->alloc_bytes) {       // every context-owned buffer was registered by asb_alloc
+        void** slot = (void**)kv.first;
+        if (*slot) (void)hipFree(*slot);
+        *slot = nullptr;
+    }
     for (auto& e : ctx->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -198,7 +199,7 @@ static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_
                  (long long)N_glob, (long long)v0, (long long)n_loc);
     if (F > 32768) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F = %lld exceeds the 32768-frame limit of the streaming kernels", (long long)F);
     ctx->F = F;
-    ctx->Fp = (F + 7) / 8 * 8;
+    ctx->Fp = (F + 15) / 16 * 16;   // rows are whole 128-byte lines; 16-frame chunks for the MFMA pass
     ctx->N_glob = N_glob;
     ctx->v0 = v0;
     ctx->n_loc = n_loc;

@@ -106,6 +106,7 @@ class HipEngine(object):
     def deflate_begin(self, K, local_support, mode=_lib.DEFLATE_RESIDUAL):
         self._ck(self.lib.asb_deflate_begin(self.h, int(K), int(mode), int(bool(local_support))))
         self.K = int(K)
+        self.mode = int(mode)
 
     def xchg_len(self):
         return int(self.lib.asb_deflate_xchg_len(self.h))
@@ -140,6 +141,11 @@ class HipEngine(object):
         nr2 = np.empty(K)
         self._ck(self.lib.asb_deflate_results(self.h, ptr(comps), ptr(weigs), ptr(idx), ptr(sigma), ptr(nr2)))
         return dict(comps=comps, weigs=weigs, idx=idx, sigma=sigma, normR2_local=nr2)
+
+    def deflate_stats(self):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return dict(panels=a.value, refreshes=b.value)
 
     def download_residual(self):
         out = np.empty((self.F, self.n_loc, 3))

@@ -14,6 +14,7 @@ import numpy as np
 from numpy import maximum, clip, sqrt, errstate, newaxis, empty, eye, allclose, dot, zeros, tensordot
 from scipy.linalg import norm, svd, orth
 
+from . import _lib
 from .distributed import Comm
 from .posSnapshots import posSnapshots
 from .utils import log_time, store_components, testSparsity, test_linear_dependency
@@ -47,8 +48,10 @@ class posComponents:  # Components == bases
         self.fileNameBases = "q_pos_"
         self.param = param
 
-        # extras (not in the reference): the selected vertices, and per-phase wall times
+        # extras (not in the reference): the selected vertices; which device algorithm to use
+        # (None = automatic, "residual", "project"; env ASB_DEFLATE_MODE overrides the default)
         self.selected_vertices = None
+        self.deflate_mode = os.environ.get("ASB_DEFLATE_MODE") or None
 
     # ------------------------------------------------------------------ comps: device-resident, lazy download
     @property
@@ -104,7 +107,14 @@ class posComponents:  # Components == bases
         local = self.support == 'local'
         if local and snaps.compute_geodesic_distance is None:
             raise ValueError("support='local' needs the mesh triangles (geodesic support maps)")
-        eng.deflate_begin(K, local)
+        # global support on one rank: residual-free panel algorithm (one read of X per panel of up to
+        # 16 components); otherwise the residual tensor is kept and updated per component.
+        mode = self.deflate_mode
+        if mode is None:
+            mode = "project" if (comm.world == 1 and not local) else "residual"
+        if mode == "project" and (local or comm.world > 1):
+            raise ValueError("deflate_mode='project' needs global support on a single rank")
+        eng.deflate_begin(K, local, _lib.DEFLATE_PROJECT if mode == "project" else _lib.DEFLATE_RESIDUAL)
         v0, n_loc = snaps._shards[comm.rank]
 
         if comm.world == 1 and not local:

@@ -20,7 +20,7 @@
  *     synchronise that stream, all others are asynchronous.
  *
  * Device layout ("vertex-major"): the (F, N, 3) snapshot tensor of the reference is held
- * as rows r = 3*v + d of Fp = roundup(F, 8) doubles, row r at byte offset r*Fp*8, so that
+ * as rows r = 3*v + d of Fp = roundup(F, 16) doubles, row r at byte offset r*Fp*8, so that
  * a vertex's 3 x F trajectory is one contiguous 24*Fp-byte run.  Padding entries are 0.
  * Multi-GPU: each context owns the contiguous vertex range [v0, v0 + n_loc).
  */
@@ -115,6 +115,9 @@ int asb_deflate_run_global(asb_ctx* ctx, int64_t k0, int64_t k1);
  * shards and square-rooted by the caller). Any pointer may be NULL. */
 int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx,
                         double* sigma, double* normR2_local);
+/* projection mode statistics of the last run: streaming passes over X (panels) and exact
+ * energy refreshes (fallback when the energy recurrence could not prove a candidate). */
+int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_refresh);
 /* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
 int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 
