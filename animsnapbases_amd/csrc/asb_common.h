@@ -73,6 +73,7 @@ struct asb_ctx {
     double* cpsum = nullptr;
     int cnblk = 0;
     double* colpart = nullptr;   // (blocks, 16)
+    double* coef = nullptr;      // (K) re-orthogonalisation coefficients
     int* hist = nullptr;
     PanelState* pstate = nullptr;
     int64_t n_panels = 0, n_refresh = 0;

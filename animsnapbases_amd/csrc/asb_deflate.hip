@@ -12,7 +12,7 @@ extern "C" void asb_test_eig3(const double* a6, double* out4) {
 // host side
 // --------------------------------------------------------------------------------------
 // one streaming pass over the residual; leaves ctx->nblk partial records
-static int stream_pass(asb_ctx* ctx, bool update, const double* wk, const double* scal_k, const double* s,
+static int stream_pass(asb_ctx* ctx, bool update, const double* wk, double* scal_k, const double* s,
                        double* ck) {
     StreamCfg c;
     if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F = %lld too large (max 32768)", (long long)ctx->F);

@@ -23,7 +23,7 @@
 // --------------------------------------------------------------------------------------
 template <int T, int E2, bool UPDATE>
 __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_stream(
-    double* __restrict__ R, const double* __restrict__ wk, const double* __restrict__ scal_k,
+    double* __restrict__ R, const double* __restrict__ wk, double* __restrict__ scal_k,
     const double* __restrict__ s, double* __restrict__ ck_out, double* __restrict__ energy,
     double* __restrict__ pmax, long long* __restrict__ pidx, double* __restrict__ psum,
     long long n_loc, int F2, const PanelState* __restrict__ panel) {
@@ -51,6 +51,24 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_stream(
             w[i] = (j < F2) ? reinterpret_cast<const double2*>(wk)[j] : make_double2(0.0, 0.0);
         }
         wn2 = scal_k[1];
+        if (panel != nullptr) {
+            // panel path: w_k was re-orthogonalised after k_pick; |w_k|^2 is recomputed here from
+            // the registers (every group holds all of w_k) and published by block 0
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < E2; ++i) q += w[i].x * w[i].x + w[i].y * w[i].y;
+            q = wave_sum(q);
+            if (NW > 1) {
+                if (lane == 0) red[g][wig][0] = q;
+                __syncthreads();
+                q = 0.0;
+#pragma unroll
+                for (int z = 0; z < NW; ++z) q += red[g][z][0];
+                __syncthreads();
+            }
+            wn2 = q;
+            if (blockIdx.x == 0 && tid == 0) scal_k[1] = q;
+        }
     }
     double bmax = -1.0, bsum = 0.0;
     long long bidx = 0x7fffffffffffffffLL;
@@ -397,7 +415,7 @@ static inline int stream_grid(const asb_ctx* ctx, const StreamCfg& c, int64_t n)
 struct StreamArgs {
     double* R;
     const double* wk;
-    const double* scal_k;
+    double* scal_k;
     const double* s;
     double* ck;
     double* energy;

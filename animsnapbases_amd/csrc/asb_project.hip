@@ -252,6 +252,38 @@ __global__ __launch_bounds__(256) void k_force_single(const double* pmax, const 
 }
 
 // --------------------------------------------------------------------------------------
+// Re-orthogonalisation of the new weight against all earlier ones.  In exact arithmetic
+// w_k is already orthogonal to w_0..w_{k-1}; numerically the candidate rows carry the
+// cancellation error eps*|X|/|R| along those directions, and since c_k = X^T w_k / |w_k|^2
+// is taken against X (not R) that error would be amplified once more (eps*kappa^2, the
+// classical-Gram-Schmidt effect).  One projection pass restores eps*kappa.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reorth_dots(const double* __restrict__ W, const double* __restrict__ scal,
+                                                     long long k, int Fp, double* __restrict__ coef,
+                                                     const PanelState* __restrict__ panel) {
+    if (panel->done) return;
+    __shared__ double sh[4];
+    const long long j = blockIdx.x;
+    const double* wj = W + j * Fp;
+    const double* wk = W + k * Fp;
+    double v[1] = {0.0};
+    for (int f = threadIdx.x; f < Fp; f += blockDim.x) v[0] += wj[f] * wk[f];
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) coef[j] = v[0] / scal[j * 4 + 1];
+}
+
+__global__ __launch_bounds__(256) void k_reorth_apply(double* __restrict__ W, long long k, int Fp,
+                                                      const double* __restrict__ coef,
+                                                      const PanelState* __restrict__ panel) {
+    if (panel->done) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= Fp) return;
+    double acc = 0.0;
+    for (long long j = 0; j < k; ++j) acc += coef[j] * W[j * Fp + f];
+    W[k * Fp + f] -= acc;
+}
+
+// --------------------------------------------------------------------------------------
 // panel weights in B-operand order: Wt[f][t] (Fp x 16), zero columns beyond ncols
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_wt(const double* __restrict__ W, const double* __restrict__ scal,
@@ -515,6 +547,7 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if ((rc = asb_alloc(ctx, &ctx->colpart, (size_t)ctx->nblk_cap * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->coef, (size_t)K))) return rc;
     ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
     // initial energies straight from X (read-only pass)
     StreamCfg c;
@@ -576,6 +609,12 @@ static int panel_steps(asb_ctx* ctx, long long k0, int steps, long long* committ
                            ctx->cnblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
                            (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k, (long long)ctx->K, 0, ctx->pstate,
                            ctx->cand_idx, k0);
+        if (k > 0) {
+            hipLaunchKernelGGL(k_reorth_dots, dim3((unsigned)k), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, k,
+                               (int)ctx->Fp, ctx->coef, ctx->pstate);
+            hipLaunchKernelGGL(k_reorth_apply, dim3((unsigned)((ctx->Fp + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->W, k, (int)ctx->Fp, ctx->coef, ctx->pstate);
+        }
         const int grid = stream_grid(ctx, c, ctx->m_cap);
         StreamArgs a{ctx->candR, ctx->W + k * ctx->Fp, ctx->scal + k * 4, nullptr, ctx->cand_c, ctx->cand_e,
                      ctx->cpmax, ctx->cpidx, ctx->cpsum, (long long)ctx->m_cap, ctx->pstate};

@@ -144,8 +144,11 @@ def main():
 
     if rank == 0:
         value = F * args.steps / dt
-        # dominant kernel: k_stream (one pass over this rank's residual shard per component).
+        # dominant kernel: one streaming pass over this rank's shard -- k_project_mfma (projection mode:
+        # one launch per PANEL of up to 16 components) or k_stream (residual mode: one per component).
         # algorithmic bytes per launch = 24 * n_loc * F (c = 1: one read of the shard)
+        stats = eng.deflate_stats()
+        mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
         alg_bytes = 24.0 * n_loc * F
         avg_ms = kern_ms / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
@@ -159,7 +162,10 @@ def main():
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": "k_stream<T,E2,UPDATE> (deflation pass)", "launches": launches,
+                         "kernel": ("k_project_mfma<8,16> (f64-MFMA panel projection, one read of X per panel)"
+                                    if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
+                         "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
+                         "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:
