@@ -73,7 +73,9 @@ struct asb_ctx {
     double* cpsum = nullptr;
     int cnblk = 0;
     double* colpart = nullptr;   // (blocks, 16)
-    double* coef = nullptr;      // (K) re-orthogonalisation coefficients
+    double* gram = nullptr;      // (K, 16) w_j . w_panel
+    long long* ctmp = nullptr;   // compaction scratch
+    long long* ccnt = nullptr;
     int* hist = nullptr;
     PanelState* pstate = nullptr;
     int64_t n_panels = 0, n_refresh = 0;

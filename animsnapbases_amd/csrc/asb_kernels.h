@@ -51,24 +51,6 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_stream(
             w[i] = (j < F2) ? reinterpret_cast<const double2*>(wk)[j] : make_double2(0.0, 0.0);
         }
         wn2 = scal_k[1];
-        if (panel != nullptr) {
-            // panel path: w_k was re-orthogonalised after k_pick; |w_k|^2 is recomputed here from
-            // the registers (every group holds all of w_k) and published by block 0
-            double q = 0.0;
-#pragma unroll
-            for (int i = 0; i < E2; ++i) q += w[i].x * w[i].x + w[i].y * w[i].y;
-            q = wave_sum(q);
-            if (NW > 1) {
-                if (lane == 0) red[g][wig][0] = q;
-                __syncthreads();
-                q = 0.0;
-#pragma unroll
-                for (int z = 0; z < NW; ++z) q += red[g][z][0];
-                __syncthreads();
-            }
-            wn2 = q;
-            if (blockIdx.x == 0 && tid == 0) scal_k[1] = q;
-        }
     }
     double bmax = -1.0, bsum = 0.0;
     long long bidx = 0x7fffffffffffffffLL;

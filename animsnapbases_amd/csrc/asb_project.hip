@@ -19,6 +19,8 @@
 // HBM traffic: one read of X per PANEL instead of a read + write of R per COMPONENT.
 #include "asb_kernels.h"
 
+#include <cstdlib>
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define ASB_NBINS 2048
@@ -161,20 +163,34 @@ __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long
 __global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, double* __restrict__ sc, int level,
                                              long long m_target, long long m_cap) {
     __shared__ int lh[ASB_NBINS];
-    for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = hist[i];
+    __shared__ int seg[256];
+    constexpr int PER = ASB_NBINS / 256;
+    int ssum = 0;
+    for (int q = 0; q < PER; ++q) {
+        const int v = hist[threadIdx.x * PER + q];
+        lh[threadIdx.x * PER + q] = v;
+        ssum += v;
+    }
+    seg[threadIdx.x] = ssum;
     __syncthreads();
     if (threadIdx.x != 0) return;
     const double lo = sc[SC_LO], hi = sc[SC_HI];
     const double width = (hi - lo) / (double)ASB_NBINS;
     long long acc = (long long)sc[SC_ABOVE];
-    int b = ASB_NBINS - 1;
-    for (; b >= 0; --b) {
-        if (acc + lh[b] >= m_target) break;
-        acc += lh[b];
+    int sg = 255;
+    for (; sg >= 0; --sg) {                 // coarse: segments of PER bins from the top
+        if (acc + seg[sg] >= m_target) break;
+        acc += seg[sg];
     }
+    int b = -1;
+    if (sg >= 0)
+        for (b = sg * PER + PER - 1; b >= sg * PER; --b) {
+            if (acc + lh[b] >= m_target) break;
+            acc += lh[b];
+        }
     if (b < 0) {                       // fewer than m_target vertices in range: take them all
-        sc[SC_TAU] = (level == 1) ? -1.0 : lo;
         if (level == 1) { sc[SC_LO] = 0.0; sc[SC_HI] = 0.0; sc[SC_ABOVE] = (double)acc; sc[SC_TAU] = -1.0; }
+        else sc[SC_TAU] = nextafter(lo, -1.0e300);
         return;
     }
     const double edge_lo = lo + b * width, edge_hi = (b == ASB_NBINS - 1) ? hi : lo + (b + 1) * width;
@@ -184,45 +200,68 @@ __global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, doubl
         sc[SC_ABOVE] = (double)acc;
         sc[SC_TAU] = edge_lo;          // provisional
     } else {
-        // candidates are E > tau.  Lower edge keeps the crossing bin (>= m_target candidates).
+        // candidates are E > tau.  The lower edge keeps the crossing bin (>= m_target candidates),
+        // the upper edge drops it when it would overflow the buffer.
         double tau = edge_lo;
         if (acc + lh[b] > m_cap && acc > 0) tau = edge_hi;
-        // strict '>' in the compaction: nudge below the edge so that e == edge_lo is kept
-        sc[SC_TAU] = nextafter(tau, -1.0e300);
+        sc[SC_TAU] = nextafter(tau, -1.0e300);      // strict '>' in the compaction keeps e == edge
     }
 }
 
-// ordered compaction (one block): cand_idx = global ids of { v : E[v] > tau } in increasing
-// order, at most m_cap of them; initialises the panel state.
-__global__ __launch_bounds__(1024) void k_compact(const double* __restrict__ E, long long n, long long v0,
-                                                  const double* __restrict__ sc, int take_all, long long m_cap,
-                                                  long long* __restrict__ cand_idx, PanelState* __restrict__ panel,
-                                                  double margin_rel) {
-    __shared__ long long cnt[1024];
+// ordered compaction, two stages: cand_idx = global ids of { v : E[v] > tau } in increasing
+// order (so that slot order == vertex order and arg-max ties resolve to the lowest vertex), at
+// most m_cap of them; stage B also initialises the panel state.
+#define ASB_CBLOCKS 128
+__global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E, long long n, long long v0,
+                                                   const double* __restrict__ sc, int take_all, long long m_cap,
+                                                   long long* __restrict__ tmp, long long* __restrict__ cnt) {
+    __shared__ long long pre[256];
     const int tid = threadIdx.x;
     const double tau = take_all ? -1.0e300 : sc[SC_TAU];
-    const long long seg = (n + 1023) / 1024;
-    const long long a = tid * seg, b = (a + seg < n) ? a + seg : n;
+    const long long seg = (n + gridDim.x - 1) / gridDim.x;
+    const long long s0 = blockIdx.x * seg, s1 = (s0 + seg < n) ? s0 + seg : n;
+    const long long sub = (seg + 255) / 256;
+    const long long a = s0 + tid * sub, b = (a + sub < s1) ? a + sub : s1;
     long long c = 0;
     for (long long i = a; i < b; ++i) c += (E[i] > tau);
-    cnt[tid] = c;
+    pre[tid] = c;
     __syncthreads();
-    // inclusive scan (Hillis-Steele)
-    for (int o = 1; o < 1024; o <<= 1) {
-        long long add = (tid >= o) ? cnt[tid - o] : 0;
+    for (int o = 1; o < 256; o <<= 1) {
+        const long long add = (tid >= o) ? pre[tid - o] : 0;
         __syncthreads();
-        cnt[tid] += add;
+        pre[tid] += add;
         __syncthreads();
     }
-    long long pos = cnt[tid] - c;
-    const long long total = cnt[1023];
+    long long pos = pre[tid] - c;
+    long long* out = tmp + (long long)blockIdx.x * m_cap;
     for (long long i = a; i < b; ++i)
         if (E[i] > tau) {
-            if (pos < m_cap) cand_idx[pos] = v0 + i;
+            if (pos < m_cap) out[pos] = v0 + i;
             ++pos;
         }
-    if (tid == 0) {
+    if (tid == 255) cnt[blockIdx.x] = pre[255];
+}
+
+__global__ __launch_bounds__(256) void k_compact_b(const long long* __restrict__ tmp, const long long* __restrict__ cnt,
+                                                   int nb, long long n, const double* __restrict__ sc, int take_all,
+                                                   long long m_cap, long long* __restrict__ cand_idx,
+                                                   PanelState* __restrict__ panel, double margin_rel) {
+    __shared__ long long off[ASB_CBLOCKS + 1];
+    if (threadIdx.x == 0) {
+        long long acc = 0;
+        for (int b = 0; b < nb; ++b) { off[b] = acc; acc += cnt[b]; }
+        off[nb] = acc;
+    }
+    __syncthreads();
+    const long long total = off[nb];
+    for (int b = 0; b < nb; ++b) {
+        const long long c = cnt[b] < m_cap ? cnt[b] : m_cap;
+        for (long long q = threadIdx.x; q < c; q += blockDim.x)
+            if (off[b] + q < m_cap) cand_idx[off[b] + q] = tmp[(long long)b * m_cap + q];
+    }
+    if (threadIdx.x == 0) {
         const bool overflow = total > m_cap;
+        const double tau = take_all ? -1.0e300 : sc[SC_TAU];
         panel->n_cand = overflow ? m_cap : total;
         // every non-candidate has E <= tau; with dropped candidates nothing can be proven
         panel->theta = overflow ? 1.0e300 : ((take_all || total >= n) ? -1.0e300 : tau);
@@ -252,35 +291,105 @@ __global__ __launch_bounds__(256) void k_force_single(const double* pmax, const 
 }
 
 // --------------------------------------------------------------------------------------
-// Re-orthogonalisation of the new weight against all earlier ones.  In exact arithmetic
-// w_k is already orthogonal to w_0..w_{k-1}; numerically the candidate rows carry the
-// cancellation error eps*|X|/|R| along those directions, and since c_k = X^T w_k / |w_k|^2
-// is taken against X (not R) that error would be amplified once more (eps*kappa^2, the
-// classical-Gram-Schmidt effect).  One projection pass restores eps*kappa.
+// Orthogonality correction of a panel.  In exact arithmetic the new weights are orthogonal
+// to every earlier w_j; numerically the candidate rows they are built from carry the
+// cancellation error eps*|X|/|R| along those directions, and since the projection is taken
+// against X (not the residual), Y = X.W_panel picks up  sum_j c_j[v] (w_j . w_t).  Left in, it
+// costs eps*kappa^2 (the classical-Gram-Schmidt effect); removing it restores eps*kappa:
+//     c_t[v] = ( X_v . w_t - sum_{j<k0} c_j[v] |w_j|^2-free Gram term ) / |w_t|^2
+// k_panel_gram: G[j][t] = w_j . w_{k0+t}  (j < k0).   k_correct: applies it, then updates the
+// energies E[v] -= sum_t |w_t|^2 |c_t[v]|^2 and the per-block partial records.
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reorth_dots(const double* __restrict__ W, const double* __restrict__ scal,
-                                                     long long k, int Fp, double* __restrict__ coef,
-                                                     const PanelState* __restrict__ panel) {
-    if (panel->done) return;
-    __shared__ double sh[4];
-    const long long j = blockIdx.x;
-    const double* wj = W + j * Fp;
-    const double* wk = W + k * Fp;
-    double v[1] = {0.0};
-    for (int f = threadIdx.x; f < Fp; f += blockDim.x) v[0] += wj[f] * wk[f];
-    block_sum<1>(v, sh);
-    if (threadIdx.x == 0) coef[j] = v[0] / scal[j * 4 + 1];
+__global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W, const double* __restrict__ Wt,
+                                                    int Fp, double* __restrict__ G) {
+    __shared__ double sh[4 * 16];
+    const double* wj = W + (long long)blockIdx.x * Fp;
+    double acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+    for (int f = threadIdx.x; f < Fp; f += blockDim.x) {
+        const double a = wj[f];
+        const double* wt = Wt + (long long)f * ASB_PANEL_COLS;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] += a * wt[t];
+    }
+    block_sum<16>(acc, sh);
+    if (threadIdx.x < 16) G[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_reorth_apply(double* __restrict__ W, long long k, int Fp,
-                                                      const double* __restrict__ coef,
-                                                      const PanelState* __restrict__ panel) {
-    if (panel->done) return;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= Fp) return;
-    double acc = 0.0;
-    for (long long j = 0; j < k; ++j) acc += coef[j] * W[j * Fp + f];
-    W[k * Fp + f] -= acc;
+__global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, long long comp_stride, long long n_vert,
+                                                 int k0, int ncols, const double* __restrict__ G,
+                                                 const double* __restrict__ wn2, double* __restrict__ E,
+                                                 double* __restrict__ pmax, long long* __restrict__ pidx,
+                                                 double* __restrict__ psum, double* __restrict__ colpart) {
+    __shared__ double gs[64 * 16];
+    __shared__ double sh_d[512];
+    __shared__ long long sh_i[256];
+    const int tid = threadIdx.x;
+    double bmax = -1.0, bsum = 0.0, csum[16];
+    long long bidx = 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) csum[t] = 0.0;
+    double inv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) inv[t] = wn2[t];
+    for (long long base = (long long)blockIdx.x * 256; base < n_vert; base += (long long)gridDim.x * 256) {
+        const long long v = base + tid;
+        const bool valid = v < n_vert;
+        double c[16][3];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const double* p = comps + (long long)(k0 + t) * comp_stride + v * 3;
+            const bool on = valid && t < ncols;
+            c[t][0] = on ? p[0] : 0.0; c[t][1] = on ? p[1] : 0.0; c[t][2] = on ? p[2] : 0.0;
+        }
+        for (int j0 = 0; j0 < k0; j0 += 64) {
+            const int jn = (k0 - j0 < 64) ? k0 - j0 : 64;
+            __syncthreads();
+            for (int q = tid; q < jn * 16; q += 256) gs[q] = G[(long long)j0 * 16 + q] / inv[q & 15];
+            __syncthreads();
+            for (int j = 0; j < jn; ++j) {
+                const double* p = comps + (long long)(j0 + j) * comp_stride + v * 3;
+                const double a0 = valid ? p[0] : 0.0, a1 = valid ? p[1] : 0.0, a2 = valid ? p[2] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const double gq = gs[j * 16 + t];
+                    c[t][0] -= a0 * gq; c[t][1] -= a1 * gq; c[t][2] -= a2 * gq;
+                }
+            }
+        }
+        if (valid) {
+            double loss = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < ncols) {
+                    double* p = comps + (long long)(k0 + t) * comp_stride + v * 3;
+                    p[0] = c[t][0]; p[1] = c[t][1]; p[2] = c[t][2];
+                    const double q = (c[t][0] * c[t][0] + c[t][1] * c[t][1] + c[t][2] * c[t][2]) * inv[t];
+                    loss += q;
+                    csum[t] += q;
+                }
+            double e = E[v] - loss;
+            if (e < 0.0) e = 0.0;
+            E[v] = e;
+            bsum += e;
+            if (am_better(e, v, bmax, bidx)) { bmax = e; bidx = v; }
+        }
+    }
+    __syncthreads();
+    block_sum<16>(csum, sh_d);
+    if (tid < 16) colpart[(long long)blockIdx.x * 16 + tid] = csum[tid];
+    __syncthreads();
+    sh_d[tid] = bmax; sh_d[256 + tid] = bsum; sh_i[tid] = bidx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            sh_d[256 + tid] += sh_d[256 + tid + o];
+            if (am_better(sh_d[tid + o], sh_i[tid + o], sh_d[tid], sh_i[tid])) { sh_d[tid] = sh_d[tid + o]; sh_i[tid] = sh_i[tid + o]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; psum[blockIdx.x] = sh_d[256]; }
 }
 
 // --------------------------------------------------------------------------------------
@@ -309,20 +418,15 @@ __global__ __launch_bounds__(256) void k_build_wt(const double* __restrict__ W, 
 // Per group of 48 rows (16 vertices): each lane loads 32 B = frames 4g..4g+3 of row i
 // straight into the A-operand position (k slot g <-> frame 16*chunk + 4g + j for MFMA j),
 // 3 row tiles x CPW chunks x 4 MFMAs, then the NWV partial 48x16 tiles are summed
-// through LDS and the epilogue writes c = y / |w|^2 and E[v] -= sum y^2 / |w|^2.
+// through LDS and the epilogue writes the raw coefficients y / |w|^2 (k_correct finishes).
 // --------------------------------------------------------------------------------------
 template <int NWV, int CPW>
 __global__ __launch_bounds__(NWV * 64) void k_project_mfma(
     const double* __restrict__ X, long long rows, long long n_vert, int Fp, int NC, const double* __restrict__ Wt,
-    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride,
-    double* __restrict__ E, double* __restrict__ pmax, long long* __restrict__ pidx, double* __restrict__ psum,
-    double* __restrict__ colpart) {
+    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride) {
     constexpr int NT = NWV * 64;
     __shared__ double red[NWV * 768];
     __shared__ double ysh[768];
-    __shared__ double vmax_e[16];
-    __shared__ long long vmax_i[16];
-    __shared__ double vsum[16];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, g = l >> 4;
 
     // super-chunks: NWV*CPW chunks (of 16 frames) are covered per sweep; F <= 2048 needs one sweep
@@ -340,13 +444,6 @@ __global__ __launch_bounds__(NWV * 64) void k_project_mfma(
         }
     };
     if (nsweep == 1) load_b(0);
-    // epilogue roles: threads [0,256) write components, 16 threads own the group's vertices
-    // (energies), 16 threads own the panel's columns (norm sums); on 512+-thread blocks these
-    // sit in different waves and overlap.
-    constexpr int VBASE = (NT >= 512) ? 256 : 0, CBASE = (NT >= 512) ? 320 : 64;
-    double run_max = -1.0, run_sum = 0.0, col_acc = 0.0;
-    long long run_idx = 0x7fffffffffffffffLL;
-
     const long long ngroups = (rows + 47) / 48;
     for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const long long row0 = grp * 48;
@@ -398,51 +495,7 @@ __global__ __launch_bounds__(NWV * 64) void k_project_mfma(
                 dst[2] = ysh[(3 * vl + 2) * 16 + col] / inv;
             }
         }
-        if (tid >= VBASE && tid < VBASE + 16) {      // energies: E[v] -= sum_t |w_t|^2 |c_t[v]|^2
-            const int vt = tid - VBASE;
-            const long long v = grp * 16 + vt;
-            if (v < n_vert) {
-                double loss = 0.0;
-                for (int col = 0; col < ncols; ++col) {
-                    const double y0 = ysh[(3 * vt + 0) * 16 + col], y1 = ysh[(3 * vt + 1) * 16 + col],
-                                 y2 = ysh[(3 * vt + 2) * 16 + col];
-                    loss += (y0 * y0 + y1 * y1 + y2 * y2) / wn2[col];
-                }
-                double e = E[v] - loss;
-                if (e < 0.0) e = 0.0;
-                E[v] = e;
-                run_sum += e;
-                if (am_better(e, v, run_max, run_idx)) { run_max = e; run_idx = v; }
-            }
-        }
-        if (tid >= CBASE && tid < CBASE + 16) {      // per-column |w|^2 |c|_F^2 of this shard
-            const int col = tid - CBASE;
-            if (col < ncols) {
-                long long nr = rows - row0;
-                if (nr > 48) nr = 48;
-                double sq = 0.0;
-                for (int r = 0; r < (int)nr; ++r) { const double y = ysh[r * 16 + col]; sq += y * y; }
-                col_acc += sq / wn2[col];
-            }
-        }
         __syncthreads();
-    }
-    // block partials
-    if (tid >= VBASE && tid < VBASE + 16) {
-        vmax_e[tid - VBASE] = run_max;
-        vmax_i[tid - VBASE] = run_idx;
-        vsum[tid - VBASE] = run_sum;
-    }
-    if (tid >= CBASE && tid < CBASE + 16) colpart[(long long)blockIdx.x * 16 + (tid - CBASE)] = col_acc;
-    __syncthreads();
-    if (tid == 0) {
-        double be = vmax_e[0], bs = vsum[0];
-        long long bi = vmax_i[0];
-        for (int q = 1; q < 16; ++q) {
-            bs += vsum[q];
-            if (am_better(vmax_e[q], vmax_i[q], be, bi)) { be = vmax_e[q]; bi = vmax_i[q]; }
-        }
-        pmax[blockIdx.x] = be; pidx[blockIdx.x] = bi; psum[blockIdx.x] = bs;
     }
 }
 
@@ -496,8 +549,7 @@ template <int NWV, int CPW>
 static void launch_project_t(asb_ctx* ctx, int grid, int ncols, long long k0) {
     hipLaunchKernelGGL((k_project_mfma<NWV, CPW>), dim3(grid), dim3(NWV * 64), 0, ctx->stream, ctx->X,
                        (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)ctx->Fp, (int)(ctx->Fp / 16), ctx->Wt,
-                       ctx->wn2t, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc),
-                       ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart);
+                       ctx->wn2t, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc));
 }
 
 // one projection pass for components [k0, k0+ncols)
@@ -519,7 +571,14 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     ASB_CHECK_LAUNCH(ctx);
     rc = prof_end(ctx, slot);
     if (rc) return rc;
-    ctx->nblk = grid;
+    if (k0 > 0) hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)k0), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                       ctx->psum, ctx->colpart);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -547,7 +606,9 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if ((rc = asb_alloc(ctx, &ctx->colpart, (size_t)ctx->nblk_cap * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->coef, (size_t)K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->gram, (size_t)K * ASB_PANEL_COLS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->ctmp, (size_t)ASB_CBLOCKS * ctx->m_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->ccnt, (size_t)ASB_CBLOCKS))) return rc;
     ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
     // initial energies straight from X (read-only pass)
     StreamCfg c;
@@ -587,8 +648,10 @@ static int panel_select(asb_ctx* ctx, long long k, int forced) {
             }
             ASB_CHECK_LAUNCH(ctx);
         }
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0, ctx->scalar_dev,
-                           take_all, (long long)ctx->m_cap, ctx->cand_idx, ctx->pstate, 1.0e-11);
+        hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0,
+                           ctx->scalar_dev, take_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt);
+        hipLaunchKernelGGL(k_compact_b, dim3(1), dim3(256), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS, n,
+                           ctx->scalar_dev, take_all, (long long)ctx->m_cap, ctx->cand_idx, ctx->pstate, 1.0e-11);
         ASB_CHECK_LAUNCH(ctx);
     }
     // exact residual rows of the candidates
@@ -609,12 +672,6 @@ static int panel_steps(asb_ctx* ctx, long long k0, int steps, long long* committ
                            ctx->cnblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
                            (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k, (long long)ctx->K, 0, ctx->pstate,
                            ctx->cand_idx, k0);
-        if (k > 0) {
-            hipLaunchKernelGGL(k_reorth_dots, dim3((unsigned)k), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, k,
-                               (int)ctx->Fp, ctx->coef, ctx->pstate);
-            hipLaunchKernelGGL(k_reorth_apply, dim3((unsigned)((ctx->Fp + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->W, k, (int)ctx->Fp, ctx->coef, ctx->pstate);
-        }
         const int grid = stream_grid(ctx, c, ctx->m_cap);
         StreamArgs a{ctx->candR, ctx->W + k * ctx->Fp, ctx->scal + k * 4, nullptr, ctx->cand_c, ctx->cand_e,
                      ctx->cpmax, ctx->cpidx, ctx->cpsum, (long long)ctx->m_cap, ctx->pstate};
@@ -641,6 +698,14 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
         long long done = 0;
         if ((rc = panel_steps(ctx, k, steps, &done))) return rc;
         ctx->n_panels++;
+        if (getenv("ASB_DEBUG_PANELS")) {
+            PanelState h;
+            double sc[8];
+            (void)hipMemcpy(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[asb] panel at k=%lld: n_cand=%lld committed=%lld theta=%.6f emax=%.6f above=%g\n", k, h.n_cand,
+                    h.committed, h.theta, sc[SC_EMAX], sc[SC_ABOVE]);
+        }
         if (done == 0) {
             // the energy recurrence could not prove any candidate: refresh ALL energies exactly, retry;
             // a second failure (massive exact ties) forces the first arg-max as the only candidate
