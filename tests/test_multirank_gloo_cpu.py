@@ -1,0 +1,84 @@
+"""CPU, world_size = 2, gloo: the product's multi-rank host logic (posSnapshots /
+posComponents + Comm) driven through the CPU test double of the device engine.
+Checks: 2-rank result == oracle single-process result (index sequence exact), every rank
+holds the full gathered basis, uneven shards (odd N)."""
+import os
+import socket
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, support, tmpdir):
+    import contextlib
+    import io
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.chdir(tmpdir)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from animsnapbases_amd import Comm, posComponents, posSnapshots
+        from fake_engine import FakeEngine
+        from oracle import asb_oracle as orc
+        from conftest import align_signs, relerr
+
+        rest, tris = orc.synth_mesh(7, 9, seed=3)               # N = 65 (odd: uneven shards)
+        verts = orc.synth_snapshots(rest, 21, rank=5, seed=3, kind="bumps" if support == "local" else "iid")
+        K = 5
+        param = types.SimpleNamespace(vertPos_bases_type="PCA", vertPos_numComponents=K, q_support=support,
+                                      store_vertPos_PCA_sing_val=True, vertPos_smooth_min_dist=0.1,
+                                      vertPos_smooth_max_dist=0.35, q_standarize=True, q_massWeight=False,
+                                      q_orthogonal=False, vertPos_output_directory=tmpdir, name="mr%d" % rank)
+        comm = Comm()
+        assert comm.world == world and comm.rank == rank
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False,
+                                             engine=FakeEngine(), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.compute_components_store_singvalues()
+        assert snaps._engine.n_loc == comm.my_shard(65)[1] and sum(n for _, n in comm.shards(65)) == 65
+        pre = orc.prepare_snapshots(verts, "first", True)
+        assert abs(snaps.pre_scale_factor - pre["pre_scale_factor"]) < 1e-12 * pre["pre_scale_factor"]
+        assert relerr(snaps.mean, pre["mean"]) < 1e-14
+        assert relerr(snaps.snapTensor, pre["snapTensor"]) < 1e-13
+        geo = orc.Geodesics(verts[0], tris) if support == "local" else None
+        ref = orc.extract_k_components(pre["snapTensor"], K, support, geo, 0.1, 0.35)
+        assert comp.selected_vertices.tolist() == ref["idx"].tolist()
+        comps, weigs = comp.comps, comp.weigs
+        assert comps.shape == (K, 65, 3)
+        if support == "global":
+            comps, weigs = align_signs(comps, weigs, ref["comps"])
+        assert relerr(comps, ref["comps"]) < 1e-9
+        assert relerr(weigs, ref["weigs"]) < 1e-9
+        assert relerr(comp.measures_at_largeDeforVerts, ref["measures"]) < 1e-9
+        with contextlib.redirect_stdout(io.StringIO()):
+            comp.post_process_components()
+        post = orc.post_process_components(comp.comps * 0 + comps if False else ref["comps"], pre["pre_scale_factor"], pre["mean"])
+        if support == "local":
+            assert relerr(comp.comps, post) < 1e-9
+        if rank == 0:
+            assert os.path.exists(os.path.join(tmpdir, "mr0_posBases_pcaExtraction_singValues_errorNorm.csv"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("support", ["global", "local"])
+def test_two_rank_gloo_matches_oracle(support, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, support, str(tmp_path)), nprocs=2, join=True)
