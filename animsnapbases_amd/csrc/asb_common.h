@@ -25,6 +25,8 @@ struct StreamCfg {
     int T, E2, block, vpb;
 };
 
+struct asb_splocs;
+
 struct asb_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -80,6 +82,8 @@ struct asb_ctx {
     PanelState* pstate = nullptr;
     int64_t n_panels = 0, n_refresh = 0;
 
+    asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
+
     // ---- profiling of the dominant streaming kernel ----
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -89,6 +93,7 @@ struct asb_ctx {
 // projection path entry points (asb_project.hip), dispatched on ctx->mode
 int asb_project_begin(asb_ctx* ctx, int64_t K);
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
+void asb_splocs_free(asb_ctx* ctx);
 int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local);
 
 #define ASB_FAIL(ctx, code, ...)                                   \

@@ -499,6 +499,20 @@ __global__ __launch_bounds__(NWV * 64) void k_project_mfma(
     }
 }
 
+// B-operand panel from a frame-major (F x ldw) matrix: columns k0 .. k0+ncols-1, unit norms
+__global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ Wfk, long long ldw, long long k0,
+                                                     int ncols, int F, int Fp, double* __restrict__ Wt,
+                                                     double* __restrict__ wn2) {
+    const long long total = (long long)Fp * ASB_PANEL_COLS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ASB_PANEL_COLS);
+        const long long f = i / ASB_PANEL_COLS;
+        Wt[i] = (t < ncols && f < F) ? Wfk[f * ldw + k0 + t] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS) wn2[threadIdx.x] = 1.0;
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
                                                 double* __restrict__ scal) {
@@ -545,12 +559,7 @@ static void launch_gather(asb_ctx* ctx, const StreamCfg& c, int grid, const long
     }
 }
 
-template <int NWV, int CPW>
-static void launch_project_t(asb_ctx* ctx, int grid, int ncols, long long k0) {
-    hipLaunchKernelGGL((k_project_mfma<NWV, CPW>), dim3(grid), dim3(NWV * 64), 0, ctx->stream, ctx->X,
-                       (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)ctx->Fp, (int)(ctx->Fp / 16), ctx->Wt,
-                       ctx->wn2t, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc));
-}
+static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
 // one projection pass for components [k0, k0+ncols)
 static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
@@ -565,9 +574,7 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     size_t slot;
     int rc = prof_begin(ctx, slot);
     if (rc) return rc;
-    if (NC <= 16) launch_project_t<4, 4>(ctx, grid, ncols, k0);
-    else if (NC <= 64) launch_project_t<8, 8>(ctx, grid, ncols, k0);
-    else launch_project_t<8, 16>(ctx, grid, ncols, k0);      // F > 2048: several sweeps per row group
+    launch_project(ctx, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc);
     ASB_CHECK_LAUNCH(ctx);
     rc = prof_end(ctx, slot);
     if (rc) return rc;
@@ -580,6 +587,36 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     ASB_CHECK_LAUNCH(ctx);
     ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+static void launch_project(asb_ctx* ctx, int ncols, double* out) {
+    const int NC = (int)(ctx->Fp / 16);
+    const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
+    int grid = ctx->n_cu * ((NC <= 16) ? 2 : 1);
+    if (grid > nwg) grid = nwg;
+    if (grid < 1) grid = 1;
+    const long long rows = 3 * ctx->n_loc;
+    if (NC <= 16)
+        hipLaunchKernelGGL((k_project_mfma<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
+                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
+    else if (NC <= 64)
+        hipLaunchKernelGGL((k_project_mfma<8, 8>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
+                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
+    else
+        hipLaunchKernelGGL((k_project_mfma<8, 16>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
+                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
+}
+
+// out_rows (ncols, 3 n_loc) = X . Wfk[:, k0:k0+ncols]   (raw products, used for c = W^T X of SPLOCS)
+int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows) {
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt, (size_t)ctx->Fp * ASB_PANEL_COLS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t, (size_t)ASB_PANEL_COLS))) return rc;
+    hipLaunchKernelGGL(k_build_wt_fk, dim3(64), dim3(256), 0, ctx->stream, Wfk, (long long)ldw, (long long)k0, ncols,
+                       (int)ctx->F, (int)ctx->Fp, ctx->Wt, ctx->wn2t);
+    launch_project(ctx, ncols, out_rows);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }

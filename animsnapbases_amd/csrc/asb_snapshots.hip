@@ -155,6 +155,7 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
         if (*slot) (void)hipFree(*slot);
         *slot = nullptr;
     }
+    asb_splocs_free(ctx);
     for (auto& e : ctx->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);

@@ -1,0 +1,453 @@
+// SPLOCS global optimisation on the GPU -- posComponents.splocs_glob_optimization,
+// snapbases/posComponents.py:132-189 of the reference.  gfx950 (MI355X) only.
+//
+// The reference sweeps the F x 3N residual ~5K times per outer iteration (rank-1 updates per
+// component).  Here the residual is never formed.  With C fixed during the weight sweep,
+//     P = X C^T (F x K),  M = C C^T (K x K)           -- ONE pass over X (f64 MFMA)
+//     opt_k = (P[:,k] - W M[:,k]) / M[k,k] + W[:,k]    -- O(F K) per component, sequential in k
+// (identical to  Rflat += w_k c_k^T; opt = Rflat c_k / |c_k|^2  of :153-154 because Rflat = X - W C
+// throughout), the ADMM right-hand side c = W^T X is the same 16-column projection kernel as the
+// deflation, the K x K solve is an explicit (G + rho I)^-1 applied with MFMA, and
+//     |X - W C|^2 = |X|^2 - 2 <W, X C^T> + <W^T W, C C^T>
+// needs only the next iteration's P and M.  Support maps (Lambda) come from the host geodesics.
+#include "asb_kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// defined in asb_project.hip
+int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows);
+
+// --------------------------------------------------------------------------------------
+// k_gemm_tn:  part[s][i][j] = sum_{r in slab s} A[r][i] * B[r][j]      (f64 MFMA 16x16x4)
+// A: (Rn x lda), B: (Rn x ldb), contraction index r is the slow dimension of both.
+// One wave per (16x16 output tile, slab).  Lane (i = l&15, g = l>>4) feeds A[r+g][i0+i],
+// B[r+g][j0+i]: four rows x 128 contiguous bytes per operand per MFMA.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gemm_tn(const double* __restrict__ A, long long lda,
+                                                const double* __restrict__ B, long long ldb, long long Rn, int I,
+                                                int J, long long slab, double* __restrict__ part) {
+    const int l = threadIdx.x, i = l & 15, g = l >> 4;
+    const int tj = (J + 15) / 16;
+    const int ti = blockIdx.x / tj, tjx = blockIdx.x % tj;
+    const int i0 = ti * 16, j0 = tjx * 16;
+    const long long r0 = (long long)blockIdx.y * slab;
+    long long r1 = r0 + slab;
+    if (r1 > Rn) r1 = Rn;
+    const bool ai = (i0 + i) < I, bj = (j0 + i) < J;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = A + (i0 + i);
+    const double* pb = B + (j0 + i);
+    for (long long rb = r0; rb < r1; rb += 4) {
+        const long long r = rb + g;
+        const bool in = r < r1;
+        const double a = (in && ai) ? pa[r * lda] : 0.0;
+        const double b = (in && bj) ? pb[r * ldb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double* out = part + (long long)blockIdx.y * I * J;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oi = i0 + g + 4 * q, oj = j0 + i;
+        if (oi < I && oj < J) out[(long long)oi * J + oj] = acc[q];
+    }
+}
+
+// out[e] = sum_s part[s][e]
+__global__ __launch_bounds__(256) void k_sum_slabs(const double* __restrict__ part, int S, long long n,
+                                                   double* __restrict__ out) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < S; ++q) s += part[(long long)q * n + e];
+        out[e] = s;
+    }
+}
+
+// (rows x cols) -> (cols x rows)
+__global__ __launch_bounds__(256) void k_transpose_small(const double* __restrict__ in, long long rows, long long cols,
+                                                         double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    for (int q = 0; q < 4; ++q) {
+        const long long r = r0 + ty + q * 8, c = c0 + tx;
+        tile[ty + q * 8][tx] = (r < rows && c < cols) ? in[r * cols + c] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const long long c = c0 + ty + q * 8, r = r0 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + q * 8];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// k_bcd: the block-coordinate-descent sweep over the K weight columns (:144-156), one block.
+// W (F x K) row-major is updated in place;  opt = (P[:,k] - W M[:,k]) / M[k,k] + W[:,k];
+// W[:,k] = project_weight(opt)  (clamp at 0, divide by the max unless it is 0).
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_bcd(double* __restrict__ W, const double* __restrict__ P,
+                                              const double* __restrict__ M, int F, int K) {
+    extern __shared__ double sm[];       // K (column of M) + 16 (wave maxima)
+    double* mcol = sm;
+    double* wmax = sm + K;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k = 0; k < K; ++k) {
+        const double nk = M[(long long)k * K + k];
+        if (nk <= 1.e-8) {               // component is zero everywhere: zero activation (:147-150)
+            for (int f = tid; f < F; f += nt) W[(long long)f * K + k] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        for (int j = tid; j < K; j += nt) mcol[j] = M[(long long)j * K + k];
+        __syncthreads();
+        double mx = 0.0;
+        for (int f = tid; f < F; f += nt) {
+            const double* wr = W + (long long)f * K;
+            double s = 0.0;
+            for (int j = 0; j < K; ++j) s += wr[j] * mcol[j];
+            double opt = (P[(long long)f * K + k] - s) / nk + wr[k];
+            opt = fmax(0.0, opt);
+            W[(long long)f * K + k] = opt;            // own row only: no cross-thread hazard
+            mx = fmax(mx, opt);
+        }
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+        __syncthreads();
+        mx = 0.0;
+        for (int q = 0; q < (nt >> 6); ++q) mx = fmax(mx, wmax[q]);
+        if (mx != 0.0)
+            for (int f = tid; f < F; f += nt) W[(long long)f * K + k] /= mx;
+        __syncthreads();
+    }
+}
+
+// per component: vertex with the largest |C_k[v]|^2 (first on ties) (:161)
+__global__ __launch_bounds__(256) void k_centres(const double* __restrict__ C, long long n_vert, long long v0,
+                                                 long long* __restrict__ idx_out, double* __restrict__ val_out) {
+    __shared__ double sh_d[256];
+    __shared__ long long sh_i[256];
+    const double* c = C + (long long)blockIdx.x * n_vert * 3;
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long v = threadIdx.x; v < n_vert; v += blockDim.x) {
+        const double e = c[3 * v] * c[3 * v] + c[3 * v + 1] * c[3 * v + 1] + c[3 * v + 2] * c[3 * v + 2];
+        if (am_better(e, v, be, bi)) { be = e; bi = v; }
+    }
+    sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o && am_better(sh_d[threadIdx.x + o], sh_i[threadIdx.x + o], sh_d[threadIdx.x], sh_i[threadIdx.x])) {
+            sh_d[threadIdx.x] = sh_d[threadIdx.x + o];
+            sh_i[threadIdx.x] = sh_i[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { idx_out[blockIdx.x] = v0 + sh_i[0]; val_out[blockIdx.x] = sh_d[0]; }
+}
+
+// --------------------------------------------------------------------------------------
+// k_cholinv: Ginv = (G + rho I)^-1 through a Cholesky factorisation, one block (K <= 128).
+// status[0] = 1 when a pivot is not positive.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cholinv(const double* __restrict__ G, double rho, int K,
+                                                 double* __restrict__ Ginv, int* __restrict__ status) {
+    extern __shared__ double L[];        // K x K
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < K * K; e += nt) L[e] = G[e] + ((e / K == e % K) ? rho : 0.0);
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        const double d = L[j * K + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) status[0] = 1;
+            return;
+        }
+        const double sq = sqrt(d);
+        __syncthreads();
+        for (int i = j + tid; i < K; i += nt) L[i * K + j] = (i == j) ? sq : L[i * K + j] / sq;
+        __syncthreads();
+        for (int e = tid; e < (K - j - 1) * (K - j - 1); e += nt) {
+            const int i = j + 1 + e / (K - j - 1), c = j + 1 + e % (K - j - 1);
+            if (c <= i) L[i * K + c] -= L[i * K + j] * L[c * K + j];
+        }
+        __syncthreads();
+    }
+    // columns of the inverse: thread c solves L y = e_c, L^T x = y, entirely in its own column of
+    // global scratch (Ginv)
+    for (int c = tid; c < K; c += nt) {
+        for (int i = 0; i < K; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s -= L[i * K + j] * Ginv[(long long)j * K + c];
+            Ginv[(long long)i * K + c] = s / L[i * K + i];
+        }
+        for (int i = K - 1; i >= 0; --i) {
+            double s = Ginv[(long long)i * K + c];
+            for (int j = i + 1; j < K; ++j) s -= L[j * K + i] * Ginv[(long long)j * K + c];
+            Ginv[(long long)i * K + c] = s / L[i * K + i];
+        }
+    }
+}
+
+// rhs = c + rho (Z - U)     (:176)
+__global__ __launch_bounds__(256) void k_admm_rhs(const double* __restrict__ c, const double* __restrict__ Z,
+                                                  const double* __restrict__ U, double rho, long long n,
+                                                  double* __restrict__ rhs) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        rhs[e] = c[e] + rho * (Z[e] - U[e]);
+}
+
+// Z = prox_l1l2(Lambda, C + U, 1/rho);  U = U + C - Z     (:177-178, :252-256), one thread per (k, v)
+__global__ __launch_bounds__(256) void k_admm_prox(const double* __restrict__ C, double* __restrict__ Z,
+                                                   double* __restrict__ U, const double* __restrict__ Lambda,
+                                                   double beta, long long kn) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < kn; e += (long long)gridDim.x * blockDim.x) {
+        const double c0 = C[3 * e], c1 = C[3 * e + 1], c2 = C[3 * e + 2];
+        const double u0 = U[3 * e], u1 = U[3 * e + 1], u2 = U[3 * e + 2];
+        const double x0 = c0 + u0, x1 = c1 + u1, x2 = c2 + u2;
+        const double len = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double shrink = fmax(0.0, 1.0 - beta * Lambda[e] / len);      // len == 0 -> -inf -> 0
+        const double z0 = x0 * shrink, z1 = x1 * shrink, z2 = x2 * shrink;
+        Z[3 * e] = z0; Z[3 * e + 1] = z1; Z[3 * e + 2] = z2;
+        U[3 * e] = u0 + c0 - z0; U[3 * e + 1] = u1 + c1 - z1; U[3 * e + 2] = u2 + c2 - z2;
+    }
+}
+
+// block partials of sum a[e]*b[e]  (b == nullptr: sum Lambda-weighted group norms, see host)
+__global__ __launch_bounds__(256) void k_dot_part(const double* __restrict__ a, const double* __restrict__ b,
+                                                  long long n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double v[1] = {0.0};
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        v[0] += a[e] * b[e];
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+// block partials of sum_{k,v} Lambda[k,v] * |C[k,v,:]|     (:184)
+__global__ __launch_bounds__(256) void k_sparsity_part(const double* __restrict__ C, const double* __restrict__ Lambda,
+                                                       long long kn, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double v[1] = {0.0};
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < kn; e += (long long)gridDim.x * blockDim.x)
+        v[0] += Lambda[e] * sqrt(C[3 * e] * C[3 * e] + C[3 * e + 1] * C[3 * e + 1] + C[3 * e + 2] * C[3 * e + 2]);
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(256) void k_sum1(const double* __restrict__ in, int n, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v[0] += in[i];
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) out[0] = v[0];
+}
+
+// W (K x Fp) component-major -> Wfk (F x K) frame-major
+__global__ __launch_bounds__(256) void k_w_to_fk(const double* __restrict__ W, int Fp, int F, int K,
+                                                 double* __restrict__ Wfk) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)F * K;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(e / K), k = (int)(e % K);
+        Wfk[e] = W[(long long)k * Fp + f];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+struct asb_splocs {
+    int64_t K = 0;
+    double *C = nullptr, *Z = nullptr, *U = nullptr, *c = nullptr, *rhs = nullptr, *Lambda = nullptr, *Ct = nullptr;
+    double *Wfk = nullptr, *P = nullptr, *M = nullptr, *G = nullptr, *Ginv = nullptr, *part = nullptr, *red = nullptr;
+    double *cen_val = nullptr;
+    long long* cen_idx = nullptr;
+    int* status = nullptr;
+    size_t part_cap = 0;
+};
+
+static int gemm_tn(asb_ctx* ctx, asb_splocs* s, const double* A, long long lda, const double* B, long long ldb,
+                   long long Rn, int I, int J, double* out) {
+    const int tiles = ((I + 15) / 16) * ((J + 15) / 16);
+    int S = (int)(4096 / (tiles > 0 ? tiles : 1));
+    if (S < 1) S = 1;
+    long long maxS = (Rn + 63) / 64;
+    if (S > maxS) S = (int)maxS;
+    if (S > 64) S = 64;
+    long long slab = ((Rn + S - 1) / S + 3) / 4 * 4;
+    S = (int)((Rn + slab - 1) / slab);
+    const size_t need = (size_t)S * I * J;
+    if (need > s->part_cap) {
+        int rc = asb_alloc(ctx, &s->part, need);
+        if (rc) return rc;
+        s->part_cap = need;
+    }
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64), 0, ctx->stream, A, lda, B, ldb, Rn, I, J, slab,
+                       S == 1 ? out : s->part);
+    if (S > 1) {
+        const long long n = (long long)I * J;
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                           ctx->stream, s->part, S, n, out);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+static int dot_to_host(asb_ctx* ctx, asb_splocs* s, const double* a, const double* b, long long n, double* out) {
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_dot_part, dim3(grid), dim3(256), 0, ctx->stream, a, b, n, s->red);
+    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(256), 0, ctx->stream, s->red, grid, s->red + 1024);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(out, s->red + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+extern "C" int asb_splocs_begin(asb_ctx* ctx) {
+    if (!ctx || !ctx->comps || !ctx->W) return ASB_ERR_ARG;
+    if (ctx->K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "SPLOCS on the device supports K <= 128 (K = %lld)", (long long)ctx->K);
+    if (!ctx->splocs) ctx->splocs = new asb_splocs();
+    asb_splocs* s = ctx->splocs;
+    const int64_t K = ctx->K, n3 = 3 * ctx->n_loc, F = ctx->F;
+    s->K = K;
+    int rc;
+    if ((rc = asb_alloc(ctx, &s->C, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->Z, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->U, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->c, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->rhs, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->Ct, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &s->Lambda, (size_t)K * ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &s->Wfk, (size_t)F * K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->P, (size_t)F * K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->M, (size_t)K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->G, (size_t)K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->Ginv, (size_t)K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->red, (size_t)2048))) return rc;
+    if ((rc = asb_alloc(ctx, &s->cen_val, (size_t)K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->cen_idx, (size_t)K))) return rc;
+    if ((rc = asb_alloc(ctx, &s->status, (size_t)4))) return rc;
+    // C = comps.copy(); W = weigs.copy(); U = 0     (:136-138)
+    ASB_HIP(ctx, hipMemcpyAsync(s->C, ctx->comps, (size_t)K * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(s->U, 0, (size_t)K * n3 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_w_to_fk, dim3(256), dim3(256), 0, ctx->stream, ctx->W, (int)ctx->Fp, (int)F, (int)K, s->Wfk);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// local Gram pieces of the current C:  P = X C^T (F x K),  M = C C^T (K x K), written to the
+// caller's device buffers (to be all-reduced over ranks) or, when NULL, kept inside the context;
+// normX2_local (optional): |X|^2 of the shard.
+extern "C" int asb_splocs_gram(asb_ctx* ctx, double* P_dev, double* M_dev, double* normX2_local) {
+    if (!ctx || !ctx->splocs) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    const int64_t K = s->K, n3 = 3 * ctx->n_loc;
+    double* Pout = P_dev ? P_dev : s->P;
+    double* Mout = M_dev ? M_dev : s->M;
+    dim3 tg((unsigned)((n3 + 31) / 32), (unsigned)((K + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_small, tg, dim3(256), 0, ctx->stream, s->C, (long long)K, (long long)n3, s->Ct);
+    ASB_CHECK_LAUNCH(ctx);
+    int rc;
+    if ((rc = gemm_tn(ctx, s, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout))) return rc;
+    if ((rc = gemm_tn(ctx, s, s->Ct, K, s->Ct, K, n3, (int)K, (int)K, Mout))) return rc;
+    if (normX2_local) return dot_to_host(ctx, s, ctx->X, ctx->X, (long long)n3 * ctx->Fp, normX2_local);
+    return ASB_OK;
+}
+
+// weight sweep with the (all-reduced) P, M; then G = W^T W.  centres: per component the
+// shard's vertex of largest displacement (global index) and its value.
+extern "C" int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const double* M_dev, int64_t* centre_idx,
+                                  double* centre_val) {
+    if (!ctx || !ctx->splocs) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    const int K = (int)s->K, F = (int)ctx->F;
+    if (P_dev) ASB_HIP(ctx, hipMemcpyAsync(s->P, P_dev, (size_t)F * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (M_dev) ASB_HIP(ctx, hipMemcpyAsync(s->M, M_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bcd, dim3(1), dim3(1024), (K + 16) * sizeof(double), ctx->stream, s->Wfk, s->P, s->M, F, K);
+    ASB_CHECK_LAUNCH(ctx);
+    int rc = gemm_tn(ctx, s, s->Wfk, K, s->Wfk, K, F, K, K, s->G);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_centres, dim3(K), dim3(256), 0, ctx->stream, s->C, (long long)ctx->n_loc, (long long)ctx->v0,
+                       s->cen_idx, s->cen_val);
+    ASB_CHECK_LAUNCH(ctx);
+    if (centre_idx) ASB_HIP(ctx, hipMemcpyAsync(centre_idx, s->cen_idx, K * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (centre_val) ASB_HIP(ctx, hipMemcpyAsync(centre_val, s->cen_val, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// ADMM (:168-181) with Lambda (K, n_loc) from the host; leaves C = Z.
+extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, int n_iter) {
+    if (!ctx || !ctx->splocs || !Lambda) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    const int64_t K = s->K, n3 = 3 * ctx->n_loc, kn = K * ctx->n_loc;
+    ASB_HIP(ctx, hipMemcpyAsync(s->Lambda, Lambda, (size_t)kn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // c = W^T X  (K x 3n): the deflation's projection kernel, 16 columns per pass over X
+    for (int64_t k0 = 0; k0 < K; k0 += 16) {
+        const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
+        int rc = asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3);
+        if (rc) return rc;
+    }
+    ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
+    if ((size_t)K * K * sizeof(double) > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_cholinv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(K * K * sizeof(double))));
+    hipLaunchKernelGGL(k_cholinv, dim3(1), dim3(256), (size_t)K * K * sizeof(double), ctx->stream, s->G, rho, (int)K,
+                       s->Ginv, s->status);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(s->Z, s->C, (size_t)K * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // Z = C.copy()
+    const long long n = (long long)K * n3;
+    const int eg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    const int pg = (int)((kn + 255) / 256 < 4096 ? (kn + 255) / 256 : 4096);
+    for (int it = 0; it < n_iter; ++it) {
+        hipLaunchKernelGGL(k_admm_rhs, dim3(eg), dim3(256), 0, ctx->stream, s->c, s->Z, s->U, rho, n, s->rhs);
+        int rc = gemm_tn(ctx, s, s->Ginv, K, s->rhs, n3, K, (int)K, (int)n3, s->C);      // C = (G + rho I)^-1 rhs
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_admm_prox, dim3(pg), dim3(256), 0, ctx->stream, s->C, s->Z, s->U, s->Lambda, 1.0 / rho, kn);
+    }
+    ASB_HIP(ctx, hipMemcpyAsync(s->C, s->Z, (size_t)K * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // C = Z
+    ASB_CHECK_LAUNCH(ctx);
+    int st[4];
+    ASB_HIP(ctx, hipMemcpyAsync(st, s->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[0]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "SPLOCS: W^T W + rho I is not positive definite");
+    return ASB_OK;
+}
+
+// objective pieces after asb_splocs_gram() was called for the NEW C (with all-reduced P, M):
+// wp = <W, P>, gm = <G, M>, sparsity_local = sum Lambda |C_v|   (:183-186)
+extern "C" int asb_splocs_objective(asb_ctx* ctx, const double* P_dev, const double* M_dev, double* wp, double* gm,
+                                    double* sparsity_local) {
+    if (!ctx || !ctx->splocs) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    const int64_t K = s->K;
+    if (P_dev) ASB_HIP(ctx, hipMemcpyAsync(s->P, P_dev, (size_t)ctx->F * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (M_dev) ASB_HIP(ctx, hipMemcpyAsync(s->M, M_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    int rc;
+    if (wp && (rc = dot_to_host(ctx, s, s->Wfk, s->P, (long long)ctx->F * K, wp))) return rc;
+    if (gm && (rc = dot_to_host(ctx, s, s->G, s->M, (long long)K * K, gm))) return rc;
+    if (sparsity_local) {
+        const long long kn = K * ctx->n_loc;
+        const int grid = (int)((kn + 255) / 256 < 1024 ? (kn + 255) / 256 : 1024);
+        hipLaunchKernelGGL(k_sparsity_part, dim3(grid), dim3(256), 0, ctx->stream, s->C, s->Lambda, kn, s->red);
+        hipLaunchKernelGGL(k_sum1, dim3(1), dim3(256), 0, ctx->stream, s->red, grid, s->red + 1024);
+        ASB_CHECK_LAUNCH(ctx);
+        ASB_HIP(ctx, hipMemcpyAsync(sparsity_local, s->red + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ASB_OK;
+}
+
+// refined components (K, n_loc, 3) and weights (F, K); either may be NULL
+extern "C" int asb_splocs_results(asb_ctx* ctx, double* C_out, double* W_out) {
+    if (!ctx || !ctx->splocs) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    if (C_out) ASB_HIP(ctx, hipMemcpyAsync(C_out, s->C, (size_t)s->K * 3 * ctx->n_loc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (W_out) ASB_HIP(ctx, hipMemcpyAsync(W_out, s->Wfk, (size_t)ctx->F * s->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+void asb_splocs_free(asb_ctx* ctx) {
+    if (ctx->splocs) {
+        delete ctx->splocs;       // device buffers are released through ctx->alloc_bytes
+        ctx->splocs = nullptr;
+    }
+}

@@ -80,6 +80,30 @@ class Comm(object):
             return
         self.dist.all_gather_into_tensor(recs, rec, group=self.group)
 
+    def new_gram_buffers(self, F, K, on_device):
+        """Device buffers for the partial Gram matrices P (F x K) and M (K x K) of SPLOCS."""
+        torch = self._torch
+        dev = self._dev if on_device else torch.device("cpu")
+        return (torch.zeros(F * K, dtype=torch.float64, device=dev), torch.zeros(K * K, dtype=torch.float64, device=dev))
+
+    def allreduce_tensor(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def global_argmax(self, idx, val):
+        """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties."""
+        if self.world == 1:
+            return idx
+        torch = self._torch
+        loc = torch.from_numpy(np.stack([val, idx.astype(np.float64)])).to(self._dev)
+        outs = [torch.empty_like(loc) for _ in range(self.world)]
+        self.dist.all_gather(outs, loc, group=self.group)
+        allv = np.stack([o.cpu().numpy() for o in outs])          # (world, 2, K)
+        best = np.empty(idx.shape[0], dtype=np.int64)
+        for k in range(idx.shape[0]):
+            order = sorted(range(self.world), key=lambda r: (-allv[r, 0, k], allv[r, 1, k]))
+            best[k] = int(allv[order[0], 1, k])
+        return best
+
     def all_gather_rows(self, local, N, axis):
         """Concatenates per-rank blocks along ``axis`` (block sizes follow ``partition``)."""
         if self.world == 1:

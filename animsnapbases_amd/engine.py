@@ -152,6 +152,42 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_download_residual(self.h, ptr(out)))
         return out
 
+    # ------------------------------------------------------------------ SPLOCS
+    def splocs_begin(self):
+        self._ck(self.lib.asb_splocs_begin(self.h))
+
+    def splocs_gram(self, P_dev_ptr=None, M_dev_ptr=None, want_norm=False):
+        nx = ctypes.c_double()
+        self._ck(self.lib.asb_splocs_gram(self.h, ctypes.c_void_p(P_dev_ptr) if P_dev_ptr else None,
+                                          ctypes.c_void_p(M_dev_ptr) if M_dev_ptr else None,
+                                          ctypes.byref(nx) if want_norm else None))
+        return nx.value if want_norm else None
+
+    def splocs_weights(self, P_dev_ptr=None, M_dev_ptr=None):
+        idx = np.empty(self.K, dtype=np.int64)
+        val = np.empty(self.K)
+        self._ck(self.lib.asb_splocs_weights(self.h, ctypes.c_void_p(P_dev_ptr) if P_dev_ptr else None,
+                                             ctypes.c_void_p(M_dev_ptr) if M_dev_ptr else None, ptr(idx), ptr(val)))
+        return idx, val
+
+    def splocs_admm(self, Lambda_loc, rho, n_iter):
+        Lambda_loc = np.ascontiguousarray(Lambda_loc, dtype=np.float64)
+        assert Lambda_loc.shape == (self.K, self.n_loc)
+        self._ck(self.lib.asb_splocs_admm(self.h, ptr(Lambda_loc), float(rho), int(n_iter)))
+
+    def splocs_objective(self, P_dev_ptr=None, M_dev_ptr=None):
+        wp, gm, sp = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._ck(self.lib.asb_splocs_objective(self.h, ctypes.c_void_p(P_dev_ptr) if P_dev_ptr else None,
+                                               ctypes.c_void_p(M_dev_ptr) if M_dev_ptr else None, ctypes.byref(wp),
+                                               ctypes.byref(gm), ctypes.byref(sp)))
+        return wp.value, gm.value, sp.value
+
+    def splocs_results(self):
+        C = np.empty((self.K, self.n_loc, 3))
+        W = np.empty((self.F, self.K))
+        self._ck(self.lib.asb_splocs_results(self.h, ptr(C), ptr(W)))
+        return C, W
+
     # ------------------------------------------------------------------ post-processing
     def components_post(self, unscale, pre_scale_factor, invMassL_loc=None):
         out = np.empty((self.K, self.n_loc, 3))

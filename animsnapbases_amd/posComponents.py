@@ -155,8 +155,73 @@ class posComponents:  # Components == bases
 
     @log_time("")
     def splocs_glob_optimization(self, num_iters_max, num_admm_iterations, R, compute_geodesic_distance):
-        """posComponents.py:131-189 -- device implementation pending."""
-        raise NotImplementedError("SPLOCS refinement on the GPU is not built yet; there is no CPU fallback")
+        """posComponents.py:131-189 on the GPU (csrc/asb_splocs.hip).
+
+        Like the reference, this leaves ``comps`` / ``weigs`` untouched (the reference works on
+        local copies and discards them) and prints one
+        ``itr %03d, Energy =%f, Error =%f`` line per outer iteration.  Extras: the refined
+        ``splocs_comps`` (K,N,3), ``splocs_weigs`` (F,K), ``splocs_trace`` (its,2) and
+        ``splocs_centres`` (its,K) attributes.  ``R`` is accepted for signature compatibility;
+        the device works from X, W and C (the residual is never formed).
+        """
+        snaps = self.pos_snapshots
+        eng, comm = snaps._engine, snaps._comm
+        K, N, F = self.numComp, snaps.nVerts, snaps.frs
+        v0, n_loc = snaps._shards[comm.rank]
+        lam, rho = self.param.splocs_lambda, self.param.splocs_rho
+        if compute_geodesic_distance is None:
+            raise ValueError("SPLOCS needs the mesh triangles (geodesic support maps)")
+        eng.splocs_begin()
+        Pbuf = Mbuf = None
+        if comm.world > 1:
+            Pbuf, Mbuf = comm.new_gram_buffers(F, K, eng.device_exchange)
+
+        def gram(want_norm=False):
+            nx = eng.splocs_gram(Pbuf.data_ptr() if Pbuf is not None else None,
+                                 Mbuf.data_ptr() if Mbuf is not None else None, want_norm)
+            if comm.world > 1:                 # partial Gram matrices: RCCL all-reduce (sum) over the ranks
+                comm.allreduce_tensor(Pbuf)
+                comm.allreduce_tensor(Mbuf)
+            return nx
+
+        def ptrs():
+            return (Pbuf.data_ptr(), Mbuf.data_ptr()) if Pbuf is not None else (None, None)
+
+        normX2 = comm.allreduce_sum(gram(True))[0]
+        phi_cache = {}
+        trace, centres = [], []
+        for it in range(num_iters_max):
+            cidx, cval = eng.splocs_weights(*ptrs())                          # :144-156, :161
+            if comm.world > 1:
+                cidx = comm.global_argmax(cidx, cval)
+            missing = [int(i) for i in dict.fromkeys(cidx.tolist()) if int(i) not in phi_cache]
+            if missing:
+                many = getattr(compute_geodesic_distance, "solve_many", None)
+                phis = many(missing) if many else [compute_geodesic_distance(i) for i in missing]
+                for i, phi in zip(missing, phis):
+                    phi_cache[i] = phi
+            Lambda = np.empty((K, n_loc))
+            for k in range(K):                                                # :162-165
+                phi = phi_cache[int(cidx[k])]
+                smap = (clip(phi, self.smooth_min_dist, self.smooth_max_dist) - self.smooth_min_dist) \
+                    / (self.smooth_max_dist - self.smooth_min_dist)
+                Lambda[k] = lam * smap[v0:v0 + n_loc]
+            eng.splocs_admm(Lambda, rho, num_admm_iterations)                 # :167-181
+            gram()
+            wp, gm, sp = eng.splocs_objective(*ptrs())
+            sparsity = comm.allreduce_sum(sp)[0]
+            r2 = max(normX2 - 2.0 * wp + gm, 0.0)                             # |X - W C|^2
+            E_rms = np.sqrt(r2) / sqrt(3 * N * F)
+            energy = r2 + sparsity
+            trace.append([energy, E_rms])
+            centres.append(cidx.copy())
+            if comm.rank == 0:
+                print("itr %03d, Energy =%f, Error =%f" % (it, energy, E_rms))
+        C_loc, W_new = eng.splocs_results()
+        self.splocs_comps = comm.all_gather_rows(C_loc, N, axis=1)
+        self.splocs_weigs = W_new
+        self.splocs_trace = np.array(trace)
+        self.splocs_centres = np.array(centres, dtype=np.int64)
 
     @log_time("")
     def compute_components_store_singvalues(self):

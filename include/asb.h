@@ -130,6 +130,30 @@ int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
                         const double* invMassL_loc, double* comps_out);
 
+/* ------------------------------------------------ SPLOCS refinement ----------- */
+/* posComponents.splocs_glob_optimization, snapbases/posComponents.py:132-189.
+ * State after a residual-mode deflation: C = comps, W = weigs, U = 0 (:135-139).  One outer
+ * iteration = weights -> (host support maps) -> admm -> gram -> objective.  The F x 3N
+ * residual is never formed (see csrc/asb_splocs.hip).  K <= 128. */
+int asb_splocs_begin(asb_ctx* ctx);
+/* P = X C^T (F x K) and M = C C^T (K x K) of this shard for the CURRENT C, into the
+ * caller's device buffers (to be all-reduced over ranks) or into the context when NULL.
+ * normX2_local (optional): |X|^2 of the shard. */
+int asb_splocs_gram(asb_ctx* ctx, double* P_dev, double* M_dev, double* normX2_local);
+/* :144-156 weight sweep with the (all-reduced) P, M (NULL: the context's own), G = W^T W;
+ * centre_idx/val (K): per component this shard's vertex of largest |C_k[v]|^2 (:161). */
+int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const double* M_dev,
+                       int64_t* centre_idx, double* centre_val);
+/* :167-181 ADMM with Lambda (host, K x n_loc) = splocs_lambda * support_map; C = Z at the end */
+int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, int n_iter);
+/* :183-186 pieces of the objective for the new C (call asb_splocs_gram first):
+ * wp = <W, P>, gm = <W^T W, M>  =>  |X - W C|^2 = |X|^2 - 2 wp + gm;
+ * sparsity_local = sum Lambda |C_v| over the shard. */
+int asb_splocs_objective(asb_ctx* ctx, const double* P_dev, const double* M_dev, double* wp,
+                         double* gm, double* sparsity_local);
+/* refined components (K, n_loc, 3) and weights (F, K); either may be NULL */
+int asb_splocs_results(asb_ctx* ctx, double* C_out, double* W_out);
+
 /* ------------------------------------------------ host-side probes ----------- */
 /* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
  * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */

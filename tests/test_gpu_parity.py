@@ -229,3 +229,44 @@ def test_project_mode_many_panels(kind, N, F, K):
         assert relerr(weigs, ref["weigs"]) < 1e-8
         assert relerr(outs[mode]["sigma"], ref["measures"][:, 1]) < 1e-9
         assert relerr(np.sqrt(outs[mode]["normR2_local"]), ref["measures"][:, 2]) < 1e-6
+
+
+def test_splocs_vs_reference_golden(capsys):
+    """SPLOCS refinement on the GPU against the trace / refined components the unmodified reference
+    produced (captured through pass-through wrappers, oracle/gen_golden.py)."""
+    g = load_golden("splocs_small")
+    param = _param(g, splocs_max_itrs=int(g["param_splocs_max_itrs"]),
+                   splocs_admm_num_itrs=int(g["param_splocs_admm_num_itrs"]),
+                   splocs_lambda=float(g["param_splocs_lambda"]), splocs_rho=float(g["param_splocs_rho"]))
+    snaps, comp = _run(g["verts"], g["tris"], param)
+    # fact 2 of SURVEY.md: comps / weigs are those of PCA-local, untouched by SPLOCS
+    assert comp.selected_vertices.tolist() == g["idx"].tolist()
+    assert relerr(comp.comps, g["comps"]) < 1e-8
+    assert relerr(comp.weigs, g["weigs"]) < TOL
+    # the reference prints %f (6 decimals): compare parsed floats (SURVEY.md 8d)
+    assert np.allclose(comp.splocs_trace, g["splocs_trace"], rtol=1e-8, atol=2e-6)
+    assert comp.splocs_centres.tolist() == g["splocs_centres"].tolist()
+    assert relerr(comp.splocs_comps, g["splocs_C_final"]) < 1e-8
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith("itr ")]
+    assert len(lines) == int(g["param_splocs_max_itrs"]) and lines[0].startswith("itr 000, Energy =")
+
+
+def test_splocs_vs_oracle_medium():
+    """A larger SPLOCS run (K = 12, 4 outer x 5 ADMM) against the NumPy oracle."""
+    rest_v, tris = orc.synth_mesh(14, 20, seed=8)          # N = 282
+    verts = orc.synth_snapshots(rest_v, 60, rank=8, seed=8, kind="bumps")
+    K = 12
+    param = _param(vertPos_numComponents=K, q_support="local", vertPos_bases_type="SPLOCS",
+                   vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.4, splocs_max_itrs=4,
+                   splocs_admm_num_itrs=5, splocs_lambda=2.0, splocs_rho=10.0)
+    snaps, comp = _run(verts, tris, param)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris)
+    d = orc.extract_k_components(pre["snapTensor"], K, "local", geo, 0.1, 0.4)
+    s = orc.splocs_glob_optimization(pre["snapTensor"], d["comps"], d["weigs"], d["R"], geo, 0.1, 0.4, 4, 5, 2.0, 10.0)
+    assert comp.selected_vertices.tolist() == d["idx"].tolist()
+    assert comp.splocs_centres.tolist() == s["idx"].tolist()
+    assert np.allclose(comp.splocs_trace, s["trace"], rtol=1e-8)
+    assert relerr(comp.splocs_comps, s["C"]) < 1e-8
+    assert relerr(comp.splocs_weigs, s["W"]) < 1e-8
