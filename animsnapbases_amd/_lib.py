@@ -43,6 +43,16 @@ PROTOTYPES = {
     "asb_deflate_apply": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_deflate_run_global": (c_int, [ctypes.c_void_p, c_i64, c_i64]),
     "asb_deflate_results": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_panel_scale": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_dbl]),
+    "asb_panel_hist": (c_int, [ctypes.c_void_p, c_int, c_dp]),
+    "asb_panel_tau": (c_int, [ctypes.c_void_p, c_int, c_dp]),
+    "asb_panel_select": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_int, c_dp, c_dp, ctypes.POINTER(c_i64),
+                                 ctypes.POINTER(c_int)]),
+    "asb_panel_capacity": (c_i64, [ctypes.c_void_p]),
+    "asb_panel_assemble": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_int, c_i64]),
+    "asb_panel_run": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
+    "asb_panel_project": (c_int, [ctypes.c_void_p, c_i64, c_int]),
+    "asb_panel_refresh": (c_int, [ctypes.c_void_p, c_i64, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_post": (c_int, [ctypes.c_void_p, c_int, c_dbl, c_dp, c_dp]),

@@ -74,6 +74,7 @@ struct asb_ctx {
     long long* cpidx = nullptr;
     double* cpsum = nullptr;
     int cnblk = 0;
+    int64_t n_slots_host = 0;   // candidates in the assembled (multi-rank) buffer
     double* colpart = nullptr;   // (blocks, 16)
     double* gram = nullptr;      // (K, 16) w_j . w_panel
     long long* ctmp = nullptr;   // compaction scratch

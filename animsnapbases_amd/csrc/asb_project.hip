@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void k_range_init(const double* pmax, const lo
     }
 }
 
+// level-1 histogram range: [0, E0max] (energies never increase)
+__global__ void k_range_l1(double* __restrict__ sc) {
+    sc[SC_LO] = 0.0;
+    sc[SC_HI] = sc[SC_E0MAX];
+    sc[SC_ABOVE] = 0.0;
+}
+
 // hist[b] = #{ lo <= e < hi falling in bin b }, the top edge is inclusive at level 1
 __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long long n, const double* __restrict__ sc,
                                               int* __restrict__ hist, int top_inclusive) {
@@ -243,9 +250,8 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
 }
 
 __global__ __launch_bounds__(256) void k_compact_b(const long long* __restrict__ tmp, const long long* __restrict__ cnt,
-                                                   int nb, long long n, const double* __restrict__ sc, int take_all,
-                                                   long long m_cap, long long* __restrict__ cand_idx,
-                                                   PanelState* __restrict__ panel, double margin_rel) {
+                                                   int nb, long long m_cap, long long* __restrict__ cand_idx,
+                                                   PanelState* __restrict__ panel) {
     __shared__ long long off[ASB_CBLOCKS + 1];
     if (threadIdx.x == 0) {
         long long acc = 0;
@@ -260,34 +266,39 @@ __global__ __launch_bounds__(256) void k_compact_b(const long long* __restrict__
             if (off[b] + q < m_cap) cand_idx[off[b] + q] = tmp[(long long)b * m_cap + q];
     }
     if (threadIdx.x == 0) {
-        const bool overflow = total > m_cap;
-        const double tau = take_all ? -1.0e300 : sc[SC_TAU];
-        panel->n_cand = overflow ? m_cap : total;
-        // every non-candidate has E <= tau; with dropped candidates nothing can be proven
-        panel->theta = overflow ? 1.0e300 : ((take_all || total >= n) ? -1.0e300 : tau);
-        panel->margin = margin_rel * sc[SC_E0MAX];
-        panel->done = 0;
-        panel->committed = 0;
+        panel->n_cand = total > m_cap ? m_cap : total;
+        panel->pad = total > m_cap ? 1 : 0;          // overflow: some candidates were dropped
     }
 }
 
-// forced single step (degenerate ties): the only candidate is the first arg-max of E.
-__global__ __launch_bounds__(256) void k_force_single(const double* pmax, const long long* pidx, const double* psum,
-                                                      int nblk, long long v0, long long* __restrict__ cand_idx,
-                                                      PanelState* __restrict__ panel) {
+// arms the panel: every vertex outside the candidate buffer has energy <= theta
+__global__ void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
+                            long long n_slots, double margin_rel) {
+    if (n_slots >= 0) panel->n_cand = n_slots;
+    panel->theta = global_all ? -1.0e300 : (panel->pad ? 1.0e300 : sc[SC_TAU]);
+    panel->margin = margin_rel * sc[SC_E0MAX];
+    panel->done = 0;
+    panel->committed = 0;
+}
+
+// forced single candidate (degenerate ties): global vertex id gidx if this shard owns it
+__global__ void k_force_single(long long gidx, long long v0, long long n_loc, long long* __restrict__ cand_idx,
+                               PanelState* __restrict__ panel) {
+    const bool mine = gidx >= v0 && gidx < v0 + n_loc;
+    if (mine) cand_idx[0] = gidx;
+    panel->n_cand = mine ? 1 : 0;
+    panel->pad = 0;
+}
+
+// first arg-max of the energies over the last pass's block partials -> out[0] = energy, out[1] = local idx bits
+__global__ __launch_bounds__(256) void k_best_energy(const double* pmax, const long long* pidx, const double* psum, int nblk,
+                                                     double* __restrict__ out) {
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
     double be, bs;
     long long bi;
     reduce_partials(pmax, pidx, psum, nblk, sh_d, sh_i, be, bi, bs);
-    if (threadIdx.x == 0) {
-        cand_idx[0] = v0 + bi;
-        panel->n_cand = 1;
-        panel->theta = -1.0e300;
-        panel->margin = 0.0;
-        panel->done = 0;
-        panel->committed = 0;
-    }
+    if (threadIdx.x == 0) { out[0] = be; out[1] = __longlong_as_double(bi); out[2] = bs; }
 }
 
 // --------------------------------------------------------------------------------------
@@ -662,54 +673,119 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     return ASB_OK;
 }
 
-// candidate selection for one panel; mode 0 normal, 1 forced single candidate
-static int panel_select(asb_ctx* ctx, long long k, int forced) {
-    const StreamCfg c = ctx->cfg;
+#define ASB_MARGIN_REL 1.0e-11
+
+static int hist_grid(const asb_ctx* ctx) {
     const long long n = ctx->n_loc;
-    if (forced) {
-        hipLaunchKernelGGL(k_force_single, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
-                           (long long)ctx->v0, ctx->cand_idx, ctx->pstate);
-        ASB_CHECK_LAUNCH(ctx);
-    } else {
-        const int take_all = n <= ctx->m_cap;
-        if (!take_all) {
-            const int hgrid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-            hipLaunchKernelGGL(k_range_init, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
-                               ctx->scalar_dev, 0);
-            for (int level = 1; level <= 2; ++level) {
-                ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
-                hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->energy, n, ctx->scalar_dev, ctx->hist,
-                                   level == 1 ? 1 : 0);
-                hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level,
-                                   (long long)ctx->m_target, (long long)ctx->m_cap);
-            }
-            ASB_CHECK_LAUNCH(ctx);
-        }
-        hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0,
-                           ctx->scalar_dev, take_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt);
-        hipLaunchKernelGGL(k_compact_b, dim3(1), dim3(256), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS, n,
-                           ctx->scalar_dev, take_all, (long long)ctx->m_cap, ctx->cand_idx, ctx->pstate, 1.0e-11);
-        ASB_CHECK_LAUNCH(ctx);
+    return (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+}
+
+// level-1 range is always [0, E0max] (energies only decrease), level 2 the crossing bin
+extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    int* h = hist_dev ? hist_dev : ctx->hist;
+    if (level == 1) {
+        hipLaunchKernelGGL(k_range_l1, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev);
     }
-    // exact residual rows of the candidates
-    const int ggrid = stream_grid(ctx, c, ctx->m_cap);
-    launch_gather(ctx, c, ggrid, ctx->cand_idx, (long long)ctx->m_cap, ctx->pstate, (int)k, ctx->candR, ctx->cand_e,
-                  ctx->cpmax, ctx->cpidx, ctx->cpsum);
+    ASB_HIP(ctx, hipMemsetAsync(h, 0, ASB_NBINS * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_hist, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc,
+                       ctx->scalar_dev, h, level == 1 ? 1 : 0);
     ASB_CHECK_LAUNCH(ctx);
-    ctx->cnblk = ggrid;
     return ASB_OK;
 }
 
-// up to `steps` greedy steps on the candidate buffer; returns the number committed
-static int panel_steps(asb_ctx* ctx, long long k0, int steps, long long* committed) {
+extern "C" int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, hist_dev ? hist_dev : ctx->hist, ctx->scalar_dev, level,
+                       (long long)ctx->m_target, (long long)ctx->m_cap);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// ordered compaction of this shard's candidates (E > tau; all vertices when global_all; only
+// forced_gidx when >= 0) and their exact residual rows.  rows_out / idx_out: caller's device
+// buffers of capacity m_cap (multi-rank staging) or NULL for the context's own candidate buffer.
+extern "C" int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, int global_all, double* rows_out,
+                                long long* idx_out, int64_t* n_local, int* overflow) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    if (!pick_cfg(ctx->Fp, ctx->cfg)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
     const StreamCfg c = ctx->cfg;
+    const long long n = ctx->n_loc;
+    double* rows = rows_out ? rows_out : ctx->candR;
+    long long* idx = idx_out ? idx_out : ctx->cand_idx;
+    if (forced_gidx >= 0) {
+        hipLaunchKernelGGL(k_force_single, dim3(1), dim3(1), 0, ctx->stream, (long long)forced_gidx, (long long)ctx->v0, n,
+                           idx, ctx->pstate);
+    } else {
+        hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0,
+                           ctx->scalar_dev, global_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt);
+        hipLaunchKernelGGL(k_compact_b, dim3(1), dim3(256), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS,
+                           (long long)ctx->m_cap, idx, ctx->pstate);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    const int ggrid = stream_grid(ctx, c, ctx->m_cap);
+    launch_gather(ctx, c, ggrid, idx, (long long)ctx->m_cap, ctx->pstate, (int)k, rows, ctx->cand_e, ctx->cpmax, ctx->cpidx,
+                  ctx->cpsum);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->cnblk = ggrid;
+    if (n_local || overflow) {
+        PanelState h;
+        ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_local) *n_local = h.n_cand;
+        if (overflow) *overflow = (int)h.pad;
+    }
+    return ASB_OK;
+}
+
+// multi-rank: builds the (replicated) global candidate buffer from the all-gathered, padded
+// per-rank pieces: rows_g (world, maxcount, 3, Fp), idx_g (world, maxcount), counts (world).
+extern "C" int asb_panel_assemble(asb_ctx* ctx, const double* rows_g, const long long* idx_g, const int64_t* counts,
+                                  int world, int64_t maxcount) {
+    if (!ctx || !ctx->candR || !rows_g || !idx_g || !counts) return ASB_ERR_ARG;
+    const size_t row_b = (size_t)3 * ctx->Fp * sizeof(double);
+    int64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+        const int64_t c = counts[r];
+        if (c < 0 || c > maxcount) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_assemble: bad count");
+        if (off + c > ctx->m_cap) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_panel_assemble: %lld candidates exceed the capacity %lld",
+                                           (long long)(off + c), (long long)ctx->m_cap);
+        if (c > 0) {
+            ASB_HIP(ctx, hipMemcpyAsync((char*)ctx->candR + (size_t)off * row_b, (const char*)rows_g + (size_t)r * maxcount * row_b,
+                                        (size_t)c * row_b, hipMemcpyDeviceToDevice, ctx->stream));
+            ASB_HIP(ctx, hipMemcpyAsync(ctx->cand_idx + off, idx_g + (size_t)r * maxcount, (size_t)c * sizeof(long long),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        off += c;
+    }
+    ctx->n_slots_host = off;
+    return ASB_OK;
+}
+
+// up to `steps` greedy steps on the context's candidate buffer (asb_panel_select with NULL
+// buffers, or asb_panel_assemble); returns the number of components committed.
+extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int64_t* committed) {
+    if (!ctx || !ctx->candR || ctx->mode != ASB_DEFLATE_PROJECT || !committed) return ASB_ERR_ARG;
+    if (steps < 1 || steps > ASB_PANEL_COLS || k0 < 0 || k0 + steps > ctx->K)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_run: bad range k0=%lld steps=%d", (long long)k0, steps);
+    const StreamCfg c = ctx->cfg;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ctx->m_cap * 3))) return rc;
+    hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(1), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
+                       (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL);
+    const int grid = stream_grid(ctx, c, ctx->m_cap);
+    if (assembled) {      // energies / partial records of the assembled buffer (rows came from other ranks)
+        StreamArgs a{ctx->candR, nullptr, nullptr, nullptr, nullptr, ctx->cand_e, ctx->cpmax, ctx->cpidx, ctx->cpsum,
+                     (long long)ctx->m_cap, ctx->pstate};
+        launch_stream(ctx, c, false, grid, a);
+        ctx->cnblk = grid;
+    }
     for (int t = 0; t < steps; ++t) {
         const long long k = k0 + t;
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, ctx->stream, ctx->candR, ctx->cpmax, ctx->cpidx, ctx->cpsum,
                            ctx->cnblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
                            (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k, (long long)ctx->K, 0, ctx->pstate,
-                           ctx->cand_idx, k0);
-        const int grid = stream_grid(ctx, c, ctx->m_cap);
+                           ctx->cand_idx, (long long)k0);
         StreamArgs a{ctx->candR, ctx->W + k * ctx->Fp, ctx->scal + k * 4, nullptr, ctx->cand_c, ctx->cand_e,
                      ctx->cpmax, ctx->cpidx, ctx->cpsum, (long long)ctx->m_cap, ctx->pstate};
         launch_stream(ctx, c, true, grid, a);
@@ -720,46 +796,111 @@ static int panel_steps(asb_ctx* ctx, long long k0, int steps, long long* committ
     ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *committed = h.committed;
+    ctx->n_panels++;
+    if (getenv("ASB_DEBUG_PANELS")) {
+        double sc[8];
+        (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[asb] panel at k=%lld: n_cand=%lld committed=%lld theta=%.6f tau=%.6f\n", (long long)k0, h.n_cand,
+                h.committed, h.theta, sc[SC_TAU]);
+    }
     return ASB_OK;
 }
 
-int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
+// ONE pass over X: c_k for all vertices of the shard, energies, partial records
+extern "C" int asb_panel_project(asb_ctx* ctx, int64_t k0, int ncols) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    if (ncols < 1 || ncols > ASB_PANEL_COLS || k0 < 0 || k0 + ncols > ctx->K)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_project: bad range");
+    int rc = project_pass(ctx, k0, ncols);
+    if (rc) return rc;
+    ctx->k_done = k0 + ncols;
+    return ASB_OK;
+}
+
+// fallback: exact energies of ALL vertices of the shard (X_v - sum_j c_j w_j recomputed);
+// best_energy / best_gidx (optional, synchronises): the shard's first arg-max afterwards.
+extern "C" int asb_panel_refresh(asb_ctx* ctx, int64_t k, double* best_energy, int64_t* best_gidx) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
     if (!pick_cfg(ctx->Fp, ctx->cfg)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    const int ggrid = stream_grid(ctx, ctx->cfg, ctx->n_loc);
+    launch_gather(ctx, ctx->cfg, ggrid, nullptr, (long long)ctx->n_loc, nullptr, (int)k, nullptr, ctx->energy, ctx->pmax,
+                  ctx->pidx, ctx->psum);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->nblk = ggrid;
+    ctx->n_refresh++;
+    if (best_energy || best_gidx) {
+        hipLaunchKernelGGL(k_best_energy, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
+                           ctx->scalar_dev + 8);
+        double h[3];
+        ASB_HIP(ctx, hipMemcpyAsync(h, ctx->scalar_dev + 8, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best_energy) *best_energy = h[0];
+        if (best_gidx) {
+            long long li;
+            memcpy(&li, &h[1], 8);
+            *best_gidx = ctx->v0 + li;
+        }
+    }
+    return ASB_OK;
+}
+
+// |X|^2 and the initial maximum energy of this shard; set_e0max >= 0 installs the GLOBAL maximum
+// (histogram range and rounding margin must be identical on every rank).
+extern "C" int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max_local, double set_e0max) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    if (normX2_local || e0max_local) {
+        double sc[8];
+        ASB_HIP(ctx, hipMemcpyAsync(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (normX2_local) *normX2_local = sc[SC_NORMX2];
+        if (e0max_local) *e0max_local = sc[SC_E0MAX];
+    }
+    if (set_e0max >= 0.0)
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->scalar_dev + SC_E0MAX, &set_e0max, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return ASB_OK;
+}
+
+extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_cap : 0; }
+
+// single-rank driver: all K components with no host round trip inside a panel
+int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ctx->m_cap * 3))) return rc;
     long long k = k0;
     int stalled = 0;
+    const int global_all = ctx->n_loc <= ctx->m_cap;
     while (k < k1) {
-        if ((rc = panel_select(ctx, k, stalled >= 2))) return rc;
-        int steps = (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
-        long long done = 0;
-        if ((rc = panel_steps(ctx, k, steps, &done))) return rc;
-        ctx->n_panels++;
-        if (getenv("ASB_DEBUG_PANELS")) {
-            PanelState h;
-            double sc[8];
-            (void)hipMemcpy(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[asb] panel at k=%lld: n_cand=%lld committed=%lld theta=%.6f emax=%.6f above=%g\n", k, h.n_cand,
-                    h.committed, h.theta, sc[SC_EMAX], sc[SC_ABOVE]);
+        int64_t forced = -1;
+        if (stalled >= 2) {        // massive exact ties: the first arg-max of the (exact) energies alone
+            double be;
+            hipLaunchKernelGGL(k_best_energy, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
+                               ctx->scalar_dev + 8);
+            double h[3];
+            ASB_HIP(ctx, hipMemcpyAsync(h, ctx->scalar_dev + 8, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            long long li;
+            memcpy(&li, &h[1], 8);
+            forced = ctx->v0 + li;
+            (void)be;
+        } else if (!global_all) {
+            for (int level = 1; level <= 2; ++level) {
+                if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+                if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+            }
         }
+        if ((rc = asb_panel_select(ctx, k, forced, forced >= 0 ? 1 : global_all, nullptr, nullptr, nullptr, nullptr))) return rc;
+        const int steps = forced >= 0 ? 1 : (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
+        int64_t done = 0;
+        if ((rc = asb_panel_run(ctx, k, steps, forced >= 0 ? 1 : global_all, 0, &done))) return rc;
         if (done == 0) {
-            // the energy recurrence could not prove any candidate: refresh ALL energies exactly, retry;
+            // the energy recurrence could not prove any candidate: refresh ALL energies exactly and retry;
             // a second failure (massive exact ties) forces the first arg-max as the only candidate
-            ++stalled;
-            if (stalled > 3) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "deflation made no progress at component %lld", k);
-            const int ggrid = stream_grid(ctx, ctx->cfg, ctx->n_loc);
-            launch_gather(ctx, ctx->cfg, ggrid, nullptr, (long long)ctx->n_loc, nullptr, (int)k, nullptr, ctx->energy,
-                          ctx->pmax, ctx->pidx, ctx->psum);
-            ASB_CHECK_LAUNCH(ctx);
-            ctx->nblk = ggrid;
-            ctx->n_refresh++;
+            if (++stalled > 3) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "deflation made no progress at component %lld", k);
+            if ((rc = asb_panel_refresh(ctx, k, nullptr, nullptr))) return rc;
             continue;
         }
         stalled = 0;
-        if ((rc = project_pass(ctx, k, (int)done))) return rc;
+        if ((rc = asb_panel_project(ctx, k, (int)done))) return rc;
         k += done;
-        ctx->k_done = k;
     }
     return ASB_OK;
 }

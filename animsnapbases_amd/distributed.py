@@ -64,6 +64,42 @@ class Comm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
+    def allreduce_max(self, values):
+        a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
+        if self.world == 1:
+            return a
+        t = self._torch.from_numpy(a).to(self._dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy()
+
+    def all_gather_ints(self, values):
+        """(world, len(values)) int64 array of every rank's small integer vector."""
+        a = np.atleast_1d(np.asarray(values, dtype=np.int64)).copy()
+        if self.world == 1:
+            return a[None]
+        t = self._torch.from_numpy(a).to(self._dev)
+        out = self._torch.empty(self.world * a.shape[0], dtype=self._torch.int64, device=self._dev)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().numpy().reshape(self.world, a.shape[0])
+
+    def _need_torch(self):
+        if self._torch is None:
+            import torch
+
+            self._torch = torch
+            self._dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        return self._torch
+
+    def exchange_device(self, on_device):
+        torch = self._need_torch()
+        return self._dev if on_device else torch.device("cpu")
+
+    def all_gather_into(self, out, inp):
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
     def new_records(self, xlen, on_device):
         """(rec, recs): one exchange record and the gathered (world, xlen) buffer."""
         torch = self._torch
@@ -87,7 +123,8 @@ class Comm(object):
         return (torch.zeros(F * K, dtype=torch.float64, device=dev), torch.zeros(K * K, dtype=torch.float64, device=dev))
 
     def allreduce_tensor(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def global_argmax(self, idx, val):
         """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties."""

@@ -142,6 +142,51 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_results(self.h, ptr(comps), ptr(weigs), ptr(idx), ptr(sigma), ptr(nr2)))
         return dict(comps=comps, weigs=weigs, idx=idx, sigma=sigma, normR2_local=nr2)
 
+    # ------------------------------------------------------------------ projection mode, panel steps
+    NBINS = 2048
+
+    def panel_scale(self, set_e0max=-1.0):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self._ck(self.lib.asb_panel_scale(self.h, ctypes.byref(a), ctypes.byref(b), float(set_e0max)))
+        return a.value, b.value
+
+    def panel_hist(self, level, hist_ptr):
+        self._ck(self.lib.asb_panel_hist(self.h, int(level), ctypes.c_void_p(hist_ptr)))
+
+    def panel_tau(self, level, hist_ptr):
+        self._ck(self.lib.asb_panel_tau(self.h, int(level), ctypes.c_void_p(hist_ptr)))
+
+    def panel_capacity(self):
+        return int(self.lib.asb_panel_capacity(self.h))
+
+    def panel_row_len(self):
+        return 3 * ((self.F + 15) // 16 * 16)
+
+    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False):
+        n, ov = ctypes.c_int64(), ctypes.c_int()
+        self._ck(self.lib.asb_panel_select(self.h, int(k), int(forced_gidx), int(bool(global_all)),
+                                           ctypes.c_void_p(rows_ptr), ctypes.c_void_p(idx_ptr), ctypes.byref(n),
+                                           ctypes.byref(ov)))
+        return n.value, bool(ov.value)
+
+    def panel_assemble(self, rows_g_ptr, idx_g_ptr, counts, maxcount):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        self._ck(self.lib.asb_panel_assemble(self.h, ctypes.c_void_p(rows_g_ptr), ctypes.c_void_p(idx_g_ptr), ptr(counts),
+                                             int(counts.shape[0]), int(maxcount)))
+
+    def panel_run(self, k0, steps, global_all=False):
+        c = ctypes.c_int64()
+        self._ck(self.lib.asb_panel_run(self.h, int(k0), int(steps), int(bool(global_all)), 1, ctypes.byref(c)))
+        return c.value
+
+    def panel_project(self, k0, ncols):
+        self._ck(self.lib.asb_panel_project(self.h, int(k0), int(ncols)))
+
+    def panel_refresh(self, k):
+        e, g = ctypes.c_double(), ctypes.c_int64()
+        self._ck(self.lib.asb_panel_refresh(self.h, int(k), ctypes.byref(e), ctypes.byref(g)))
+        return e.value, g.value
+
     def deflate_stats(self):
         a, b = ctypes.c_int64(), ctypes.c_int64()
         self._ck(self.lib.asb_deflate_stats(self.h, ctypes.byref(a), ctypes.byref(b)))

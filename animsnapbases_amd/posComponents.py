@@ -52,6 +52,7 @@ class posComponents:  # Components == bases
         # (None = automatic, "residual", "project"; env ASB_DEFLATE_MODE overrides the default)
         self.selected_vertices = None
         self.deflate_mode = os.environ.get("ASB_DEFLATE_MODE") or None
+        self._stepwise_panels = False      # tests: drive the multi-rank panel protocol on one rank
 
     # ------------------------------------------------------------------ comps: device-resident, lazy download
     @property
@@ -111,14 +112,16 @@ class posComponents:  # Components == bases
         # 16 components); otherwise the residual tensor is kept and updated per component.
         mode = self.deflate_mode
         if mode is None:
-            mode = "project" if (comm.world == 1 and not local) else "residual"
-        if mode == "project" and (local or comm.world > 1):
-            raise ValueError("deflate_mode='project' needs global support on a single rank")
+            mode = "residual" if local else "project"
+        if mode == "project" and local:
+            raise ValueError("deflate_mode='project' needs global support")
         eng.deflate_begin(K, local, _lib.DEFLATE_PROJECT if mode == "project" else _lib.DEFLATE_RESIDUAL)
         v0, n_loc = snaps._shards[comm.rank]
 
-        if comm.world == 1 and not local:
+        if comm.world == 1 and not local and not self._stepwise_panels:
             eng.run_global(0, K)
+        elif mode == "project":
+            self._project_multirank(K)
         else:
             rec = recs = None
             if comm.world > 1:
@@ -152,6 +155,62 @@ class posComponents:  # Components == bases
             self.splocs_glob_optimization(self.param.splocs_max_itrs, self.param.splocs_admm_num_itrs,
                                           None, snaps.compute_geodesic_distance)
         print("Computed '", self.basesType, "' bases size ", (K, snaps.nVerts, 3))
+
+    def _project_multirank(self, K):
+        """Projection-mode deflation over several ranks.  Per PANEL (up to 16
+        components): two histogram all-reduces fix the global threshold, each rank rebuilds the
+        exact residual rows of its own candidates, ONE padded all-gather replicates the ~1000
+        candidate rows on every rank, every rank runs the identical greedy steps on them (no
+        per-component collective), then projects its own shard.  Ranks stay in lock-step because
+        every decision is taken on all-reduced / all-gathered data."""
+        snaps = self.pos_snapshots
+        eng, comm = snaps._engine, snaps._comm
+        dev = comm.exchange_device(eng.device_exchange)
+        torch = comm._torch
+        cap, rl = eng.panel_capacity(), eng.panel_row_len()
+        _, e0 = eng.panel_scale()
+        eng.panel_scale(set_e0max=float(comm.allreduce_max(e0)[0]))
+        hist = torch.zeros(eng.NBINS, dtype=torch.int32, device=dev)
+        rows_loc = torch.zeros(cap * rl, dtype=torch.float64, device=dev)
+        idx_loc = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        global_all = snaps.nVerts <= cap
+        k, stalled, forced_next = 0, 0, -1
+        while k < K:
+            forced = forced_next if stalled >= 2 else -1
+            if forced < 0 and not global_all:
+                for level in (1, 2):
+                    eng.panel_hist(level, hist.data_ptr())
+                    comm.allreduce_tensor(hist)
+                    eng.panel_tau(level, hist.data_ptr())
+            take_all = forced >= 0 or global_all
+            n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), forced, take_all)
+            info = comm.all_gather_ints([n_c, int(ov)])
+            counts, total = info[:, 0].copy(), int(info[:, 0].sum())
+            done = 0
+            if not info[:, 1].any() and 0 < total <= cap:
+                maxc = int(counts.max())
+                rows_g = torch.empty(comm.world * maxc * rl, dtype=torch.float64, device=dev)
+                idx_g = torch.empty(comm.world * maxc, dtype=torch.int64, device=dev)
+                comm.all_gather_into(rows_g, rows_loc[:maxc * rl])
+                comm.all_gather_into(idx_g, idx_loc[:maxc])
+                eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
+                steps = 1 if forced >= 0 else min(16, K - k)
+                done = eng.panel_run(k, steps, take_all)
+            if done == 0:
+                # nothing provable (stale bound / exact ties): exact energies everywhere, retry; a second
+                # failure forces the global first arg-max as the only candidate
+                stalled += 1
+                if stalled > 3:
+                    raise ArithmeticError("deflation made no progress at component %d" % k)
+                e, g = eng.panel_refresh(k)
+                both = comm.allreduce_max(np.eye(comm.world)[comm.rank] * e) if comm.world > 1 else np.array([e])
+                gids = comm.all_gather_ints([g])[:, 0]
+                order = sorted(range(comm.world), key=lambda r: (-both[r], gids[r]))
+                forced_next = int(gids[order[0]])
+                continue
+            stalled = 0
+            eng.panel_project(k, done)
+            k += done
 
     @log_time("")
     def splocs_glob_optimization(self, num_iters_max, num_admm_iterations, R, compute_geodesic_distance):

@@ -115,6 +115,37 @@ int asb_deflate_run_global(asb_ctx* ctx, int64_t k0, int64_t k1);
  * shards and square-rooted by the caller). Any pointer may be NULL. */
 int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx,
                         double* sigma, double* normR2_local);
+/* ---- projection mode, panel by panel (what asb_deflate_run_global does internally on one
+ * rank; the multi-rank driver interleaves the collectives marked [ALL-*]) ------------------
+ *   asb_panel_scale                     [ALL-REDUCE max of e0max, then set it on every rank]
+ *   per panel:
+ *     asb_panel_hist(1) [ALL-REDUCE sum] asb_panel_tau(1) asb_panel_hist(2) [ALL-REDUCE sum] asb_panel_tau(2)
+ *     asb_panel_select(rows, idx)       [ALL-GATHER counts, rows, idx]  asb_panel_assemble
+ *     asb_panel_run        -> committed (identical on every rank: same data, same arithmetic)
+ *     asb_panel_project    (local shard)                                                        */
+int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max_local, double set_e0max);
+/* local energy histogram (ASB_NBINS = 2048 ints) into hist_dev (NULL: internal) */
+int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev);
+/* threshold step from the (summed) histogram */
+int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev);
+/* this shard's candidates (energy > tau; every vertex when global_all; only forced_gidx when
+ * >= 0), in vertex order, and their exact residual rows (3*Fp doubles each) into the caller's
+ * device buffers of capacity asb_panel_capacity() (NULL: the context's own buffer).
+ * n_local / overflow (optional) synchronise. */
+int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, int global_all, double* rows_out_dev,
+                     long long* idx_out_dev, int64_t* n_local, int* overflow);
+int64_t asb_panel_capacity(const asb_ctx* ctx);
+/* replicated candidate buffer from the all-gathered padded pieces:
+ * rows_g_dev (world, maxcount, 3, Fp), idx_g_dev (world, maxcount), counts (host, world) */
+int asb_panel_assemble(asb_ctx* ctx, const double* rows_g_dev, const long long* idx_g_dev,
+                       const int64_t* counts, int world, int64_t maxcount);
+/* up to `steps` (<= 16) greedy steps on the candidate buffer; *committed of them are final */
+int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int64_t* committed);
+/* one pass over X for components [k0, k0+ncols): c_k on this shard, energies */
+int asb_panel_project(asb_ctx* ctx, int64_t k0, int ncols);
+/* fallback: exact energies of every vertex of the shard; optional first arg-max */
+int asb_panel_refresh(asb_ctx* ctx, int64_t k, double* best_energy, int64_t* best_gidx);
+
 /* projection mode statistics of the last run: streaming passes over X (panels) and exact
  * energy refreshes (fallback when the energy recurrence could not prove a candidate). */
 int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_refresh);

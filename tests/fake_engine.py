@@ -52,8 +52,10 @@ class FakeEngine(object):
 
     # ---- deflation (residual mode contract)
     def deflate_begin(self, K, local_support, mode=0):
-        assert mode == 0, "the test double only implements the residual-mode contract"
+        self.mode = int(mode)
         self.K, self.local = int(K), bool(local_support)
+        if self.mode == 1:
+            return self._project_begin()
         self.R = self.X.copy()
         self.W = np.zeros((K, self.F))
         self.C = np.zeros((K, self.n_loc, 3))
@@ -115,11 +117,14 @@ class FakeEngine(object):
         self.nr2[k] = (self.R ** 2).sum()
 
     def run_global(self, k0, k1):
+        assert self.mode == 0
         for k in range(k0, k1):
             self.pick(k)
             self.apply(k)
 
     def results(self, want_comps=True, want_weigs=True):
+        if self.mode == 1:
+            self.nr2 = self.normX2 - np.cumsum(self.colsum)
         return dict(comps=self.C.copy() if want_comps else None, weigs=self.W.T.copy() if want_weigs else None,
                     idx=self.idx.copy(), sigma=self.sigma.copy(), normR2_local=self.nr2.copy())
 
@@ -140,3 +145,132 @@ class FakeEngine(object):
 
     def sync(self):
         pass
+
+    # ---- projection-mode (panel) contract of include/asb.h, NumPy emulation --------------------------------
+    NBINS = 2048
+    M_TARGET, M_CAP = 12, 24             # tiny on purpose: forces several panels and early panel ends
+
+    def _project_begin(self):
+        K = self.K
+        self.W = np.zeros((K, self.F))
+        self.C = np.zeros((K, self.n_loc, 3))
+        self.sigma, self.wn2, self.colsum = np.zeros(K), np.zeros(K), np.zeros(K)
+        self.idx = np.zeros(K, dtype=np.int64)
+        self.E = (self.X ** 2).sum(axis=(0, 2))
+        self.normX2, self.e0max = float(self.E.sum()), float(self.E.max())
+        self.n_panels = self.n_refresh = 0
+
+    def panel_scale(self, set_e0max=-1.0):
+        out = (self.normX2, self.e0max)
+        if set_e0max >= 0:
+            self.e0max = float(set_e0max)
+        return out
+
+    def panel_capacity(self):
+        return self.M_CAP
+
+    def panel_row_len(self):
+        return 3 * self.F
+
+    def panel_hist(self, level, hist_ptr):
+        h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
+        if level == 1:
+            self.lo, self.hi, self.above = 0.0, self.e0max, 0
+        e = self.E[(self.E >= self.lo) & ((self.E <= self.hi) if level == 1 else (self.E < self.hi))]
+        scale = self.NBINS / (self.hi - self.lo) if self.hi > self.lo else 0.0
+        b = np.minimum(((e - self.lo) * scale).astype(np.int64), self.NBINS - 1)
+        h[:] = np.bincount(b, minlength=self.NBINS).astype(np.int32)
+
+    def panel_tau(self, level, hist_ptr):
+        h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
+        width = (self.hi - self.lo) / self.NBINS
+        acc, b = self.above, self.NBINS - 1
+        while b >= 0 and acc + h[b] < self.M_TARGET:
+            acc += int(h[b])
+            b -= 1
+        if b < 0:
+            self.tau = -1.0 if level == 1 else np.nextafter(self.lo, -np.inf)
+            if level == 1:
+                self.lo = self.hi = 0.0
+                self.above = acc
+            return
+        e_lo = self.lo + b * width
+        e_hi = self.hi if b == self.NBINS - 1 else self.lo + (b + 1) * width
+        if level == 1:
+            self.lo, self.hi, self.above, self.tau = e_lo, e_hi, acc, e_lo
+        else:
+            tau = e_hi if (acc + h[b] > self.M_CAP and acc > 0) else e_lo
+            self.tau = np.nextafter(tau, -np.inf)
+
+    def _residual_rows(self, vloc, k):
+        R = self.X[:, vloc, :].copy()                       # (F, m, 3)
+        for j in range(k):
+            R -= self.W[j][:, None, None] * self.C[j][vloc][None]
+        return R
+
+    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False):
+        if forced_gidx >= 0:
+            vloc = np.array([forced_gidx - self.v0]) if self.v0 <= forced_gidx < self.v0 + self.n_loc else np.zeros(0, np.int64)
+        elif global_all:
+            vloc = np.arange(self.n_loc)
+        else:
+            vloc = np.nonzero(self.E > self.tau)[0]
+        overflow = vloc.size > self.M_CAP
+        vloc = vloc[:self.M_CAP]
+        rows = _view(rows_ptr, self.M_CAP * 3 * self.F).reshape(self.M_CAP, 3, self.F)
+        ids = np.ctypeslib.as_array((ctypes.c_int64 * self.M_CAP).from_address(idx_ptr))
+        if vloc.size:
+            rows[:vloc.size] = self._residual_rows(vloc, k).transpose(1, 2, 0)
+            ids[:vloc.size] = self.v0 + vloc
+        return int(vloc.size), bool(overflow)
+
+    def panel_assemble(self, rows_g_ptr, idx_g_ptr, counts, maxcount):
+        world = len(counts)
+        rows = _view(rows_g_ptr, world * maxcount * 3 * self.F).reshape(world, maxcount, 3, self.F)
+        ids = np.ctypeslib.as_array((ctypes.c_int64 * (world * maxcount)).from_address(idx_g_ptr)).reshape(world, maxcount)
+        self.candR = np.concatenate([rows[r, :counts[r]] for r in range(world)], axis=0).copy()
+        self.cand_idx = np.concatenate([ids[r, :counts[r]] for r in range(world)]).copy()
+
+    def panel_run(self, k0, steps, global_all=False):
+        theta = -np.inf if global_all else self.tau
+        margin = 1e-11 * self.e0max
+        done = 0
+        self.n_panels += 1
+        for t in range(steps):
+            k = k0 + t
+            e = (self.candR ** 2).sum(axis=(1, 2))
+            b = int(np.argmax(e))
+            if not e[b] > theta + margin:
+                break
+            slab = self.candR[b]
+            lam, U = np.linalg.eigh(slab @ slab.T)
+            u = U[:, -1]
+            if u[np.argmax(np.abs(u))] < 0:
+                u = -u
+            w = slab.T @ u
+            self.W[k], self.sigma[k], self.wn2[k], self.idx[k] = w, np.sqrt(max(lam[-1], 0.0)), w @ w, self.cand_idx[b]
+            c = self.candR @ w / self.wn2[k]                 # (m, 3)
+            self.candR -= c[:, :, None] * w[None, None, :]
+            done += 1
+        return done
+
+    def panel_project(self, k0, ncols):
+        for t in range(ncols):
+            k = k0 + t
+            y = np.tensordot(self.W[k], self.X, (0, 0))     # (n, 3)
+            for j in range(k0):
+                y -= self.C[j] * (self.W[j] @ self.W[k])
+            self.C[k] = y / self.wn2[k]
+            loss = (self.C[k] ** 2).sum(axis=1) * self.wn2[k]
+            self.E = np.maximum(self.E - loss, 0.0)
+            self.colsum[k] = loss.sum()
+
+    def panel_refresh(self, k):
+        self.n_refresh += 1
+        R = self._residual_rows(np.arange(self.n_loc), k)
+        self.E = (R ** 2).sum(axis=(0, 2))
+        b = int(np.argmax(self.E))
+        return float(self.E[b]), int(self.v0 + b)
+
+    def deflate_stats_project(self):
+        return dict(panels=self.n_panels, refreshes=self.n_refresh)

@@ -270,3 +270,28 @@ def test_splocs_vs_oracle_medium():
     assert np.allclose(comp.splocs_trace, s["trace"], rtol=1e-8)
     assert relerr(comp.splocs_comps, s["C"]) < 1e-8
     assert relerr(comp.splocs_weigs, s["W"]) < 1e-8
+
+
+def test_project_mode_stepwise_panel_protocol():
+    """The multi-rank panel protocol (asb_panel_* steps, torch exchange buffers, assemble) driven on
+    ONE GPU must reproduce the fused single-rank run bit for bit."""
+    import torch
+    rng = np.random.default_rng(33)
+    F, N, K = 96, 4000, 20
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = _param(vertPos_numComponents=K)
+    from animsnapbases_amd import posComponents, posSnapshots
+    outs = []
+    for stepwise in (False, True):
+        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
+        if stepwise:      # the stepwise path exchanges torch tensors: share torch's stream ordering by syncing
+            torch.cuda.synchronize()
+        comp = posComponents(param, snaps)
+        comp.deflate_mode = "project"
+        comp._stepwise_panels = stepwise
+        comp.compute_components_store_singvalues()
+        outs.append((comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(),
+                     comp.measures_at_largeDeforVerts.copy()))
+    assert outs[0][0].tolist() == outs[1][0].tolist()
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert relerr(outs[1][3], outs[0][3]) < 1e-12
