@@ -138,16 +138,11 @@ __global__ __launch_bounds__(256) void k_range_init(const double* pmax, const lo
     }
 }
 
-// level-1 histogram range: [0, E0max] (energies never increase)
-__global__ void k_range_l1(double* __restrict__ sc) {
-    sc[SC_LO] = 0.0;
-    sc[SC_HI] = sc[SC_E0MAX];
-    sc[SC_ABOVE] = 0.0;
-}
-
-// hist[b] = #{ lo <= e < hi falling in bin b }, the top edge is inclusive at level 1
+// level 1 (by_exponent): hist[b] = #{ e : biased exponent of e == b } -- exact, needs no range, and
+// covers the whole dynamic range of the energies (they fall by 1e8 on low-rank data);
+// level 2: linear bins inside the crossing binade [lo, hi).
 __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long long n, const double* __restrict__ sc,
-                                              int* __restrict__ hist, int top_inclusive) {
+                                              int* __restrict__ hist, int by_exponent) {
     __shared__ int lh[ASB_NBINS];
     for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
@@ -155,9 +150,15 @@ __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long
     const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const double e = E[i];
-        if (e < lo || e > hi || (!top_inclusive && e >= hi)) continue;
-        int b = (int)((e - lo) * scale);
-        if (b > ASB_NBINS - 1) b = ASB_NBINS - 1;
+        int b;
+        if (by_exponent) {
+            if (!(e >= 0.0)) continue;
+            b = (int)((__double_as_longlong(e) >> 52) & 0x7FF);
+        } else {
+            if (e < lo || e >= hi) continue;
+            b = (int)((e - lo) * scale);
+            if (b > ASB_NBINS - 1) b = ASB_NBINS - 1;
+        }
         atomicAdd(&lh[b], 1);
     }
     __syncthreads();
@@ -200,7 +201,14 @@ __global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, doubl
         else sc[SC_TAU] = nextafter(lo, -1.0e300);
         return;
     }
-    const double edge_lo = lo + b * width, edge_hi = (b == ASB_NBINS - 1) ? hi : lo + (b + 1) * width;
+    double edge_lo, edge_hi;
+    if (level == 1) {                  // bin b = biased exponent: the binade [2^(b-1023), 2^(b-1022))
+        edge_lo = (b == 0) ? 0.0 : ldexp(1.0, b - 1023);
+        edge_hi = (b >= 2046) ? 1.7976931348623157e308 : ldexp(1.0, b - 1022);
+    } else {
+        edge_lo = lo + b * width;
+        edge_hi = (b == ASB_NBINS - 1) ? hi : lo + (b + 1) * width;
+    }
     if (level == 1) {
         sc[SC_LO] = edge_lo;
         sc[SC_HI] = edge_hi;
@@ -680,12 +688,13 @@ static int hist_grid(const asb_ctx* ctx) {
     return (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
 }
 
-// level-1 range is always [0, E0max] (energies only decrease), level 2 the crossing bin
+// level 1: exponent histogram (range-free); level 2: linear bins inside the crossing binade
 extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
     int* h = hist_dev ? hist_dev : ctx->hist;
-    if (level == 1) {
-        hipLaunchKernelGGL(k_range_l1, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev);
+    if (level == 1) {      // the count above the crossing bin starts from 0
+        const double zero = 0.0;
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->scalar_dev + SC_ABOVE, &zero, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
     ASB_HIP(ctx, hipMemsetAsync(h, 0, ASB_NBINS * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_hist, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc,

@@ -130,7 +130,9 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     ctx->dev = device_id;
     *out = ctx;
     ASB_HIP(ctx, hipSetDevice(device_id));
-    if (hip_stream) {
+    if (hip_stream == ASB_STREAM_DEFAULT) {
+        ctx->stream = nullptr;                      // the null stream
+    } else if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
         ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -18,12 +18,22 @@ class HipEngine(object):
 
     device_exchange = True      # exchange records live in device memory (torch tensors)
 
+    STREAM_DEFAULT = -1         # ASB_STREAM_DEFAULT: the device's null stream
+
     def __init__(self, device_id=0, stream=None):
+        """stream: None = private stream; an int hipStream_t handle; 0 or STREAM_DEFAULT = the null
+        stream (torch's current stream when the caller has not switched streams)."""
         self.lib = _lib.load()
         if self.lib.asb_abi_version() != 1:
             raise AsbLibraryError("libasb_hip.so ABI version mismatch")
         h = ctypes.c_void_p()
-        rc = self.lib.asb_create(int(device_id), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if stream is None:
+            sarg = None
+        elif stream in (0, self.STREAM_DEFAULT):
+            sarg = ctypes.c_void_p(-1)
+        else:
+            sarg = ctypes.c_void_p(stream)
+        rc = self.lib.asb_create(int(device_id), sarg, ctypes.byref(h))
         if rc != 0:
             msg = self.lib.asb_last_error(h).decode() if h else ""
             if h:

@@ -49,8 +49,10 @@ typedef enum asb_status {
 /* ---------------------------------------------------------------- context ---- */
 int asb_abi_version(void);
 /* stream: a hipStream_t to enqueue on (e.g. torch's current stream so that RCCL
- * collectives issued by torch.distributed are ordered with the kernels), or NULL for a
- * private stream. */
+ * collectives issued by torch.distributed are ordered with the kernels), NULL for a
+ * private stream, or ASB_STREAM_DEFAULT for the device's default (null) stream -- which is
+ * what torch's current stream is unless the caller switched streams. */
+#define ASB_STREAM_DEFAULT ((void*)(intptr_t)-1)
 int asb_create(int device_id, void* hip_stream, asb_ctx** out);
 void asb_destroy(asb_ctx* ctx);
 const char* asb_last_error(const asb_ctx* ctx);

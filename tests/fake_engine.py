@@ -174,16 +174,18 @@ class FakeEngine(object):
 
     def panel_hist(self, level, hist_ptr):
         h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
-        if level == 1:
-            self.lo, self.hi, self.above = 0.0, self.e0max, 0
-        e = self.E[(self.E >= self.lo) & ((self.E <= self.hi) if level == 1 else (self.E < self.hi))]
-        scale = self.NBINS / (self.hi - self.lo) if self.hi > self.lo else 0.0
-        b = np.minimum(((e - self.lo) * scale).astype(np.int64), self.NBINS - 1)
-        h[:] = np.bincount(b, minlength=self.NBINS).astype(np.int32)
+        if level == 1:                                        # biased-exponent histogram
+            self.above = 0
+            e = self.E[self.E >= 0]
+            b = ((e.view(np.int64) >> 52) & 0x7FF).astype(np.int64)
+        else:
+            e = self.E[(self.E >= self.lo) & (self.E < self.hi)]
+            scale = self.NBINS / (self.hi - self.lo) if self.hi > self.lo else 0.0
+            b = np.minimum(((e - self.lo) * scale).astype(np.int64), self.NBINS - 1)
+        h[:] = np.bincount(b, minlength=self.NBINS).astype(np.int32)[:self.NBINS]
 
     def panel_tau(self, level, hist_ptr):
         h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
-        width = (self.hi - self.lo) / self.NBINS
         acc, b = self.above, self.NBINS - 1
         while b >= 0 and acc + h[b] < self.M_TARGET:
             acc += int(h[b])
@@ -194,11 +196,14 @@ class FakeEngine(object):
                 self.lo = self.hi = 0.0
                 self.above = acc
             return
-        e_lo = self.lo + b * width
-        e_hi = self.hi if b == self.NBINS - 1 else self.lo + (b + 1) * width
         if level == 1:
-            self.lo, self.hi, self.above, self.tau = e_lo, e_hi, acc, e_lo
+            self.lo = 0.0 if b == 0 else float(np.ldexp(1.0, b - 1023))
+            self.hi = float(np.ldexp(1.0, b - 1022))
+            self.above, self.tau = acc, self.lo
         else:
+            width = (self.hi - self.lo) / self.NBINS
+            e_lo = self.lo + b * width
+            e_hi = self.hi if b == self.NBINS - 1 else self.lo + (b + 1) * width
             tau = e_hi if (acc + h[b] > self.M_CAP and acc > 0) else e_lo
             self.tau = np.nextafter(tau, -np.inf)
 
