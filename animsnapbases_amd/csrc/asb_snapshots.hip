@@ -252,10 +252,10 @@ extern "C" int asb_snapshots_upload(asb_ctx* ctx, const double* X, int64_t F, in
 }
 
 extern "C" int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc,
-                                       const double* massL_loc) {
+                                       const double* massL_loc, int64_t v0, int64_t N_glob) {
     if (!ctx || !X_dev) return ASB_ERR_ARG;
     ASB_HIP(ctx, hipSetDevice(ctx->dev));
-    int rc = set_shape(ctx, F, n_loc, 0, n_loc);
+    int rc = set_shape(ctx, F, N_glob, v0, n_loc);
     if (rc) return rc;
     double* mdev = nullptr;
     if (massL_loc) {

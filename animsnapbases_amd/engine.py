@@ -82,12 +82,15 @@ class HipEngine(object):
         self._ck(self.lib.asb_snapshots_upload(self.h, ptr(X), F, N, int(v0), int(n_loc), ptr(massL)))
         self.F, self.N_glob, self.v0, self.n_loc = F, N, int(v0), int(n_loc)
 
-    def adopt_device(self, dev_ptr, F, n_loc, massL_loc=None):
-        """dev_ptr: device address of an (F, n_loc, 3) float64 tensor (reference layout)."""
+    def adopt_device(self, dev_ptr, F, n_loc, massL_loc=None, v0=0, N_glob=None):
+        """dev_ptr: device address of an (F, n_loc, 3) float64 tensor (reference layout) holding this
+        rank's vertices [v0, v0 + n_loc) of N_glob."""
         if massL_loc is not None:
             massL_loc = np.ascontiguousarray(massL_loc, dtype=np.float64)
-        self._ck(self.lib.asb_snapshots_adopt_dev(self.h, ctypes.c_void_p(dev_ptr), int(F), int(n_loc), ptr(massL_loc)))
-        self.F, self.N_glob, self.v0, self.n_loc = int(F), int(n_loc), 0, int(n_loc)
+        N_glob = int(n_loc if N_glob is None else N_glob)
+        self._ck(self.lib.asb_snapshots_adopt_dev(self.h, ctypes.c_void_p(dev_ptr), int(F), int(n_loc), ptr(massL_loc),
+                                                  int(v0), N_glob))
+        self.F, self.N_glob, self.v0, self.n_loc = int(F), N_glob, int(v0), int(n_loc)
 
     def center(self, rest_shape_code, subtract):
         s = ctypes.c_double()

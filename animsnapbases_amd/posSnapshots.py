@@ -116,7 +116,6 @@ class posSnapshots:
         if self._device_data is not None:
             ptr_, F, N = self._device_data
             # the adopted tensor IS this rank's shard; global N is the sum over ranks
-            eng.adopt_device(ptr_, F, N, None)
             counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * N) if comm.world > 1 else np.array([N])
             self._shards = []
             v0 = 0
@@ -124,9 +123,8 @@ class posSnapshots:
                 self._shards.append((v0, int(n)))
                 v0 += int(n)
             self.nVerts = int(counts.sum())
-            eng.v0 = self._shards[comm.rank][0]
-            eng.N_glob = self.nVerts
             self.frs = F
+            eng.adopt_device(ptr_, F, N, None, self._shards[comm.rank][0], self.nVerts)
         else:
             v0, n_loc = comm.my_shard(self.nVerts)
             self._shards = comm.shards(self.nVerts)

@@ -69,9 +69,10 @@ int asb_prof_get(asb_ctx* ctx, int64_t* launches, double* total_ms);
 int asb_snapshots_upload(asb_ctx* ctx, const double* X, int64_t F, int64_t N_glob,
                          int64_t v0, int64_t n_loc, const double* massL);
 /* Same, but X_dev is already in device memory in the reference layout (F, n_loc, 3)
- * (synthetic benchmark inputs generated on the GPU). */
+ * (synthetic benchmark inputs generated on the GPU): this rank's vertices [v0, v0+n_loc)
+ * of N_glob. */
 int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc,
-                            const double* massL_loc);
+                            const double* massL_loc, int64_t v0, int64_t N_glob);
 /* :85-89 + posSnapshots.standarize :168 -- mean = frame 0 (rest_shape 0) or the frame
  * average (1); when subtract != 0 the mean row is subtracted.  local_sum = sum of all
  * entries of the shard afterwards (for the global mean of np.std). */

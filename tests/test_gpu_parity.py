@@ -280,12 +280,13 @@ def test_project_mode_stepwise_panel_protocol():
     F, N, K = 96, 4000, 20
     verts = rng.uniform(-1, 1, size=(F, N, 3))
     param = _param(vertPos_numComponents=K)
-    from animsnapbases_amd import posComponents, posSnapshots
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
     outs = []
     for stepwise in (False, True):
-        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
-        if stepwise:      # the stepwise path exchanges torch tensors: share torch's stream ordering by syncing
-            torch.cuda.synchronize()
+        # the stepwise path exchanges torch tensors: run the engine on torch's current (null) stream, as the
+        # multi-rank driver does, so kernels and torch copies are stream-ordered
+        eng = HipEngine(0, stream=0) if stepwise else None
+        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False, engine=eng)
         comp = posComponents(param, snaps)
         comp.deflate_mode = "project"
         comp._stepwise_panels = stepwise
@@ -295,3 +296,79 @@ def test_project_mode_stepwise_panel_protocol():
     assert outs[0][0].tolist() == outs[1][0].tolist()
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     assert relerr(outs[1][3], outs[0][3]) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode,support", [("project", "global"), ("residual", "global"), ("residual", "local")])
+def test_multirank_hip_path_on_one_gpu(world, mode, support):
+    """`world` vertex shards, each with its own HipEngine, on ONE GPU (threads + emulated collectives,
+    tests/thread_comm.py): the real multi-rank HIP kernels == the single-rank run == the oracle."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    if support == "local":
+        rest_v, tris = orc.synth_mesh(12, 17, seed=4)      # N = 206
+        verts = orc.synth_snapshots(rest_v, 48, rank=6, seed=4, kind="bumps")
+        K = 6
+    else:
+        rng = np.random.default_rng(5)
+        verts, tris, K = rng.uniform(-1, 1, size=(64, 5003, 3)), None, 24     # N above the candidate capacity, uneven shards
+    param = _param(vertPos_numComponents=K, q_support=support, vertPos_smooth_max_dist=0.35)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.deflate_mode = mode
+            comp.compute_components_store_singvalues()
+        return (comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(),
+                comp.measures_at_largeDeforVerts.copy(), snaps.pre_scale_factor)
+
+    outs = run_ranks(world, rank_fn)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris) if support == "local" else None
+    ref = orc.extract_k_components(pre["snapTensor"], K, support, geo, 0.1, 0.35)
+    for idx, comps, weigs, meas, psf in outs:
+        assert abs(psf - pre["pre_scale_factor"]) < 1e-12 * psf
+        assert idx.tolist() == ref["idx"].tolist()
+        if support == "global":
+            comps, weigs = align_signs(comps, weigs, ref["comps"])
+        assert relerr(comps, ref["comps"]) < 1e-8
+        assert relerr(weigs, ref["weigs"]) < 1e-8
+        assert relerr(meas, ref["measures"]) < 1e-7
+    for o in outs[1:]:           # every rank ends with the same replicated results
+        assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1], outs[0][1])
+
+
+def test_multirank_splocs_on_one_gpu():
+    """SPLOCS over 2 vertex shards on one GPU: partial Gram matrices summed over ranks."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    rest_v, tris = orc.synth_mesh(12, 17, seed=9)
+    verts = orc.synth_snapshots(rest_v, 40, rank=6, seed=9, kind="bumps")
+    K = 6
+    param = _param(vertPos_numComponents=K, q_support="local", vertPos_bases_type="SPLOCS",
+                   vertPos_smooth_max_dist=0.4, splocs_max_itrs=3, splocs_admm_num_itrs=4, splocs_lambda=2.0,
+                   splocs_rho=10.0)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.compute_components_store_singvalues()
+        return comp.splocs_trace.copy(), comp.splocs_comps.copy(), comp.splocs_centres.copy()
+
+    outs = run_ranks(2, rank_fn)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris)
+    d = orc.extract_k_components(pre["snapTensor"], K, "local", geo, 0.1, 0.4)
+    s = orc.splocs_glob_optimization(pre["snapTensor"], d["comps"], d["weigs"], d["R"], geo, 0.1, 0.4, 3, 4, 2.0, 10.0)
+    for trace, C, cen in outs:
+        assert cen.tolist() == s["idx"].tolist()
+        assert np.allclose(trace, s["trace"], rtol=1e-8)
+        assert relerr(C, s["C"]) < 1e-8
