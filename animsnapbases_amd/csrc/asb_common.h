@@ -77,6 +77,9 @@ struct asb_ctx {
     int64_t n_slots_host = 0;   // candidates in the assembled (multi-rank) buffer
     double* colpart = nullptr;   // (blocks, 16)
     double* gram = nullptr;      // (K, 16) w_j . w_panel
+    double* ypart = nullptr;     // partial 16x16 tiles between sweeps of k_project_lds
+    unsigned int* tile_counter = nullptr;
+    int project_kernel = 2;      // 1: k_project_mfma (register-resident Wt), 2: k_project_lds
     long long* ctmp = nullptr;   // compaction scratch
     long long* ccnt = nullptr;
     int* hist = nullptr;

@@ -257,23 +257,19 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     if (tid == 255) cnt[blockIdx.x] = pre[255];
 }
 
-__global__ __launch_bounds__(256) void k_compact_b(const long long* __restrict__ tmp, const long long* __restrict__ cnt,
-                                                   int nb, long long m_cap, long long* __restrict__ cand_idx,
-                                                   PanelState* __restrict__ panel) {
-    __shared__ long long off[ASB_CBLOCKS + 1];
-    if (threadIdx.x == 0) {
-        long long acc = 0;
-        for (int b = 0; b < nb; ++b) { off[b] = acc; acc += cnt[b]; }
-        off[nb] = acc;
-    }
-    __syncthreads();
-    const long long total = off[nb];
-    for (int b = 0; b < nb; ++b) {
-        const long long c = cnt[b] < m_cap ? cnt[b] : m_cap;
-        for (long long q = threadIdx.x; q < c; q += blockDim.x)
-            if (off[b] + q < m_cap) cand_idx[off[b] + q] = tmp[(long long)b * m_cap + q];
-    }
-    if (threadIdx.x == 0) {
+__global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ tmp, const long long* __restrict__ cnt,
+                                                  int nb, long long m_cap, long long* __restrict__ cand_idx,
+                                                  PanelState* __restrict__ panel) {
+    // block b copies its own piece to its offset = sum of the counts of the blocks before it
+    const int b = blockIdx.x;
+    long long off = 0;
+    for (int q = threadIdx.x; q < b; q += 64) off += cnt[q];
+    off = (long long)wave_sum((double)off);            // counts are small integers: exact in f64
+    const long long c = cnt[b];
+    for (long long q = threadIdx.x; q < c && q < m_cap; q += 64)
+        if (off + q < m_cap) cand_idx[off + q] = tmp[(long long)b * m_cap + q];
+    if (b == nb - 1 && threadIdx.x == 0) {
+        const long long total = off + c;
         panel->n_cand = total > m_cap ? m_cap : total;
         panel->pad = total > m_cap ? 1 : 0;          // overflow: some candidates were dropped
     }
@@ -532,6 +528,87 @@ __global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS) wn2[threadIdx.x] = 1.0;
 }
 
+// --------------------------------------------------------------------------------------
+// k_project_lds: the same product Y = X . Wt, organised for memory-level parallelism.
+// One SWEEP covers nf <= 1008 frames: that slice of Wt sits in LDS (<= 126 KB, rows permuted so
+// that the four 16-lane groups of a ds_read_b64 hit disjoint bank halves), every WAVE is
+// independent: it pulls 16-row tiles from an atomic counter, streams the tile's half-rows from
+// HBM straight into the MFMA A position (32 B per lane = whole 128-byte lines per row) and keeps
+// only 4 accumulator registers -- no cross-wave reduction, no barrier in the loop, 16 waves per CU
+// with several KB in flight each.  F > 1008 takes several sweeps (launches); the 16x16 partial
+// tiles travel through a small scratch buffer (rows x 16 doubles).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ int wt_perm(int f) { return (f & ~5) | ((f & 1) << 2) | ((f >> 2) & 1); }
+
+__global__ __launch_bounds__(1024) void k_project_lds(
+    const double* __restrict__ X, long long rows, int Fp, int f_begin, int nf, const double* __restrict__ Wt,
+    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride,
+    double* __restrict__ ypart, int first, int last, unsigned int* __restrict__ counter) {
+    extern __shared__ double wl[];
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4;
+    for (int e = tid; e < nf * 16; e += blockDim.x) {
+        const int f = e >> 4, c = e & 15;
+        wl[wt_perm(f) * 16 + c] = Wt[(long long)(f_begin + f) * ASB_PANEL_COLS + c];
+    }
+    __syncthreads();
+    const long long ntiles = (rows + 15) / 16;
+    const int nchunk = nf / 16;
+    // LDS word offsets of this lane's four B values inside a chunk (see wt_perm): frame 4g + j
+    const int boff0 = (((g >> 1) * 8 + 0 + (g & 1)) * 16 + i);         // j = 0
+    const int boff1 = (((g >> 1) * 8 + 4 + (g & 1)) * 16 + i);         // j = 1
+    const int boff2 = (((g >> 1) * 8 + 2 + (g & 1)) * 16 + i);         // j = 2
+    const int boff3 = (((g >> 1) * 8 + 6 + (g & 1)) * 16 + i);         // j = 3
+    for (;;) {
+        unsigned int t = 0;
+        if (l == 0) t = atomicAdd(counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((long long)t >= ntiles) break;
+        long long r = (long long)t * 16 + i;
+        if (r >= rows) r = rows - 1;
+        const double* xr = X + r * Fp + f_begin + 4 * g;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (!first) acc = *reinterpret_cast<const d4*>(ypart + ((long long)t * 64 + l) * 4);
+#define ASB_MFMA4(xv, cc)                                                                       \
+    {                                                                                           \
+        const double* wb = wl + (cc) * 256;                                                     \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).x, wb[boff0], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).y, wb[boff1], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).z, wb[boff2], acc, 0, 0, 0);            \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).w, wb[boff3], acc, 0, 0, 0);            \
+    }
+        // groups of 4 chunks, double-buffered in registers: the next group's 8 KB per wave is in
+        // flight while the current group's 16 MFMAs issue
+        const double4* xp = reinterpret_cast<const double4*>(xr);      // chunk c is xp[4*c]
+        int c = 0;
+        double4 a0, a1, a2, a3;
+        if (nchunk >= 4) { a0 = xp[0]; a1 = xp[4]; a2 = xp[8]; a3 = xp[12]; }
+        for (; c + 8 <= nchunk; c += 4) {
+            const double4 b0 = xp[4 * (c + 4)], b1 = xp[4 * (c + 5)], b2 = xp[4 * (c + 6)], b3 = xp[4 * (c + 7)];
+            ASB_MFMA4(a0, c) ASB_MFMA4(a1, c + 1) ASB_MFMA4(a2, c + 2) ASB_MFMA4(a3, c + 3)
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        }
+        if (c + 4 <= nchunk) {
+            ASB_MFMA4(a0, c) ASB_MFMA4(a1, c + 1) ASB_MFMA4(a2, c + 2) ASB_MFMA4(a3, c + 3)
+            c += 4;
+        }
+        for (; c < nchunk; ++c) {
+            const double4 x = xp[4 * c];
+            ASB_MFMA4(x, c)
+        }
+        if (last) {
+            if (i < ncols) {
+                const double inv = wn2[i];
+                double* dst = comps + (long long)i * comp_stride + (long long)t * 16 + g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((long long)t * 16 + g + 4 * q < rows) dst[4 * q] = acc[q] / inv;
+            }
+        } else {
+            *reinterpret_cast<d4*>(ypart + ((long long)t * 64 + l) * 4) = acc;
+        }
+    }
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
                                                 double* __restrict__ scal) {
@@ -610,7 +687,38 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     return ASB_OK;
 }
 
+static int launch_project_lds(asb_ctx* ctx, int ncols, double* out) {
+    const int NC = (int)(ctx->Fp / 16);
+    const long long rows = 3 * ctx->n_loc;
+    const int nsweep = (NC + 62) / 63;
+    const int cs = (NC + nsweep - 1) / nsweep;
+    int rc;
+    if (nsweep > 1 && (rc = asb_alloc(ctx, &ctx->ypart, (size_t)((rows + 15) / 16) * 256))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    const size_t lds = (size_t)cs * 16 * 16 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 63 * 256 * 8));
+        attr_set = true;
+    }
+    const long long ntiles = (rows + 15) / 16;
+    long long wantb = (ntiles + 15) / 16;
+    const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
+    ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
+    for (int sw = 0; sw < nsweep; ++sw) {
+        const int c0 = sw * cs, c1 = (c0 + cs < NC) ? c0 + cs : NC;
+        hipLaunchKernelGGL(k_project_lds, dim3(grid), dim3(1024), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, c0 * 16,
+                           (c1 - c0) * 16, ctx->Wt, ctx->wn2t, ncols, out, rows, ctx->ypart, sw == 0 ? 1 : 0,
+                           sw == nsweep - 1 ? 1 : 0, ctx->tile_counter + sw);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 static void launch_project(asb_ctx* ctx, int ncols, double* out) {
+    if (ctx->project_kernel == 2 && ctx->Fp <= 16 * 63 * 16) {
+        if (launch_project_lds(ctx, ncols, out) == ASB_OK) return;
+    }
     const int NC = (int)(ctx->Fp / 16);
     const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
     int grid = ctx->n_cu * ((NC <= 16) ? 2 : 1);
@@ -728,7 +836,7 @@ extern "C" int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, in
     } else {
         hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0,
                            ctx->scalar_dev, global_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt);
-        hipLaunchKernelGGL(k_compact_b, dim3(1), dim3(256), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS,
+        hipLaunchKernelGGL(k_compact_b, dim3(ASB_CBLOCKS), dim3(64), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS,
                            (long long)ctx->m_cap, idx, ctx->pstate);
     }
     ASB_CHECK_LAUNCH(ctx);

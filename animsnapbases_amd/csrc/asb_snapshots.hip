@@ -3,6 +3,7 @@
 // gfx950 (MI355X) only.
 #include "asb_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 // --------------------------------------------------------------------------------------
@@ -139,6 +140,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
         ctx->own_stream = true;
     }
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char* pk = getenv("ASB_PROJECT_KERNEL")) ctx->project_kernel = atoi(pk);
     ctx->nblk_cap = prop.multiProcessorCount * 8;   // grid cap for streaming passes (guide: G11)
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->pmax, (size_t)ctx->nblk_cap))) return rc;
