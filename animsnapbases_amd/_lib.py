@@ -56,6 +56,9 @@ PROTOTYPES = {
     "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_post": (c_int, [ctypes.c_void_p, c_int, c_dbl, c_dp, c_dp]),
+    "asb_orth_gram": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_orth_apply": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "asb_components_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
     "asb_splocs_begin": (c_int, [ctypes.c_void_p]),
     "asb_splocs_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.POINTER(c_dbl)]),
     "asb_splocs_weights": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp]),

@@ -88,6 +88,18 @@ struct asb_ctx {
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
 
+    // ---- small dense linear algebra scratch (asb_linalg.hip) ----
+    double* la_part = nullptr;
+    size_t la_part_cap = 0;
+    double* comps2 = nullptr;     // second basis buffer (orthogonalisation output)
+    double* og = nullptr;         // (3, K, K) per-dimension Gram / scaled eigenvectors
+    double* olam = nullptr;       // (3, K)
+    double* oct = nullptr;        // (3 n_loc, K) transposed basis
+    double* ovec = nullptr;       // (3, K, K) eigenvectors
+    double* osing = nullptr;      // (3, K) singular values
+    double* la_vtmp = nullptr;
+    int* la_status = nullptr;
+
     // ---- profiling of the dominant streaming kernel ----
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -98,6 +110,17 @@ struct asb_ctx {
 int asb_project_begin(asb_ctx* ctx, int64_t K);
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
 void asb_splocs_free(asb_ctx* ctx);
+// small dense linear algebra on the device (asb_linalg.hip)
+// out[i*so_i + j*so_j] = sum_r A[r*lda + i*sa] * B[r*ldb + j]   (f64 MFMA; contraction index r slow in A and B)
+int asb_gemm_tn_s(asb_ctx* ctx, const double* A, long long lda, long long sa, const double* B, long long ldb, long long Rn,
+                  int I, int J, double* out, long long so_i, long long so_j);
+static inline int asb_gemm_tn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, long long Rn,
+                              int I, int J, double* out) {
+    return asb_gemm_tn_s(ctx, A, lda, 1, B, ldb, Rn, I, J, out, J, 1);
+}
+int asb_transpose(asb_ctx* ctx, const double* in, long long rows, long long cols, double* out);   // (rows x cols) -> (cols x rows)
+// eigen-decomposition of a symmetric n x n matrix (n <= 128) on the device: lam (n) descending, V (n x n) columns
+int asb_sym_eig(asb_ctx* ctx, const double* A_dev, int n, double* lam_dev, double* V_dev);
 int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local);
 
 #define ASB_FAIL(ctx, code, ...)                                   \

@@ -1,0 +1,328 @@
+// Small dense linear algebra on the device (f64): MFMA "TN" GEMM, transpose, a one-block
+// Jacobi eigen-solver, and on top of them the per-dimension orthogonalisation of the basis --
+// posComponents.post_process_components, snapbases/posComponents.py:284-287
+// (`comps[:,:,l] = orth(comps[:,:,l].T).T`, scipy's SVD-based orth).  gfx950 only.
+#include "asb_kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// --------------------------------------------------------------------------------------
+// k_gemm_tn:  part[s][i][j] = sum_{r in slab s} A[r*lda + i*sa] * B[r*ldb + j]   (v_mfma_f64_16x16x4_f64)
+// One wave per (16x16 output tile, slab).  Lane (i = l&15, g = l>>4) feeds A[r+g][i0+i] and
+// B[r+g][j0+i].  With one slab the result goes straight to out[i*so_i + j*so_j].
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gemm_tn(const double* __restrict__ A, long long lda, long long sa,
+                                                const double* __restrict__ B, long long ldb, long long Rn, int I,
+                                                int J, long long slab, double* __restrict__ out, long long so_i,
+                                                long long so_j, long long slab_stride) {
+    const int l = threadIdx.x, i = l & 15, g = l >> 4;
+    const int tj = (J + 15) / 16;
+    const int ti = blockIdx.x / tj, tjx = blockIdx.x % tj;
+    const int i0 = ti * 16, j0 = tjx * 16;
+    const long long r0 = (long long)blockIdx.y * slab;
+    long long r1 = r0 + slab;
+    if (r1 > Rn) r1 = Rn;
+    const bool ai = (i0 + i) < I, bj = (j0 + i) < J;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = A + (long long)(i0 + i) * sa;
+    const double* pb = B + (j0 + i);
+    for (long long rb = r0; rb < r1; rb += 4) {
+        const long long r = rb + g;
+        const bool in = r < r1;
+        const double a = (in && ai) ? pa[r * lda] : 0.0;
+        const double b = (in && bj) ? pb[r * ldb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double* o = out + (long long)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oi = i0 + g + 4 * q, oj = j0 + i;
+        if (oi < I && oj < J) o[(long long)oi * so_i + (long long)oj * so_j] = acc[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_slabs(const double* __restrict__ part, int S, int I, int J,
+                                                   double* __restrict__ out, long long so_i, long long so_j) {
+    const long long n = (long long)I * J;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < S; ++q) s += part[(long long)q * n + e];
+        out[(e / J) * so_i + (e % J) * so_j] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_transpose_small(const double* __restrict__ in, long long rows, long long cols,
+                                                         double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    for (int q = 0; q < 4; ++q) {
+        const long long r = r0 + ty + q * 8, c = c0 + tx;
+        tile[ty + q * 8][tx] = (r < rows && c < cols) ? in[r * cols + c] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const long long c = c0 + ty + q * 8, r = r0 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + q * 8];
+    }
+}
+
+int asb_gemm_tn_s(asb_ctx* ctx, const double* A, long long lda, long long sa, const double* B, long long ldb, long long Rn,
+                  int I, int J, double* out, long long so_i, long long so_j) {
+    const int tiles = ((I + 15) / 16) * ((J + 15) / 16);
+    int S = (int)(4096 / (tiles > 0 ? tiles : 1));
+    if (S < 1) S = 1;
+    long long maxS = (Rn + 63) / 64;
+    if (S > maxS) S = (int)maxS;
+    if (S > 64) S = 64;
+    long long slab = ((Rn + S - 1) / S + 3) / 4 * 4;
+    S = (int)((Rn + slab - 1) / slab);
+    if (S > 1) {
+        const size_t need = (size_t)S * I * J;
+        if (need > ctx->la_part_cap) {
+            int rc = asb_alloc(ctx, &ctx->la_part, need);
+            if (rc) return rc;
+            ctx->la_part_cap = need;
+        }
+        hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64), 0, ctx->stream, A, lda, sa, B, ldb, Rn, I, J, slab,
+                           ctx->la_part, (long long)J, (long long)1, (long long)I * J);
+        const long long n = (long long)I * J;
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                           ctx->stream, ctx->la_part, S, I, J, out, so_i, so_j);
+    } else {
+        hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, 1), dim3(64), 0, ctx->stream, A, lda, sa, B, ldb, Rn, I, J, slab, out, so_i,
+                           so_j, (long long)0);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+int asb_transpose(asb_ctx* ctx, const double* in, long long rows, long long cols, double* out) {
+    dim3 tg((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_small, tg, dim3(256), 0, ctx->stream, in, rows, cols, out);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// k_jacobi_eig: cyclic two-sided Jacobi with the round-robin (tournament) ordering: n/2
+// disjoint rotations per round run in parallel, n-1 rounds per sweep.  A lives in LDS, V in
+// global memory.  One block.  Output: eigenvalues sorted descending, V columns accordingly.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ Ain, int n, double* __restrict__ lam,
+                                                     double* __restrict__ V, double* __restrict__ Vtmp,
+                                                     int* __restrict__ status) {
+    extern __shared__ double sm[];
+    const int ne = n + (n & 1);                 // even size (a decoupled dummy index when n is odd)
+    double* A = sm;                             // ne x ne
+    double* cs = A + ne * ne;                   // ne/2 cosines
+    double* sn = cs + ne / 2;                   // ne/2 sines
+    int* perm = reinterpret_cast<int*>(sn + ne / 2);      // ne
+    __shared__ double red[32];
+    __shared__ int conv;
+    const int tid = threadIdx.x, nt = blockDim.x, half = ne / 2;
+    for (int e = tid; e < ne * ne; e += nt) {
+        const int r = e / ne, c = e % ne;
+        A[e] = (r < n && c < n) ? Ain[r * n + c] : 0.0;
+    }
+    for (int e = tid; e < n * n; e += nt) Vtmp[e] = (e / n == e % n) ? 1.0 : 0.0;
+    for (int e = tid; e < ne; e += nt) perm[e] = e;
+    if (tid == 0) conv = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        // convergence: off-diagonal energy against the diagonal's
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < ne * ne; e += nt) {
+            const double v = A[e];
+            if (e / ne == e % ne) dia += v * v; else off += v * v;
+        }
+        off = wave_sum(off); dia = wave_sum(dia);
+        if ((tid & 63) == 0) { red[tid >> 6] = off; red[16 + (tid >> 6)] = dia; }
+        __syncthreads();
+        if (tid == 0) {
+            double o = 0.0, d = 0.0;
+            for (int q = 0; q < (nt >> 6); ++q) { o += red[q]; d += red[16 + q]; }
+            conv = (o <= 1.0e-60 || o <= 1.0e-34 * d) ? 1 : 0;
+        }
+        __syncthreads();
+        if (conv) break;
+        for (int round = 0; round < ne - 1; ++round) {
+            // rotation angles of this round's pairs (perm[m], perm[ne-1-m])
+            if (tid < half) {
+                int p = perm[tid], q = perm[ne - 1 - tid];
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double apq = A[p * ne + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (A[q * ne + q] - A[p * ne + p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    s = t * c;
+                }
+                cs[tid] = c; sn[tid] = s;
+            }
+            __syncthreads();
+            // columns: A <- A J
+            for (int e = tid; e < half * ne; e += nt) {
+                const int m = e / ne, i = e % ne;
+                int p = perm[m], q = perm[ne - 1 - m];
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double c = cs[m], s = sn[m];
+                const double aip = A[i * ne + p], aiq = A[i * ne + q];
+                A[i * ne + p] = c * aip - s * aiq;
+                A[i * ne + q] = s * aip + c * aiq;
+            }
+            __syncthreads();
+            // rows: A <- J^T A ; eigenvectors: V <- V J
+            for (int e = tid; e < half * ne; e += nt) {
+                const int m = e / ne, j = e % ne;
+                int p = perm[m], q = perm[ne - 1 - m];
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double c = cs[m], s = sn[m];
+                const double apj = A[p * ne + j], aqj = A[q * ne + j];
+                A[p * ne + j] = c * apj - s * aqj;
+                A[q * ne + j] = s * apj + c * aqj;
+                if (j < n && p < n && q < n) {
+                    const double vp = Vtmp[j * n + p], vq = Vtmp[j * n + q];
+                    Vtmp[j * n + p] = c * vp - s * vq;
+                    Vtmp[j * n + q] = s * vp + c * vq;
+                }
+            }
+            __syncthreads();
+            if (tid < half) {                   // exact zeros where the rotation annihilated
+                int p = perm[tid], q = perm[ne - 1 - tid];
+                A[p * ne + q] = 0.0; A[q * ne + p] = 0.0;
+            }
+            if (tid == 0) {                     // rotate the tournament: perm[1..ne-1] cyclically
+                const int last = perm[ne - 1];
+                for (int e = ne - 1; e > 1; --e) perm[e] = perm[e - 1];
+                perm[1] = last;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && !conv) status[0] = 2;
+    // sort descending (selection sort by thread 0 on <= 128 values), then permute the columns
+    if (tid == 0) {
+        for (int i = 0; i < n; ++i) perm[i] = i;
+        for (int i = 0; i < n; ++i) {
+            int b = i;
+            for (int j = i + 1; j < n; ++j)
+                if (A[perm[j] * ne + perm[j]] > A[perm[b] * ne + perm[b]]) b = j;
+            const int t = perm[i]; perm[i] = perm[b]; perm[b] = t;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nt) lam[j] = A[perm[j] * ne + perm[j]];
+    for (int e = tid; e < n * n; e += nt) {
+        const int r = e / n, j = e % n;
+        V[e] = Vtmp[r * n + perm[j]];
+    }
+}
+
+int asb_sym_eig(asb_ctx* ctx, const double* A_dev, int n, double* lam_dev, double* V_dev) {
+    if (n < 1 || n > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "device eigen-solver supports n <= 128 (n = %d)", n);
+    const int ne = n + (n & 1);
+    const size_t lds = ((size_t)ne * ne + ne) * sizeof(double) + (size_t)ne * sizeof(int) + 64;
+    static size_t attr = 0;
+    if (lds > 48 * 1024 && lds > attr) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_vtmp, (size_t)n * n))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(n <= 32 ? 256 : 1024), lds, ctx->stream, A_dev, n, lam_dev, V_dev,
+                       ctx->la_vtmp, ctx->la_status);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// per-dimension orthogonalisation of the basis
+// --------------------------------------------------------------------------------------
+// Vs[k][j] = V[k][j] / sqrt(lam[j]);  sing[j] = sqrt(lam[j]);  status[1] = 1 if rank-deficient
+__global__ __launch_bounds__(256) void k_scale_eigvecs(const double* __restrict__ V, const double* __restrict__ lam, int n,
+                                                       double tol_rel, double* __restrict__ Vs, double* __restrict__ sing,
+                                                       int* __restrict__ status) {
+    const double smax = sqrt(fmax(lam[0], 0.0));
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int j = e % n;
+        const double sj = sqrt(fmax(lam[j], 0.0));
+        Vs[e] = (sj > 0.0) ? V[e] / sj : 0.0;
+        if (e < n) {
+            const double se = sqrt(fmax(lam[e], 0.0));
+            sing[e] = se;
+            if (!(se > tol_rel * smax)) status[1] = 1;
+        }
+    }
+}
+
+// partial Gram matrices of the three coordinate slices: G[l] = A_l^T A_l (K x K), A_l[v][k] = comps[k][v][l]
+extern "C" int asb_orth_gram(asb_ctx* ctx, double* G_dev) {
+    if (!ctx || !ctx->comps) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, n = ctx->n_loc;
+    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "q_orthogonal on the device supports K <= 128 (K = %lld)", (long long)K);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->oct, (size_t)3 * n * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->og, (size_t)3 * K * K))) return rc;
+    if ((rc = asb_transpose(ctx, ctx->comps, K, 3 * n, ctx->oct))) return rc;          // (3n x K): row 3v+l
+    double* G = G_dev ? G_dev : ctx->og;
+    for (int l = 0; l < 3; ++l)
+        if ((rc = asb_gemm_tn(ctx, ctx->oct + l * K, 3 * K, ctx->oct + l * K, 3 * K, n, (int)K, (int)K, G + (size_t)l * K * K)))
+            return rc;
+    return ASB_OK;
+}
+
+// with the (all-reduced) Gram matrices: eigen-solve, U_l = A_l V S^-1, comps[:,:,l] = U_l^T.
+// sing_out (host, 3*K, optional): the singular values per dimension.  N_glob is used for scipy's
+// rank tolerance max(N, K) * eps * s_max.
+extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out) {
+    if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, n = ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->olam, (size_t)3 * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->osing, (size_t)3 * K))) return rc;
+    if (G_dev) ASB_HIP(ctx, hipMemcpyAsync(ctx->og, G_dev, (size_t)3 * K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const double Nmax = (double)(ctx->N_glob > K ? ctx->N_glob : K);
+    int st_host[4] = {0, 0, 0, 0};
+    for (int l = 0; l < 3; ++l) {
+        double* Gl = ctx->og + (size_t)l * K * K;
+        double* Vl = ctx->ovec + (size_t)l * K * K;
+        if ((rc = asb_sym_eig(ctx, Gl, (int)K, ctx->olam + l * K, Vl))) return rc;
+        hipLaunchKernelGGL(k_scale_eigvecs, dim3(1), dim3(256), 0, ctx->stream, Vl, ctx->olam + l * K, (int)K,
+                           Nmax * 2.220446049250313e-16, Gl, ctx->osing + l * K, ctx->la_status);
+        ASB_CHECK_LAUNCH(ctx);
+        int st[4];
+        ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        st_host[0] |= st[0]; st_host[1] |= st[1];
+        // U_l^T written straight into the new basis: out[v][j] -> comps2[j][3v + l]
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, Gl, K, K, (int)n, (int)K, ctx->comps2 + l, 3, 3 * n))) return rc;
+    }
+    if (st_host[0] == 2) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "orthogonalisation: the Jacobi eigen-solver did not converge");
+    if (st_host[1]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "orthogonalisation: the basis is rank deficient in one dimension "
+                                                  "(scipy.linalg.orth would drop vectors)");
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (sing_out) {
+        ASB_HIP(ctx, hipMemcpyAsync(sing_out, ctx->osing, (size_t)3 * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ASB_OK;
+}
+
+// replaces the device-resident basis by a host array (K, n_loc, 3) (a caller-assigned `comps`)
+extern "C" int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K) {
+    if (!ctx || !ctx->X || !comps_host || K < 1) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * 3 * ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+    ctx->K = K;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, comps_host, (size_t)K * 3 * ctx->n_loc * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}

@@ -18,68 +18,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows);
 
 // --------------------------------------------------------------------------------------
-// k_gemm_tn:  part[s][i][j] = sum_{r in slab s} A[r][i] * B[r][j]      (f64 MFMA 16x16x4)
-// A: (Rn x lda), B: (Rn x ldb), contraction index r is the slow dimension of both.
-// One wave per (16x16 output tile, slab).  Lane (i = l&15, g = l>>4) feeds A[r+g][i0+i],
-// B[r+g][j0+i]: four rows x 128 contiguous bytes per operand per MFMA.
-// --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gemm_tn(const double* __restrict__ A, long long lda,
-                                                const double* __restrict__ B, long long ldb, long long Rn, int I,
-                                                int J, long long slab, double* __restrict__ part) {
-    const int l = threadIdx.x, i = l & 15, g = l >> 4;
-    const int tj = (J + 15) / 16;
-    const int ti = blockIdx.x / tj, tjx = blockIdx.x % tj;
-    const int i0 = ti * 16, j0 = tjx * 16;
-    const long long r0 = (long long)blockIdx.y * slab;
-    long long r1 = r0 + slab;
-    if (r1 > Rn) r1 = Rn;
-    const bool ai = (i0 + i) < I, bj = (j0 + i) < J;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    const double* pa = A + (i0 + i);
-    const double* pb = B + (j0 + i);
-    for (long long rb = r0; rb < r1; rb += 4) {
-        const long long r = rb + g;
-        const bool in = r < r1;
-        const double a = (in && ai) ? pa[r * lda] : 0.0;
-        const double b = (in && bj) ? pb[r * ldb] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    double* out = part + (long long)blockIdx.y * I * J;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int oi = i0 + g + 4 * q, oj = j0 + i;
-        if (oi < I && oj < J) out[(long long)oi * J + oj] = acc[q];
-    }
-}
-
-// out[e] = sum_s part[s][e]
-__global__ __launch_bounds__(256) void k_sum_slabs(const double* __restrict__ part, int S, long long n,
-                                                   double* __restrict__ out) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int q = 0; q < S; ++q) s += part[(long long)q * n + e];
-        out[e] = s;
-    }
-}
-
-// (rows x cols) -> (cols x rows)
-__global__ __launch_bounds__(256) void k_transpose_small(const double* __restrict__ in, long long rows, long long cols,
-                                                         double* __restrict__ out) {
-    __shared__ double tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
-    for (int q = 0; q < 4; ++q) {
-        const long long r = r0 + ty + q * 8, c = c0 + tx;
-        tile[ty + q * 8][tx] = (r < rows && c < cols) ? in[r * cols + c] : 0.0;
-    }
-    __syncthreads();
-    for (int q = 0; q < 4; ++q) {
-        const long long c = c0 + ty + q * 8, r = r0 + tx;
-        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + q * 8];
-    }
-}
-
-// --------------------------------------------------------------------------------------
 // k_bcd: the block-coordinate-descent sweep over the K weight columns (:144-156), one block.
 // W (F x K) row-major is updated in place;  opt = (P[:,k] - W M[:,k]) / M[k,k] + W[:,k];
 // W[:,k] = project_weight(opt)  (clamp at 0, divide by the max unless it is 0).
@@ -256,39 +194,11 @@ __global__ __launch_bounds__(256) void k_w_to_fk(const double* __restrict__ W, i
 struct asb_splocs {
     int64_t K = 0;
     double *C = nullptr, *Z = nullptr, *U = nullptr, *c = nullptr, *rhs = nullptr, *Lambda = nullptr, *Ct = nullptr;
-    double *Wfk = nullptr, *P = nullptr, *M = nullptr, *G = nullptr, *Ginv = nullptr, *part = nullptr, *red = nullptr;
+    double *Wfk = nullptr, *P = nullptr, *M = nullptr, *G = nullptr, *Ginv = nullptr, *red = nullptr;
     double *cen_val = nullptr;
     long long* cen_idx = nullptr;
     int* status = nullptr;
-    size_t part_cap = 0;
 };
-
-static int gemm_tn(asb_ctx* ctx, asb_splocs* s, const double* A, long long lda, const double* B, long long ldb,
-                   long long Rn, int I, int J, double* out) {
-    const int tiles = ((I + 15) / 16) * ((J + 15) / 16);
-    int S = (int)(4096 / (tiles > 0 ? tiles : 1));
-    if (S < 1) S = 1;
-    long long maxS = (Rn + 63) / 64;
-    if (S > maxS) S = (int)maxS;
-    if (S > 64) S = 64;
-    long long slab = ((Rn + S - 1) / S + 3) / 4 * 4;
-    S = (int)((Rn + slab - 1) / slab);
-    const size_t need = (size_t)S * I * J;
-    if (need > s->part_cap) {
-        int rc = asb_alloc(ctx, &s->part, need);
-        if (rc) return rc;
-        s->part_cap = need;
-    }
-    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(64), 0, ctx->stream, A, lda, B, ldb, Rn, I, J, slab,
-                       S == 1 ? out : s->part);
-    if (S > 1) {
-        const long long n = (long long)I * J;
-        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
-                           ctx->stream, s->part, S, n, out);
-    }
-    ASB_CHECK_LAUNCH(ctx);
-    return ASB_OK;
-}
 
 static int dot_to_host(asb_ctx* ctx, asb_splocs* s, const double* a, const double* b, long long n, double* out) {
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -341,12 +251,10 @@ extern "C" int asb_splocs_gram(asb_ctx* ctx, double* P_dev, double* M_dev, doubl
     const int64_t K = s->K, n3 = 3 * ctx->n_loc;
     double* Pout = P_dev ? P_dev : s->P;
     double* Mout = M_dev ? M_dev : s->M;
-    dim3 tg((unsigned)((n3 + 31) / 32), (unsigned)((K + 31) / 32));
-    hipLaunchKernelGGL(k_transpose_small, tg, dim3(256), 0, ctx->stream, s->C, (long long)K, (long long)n3, s->Ct);
-    ASB_CHECK_LAUNCH(ctx);
     int rc;
-    if ((rc = gemm_tn(ctx, s, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout))) return rc;
-    if ((rc = gemm_tn(ctx, s, s->Ct, K, s->Ct, K, n3, (int)K, (int)K, Mout))) return rc;
+    if ((rc = asb_transpose(ctx, s->C, K, n3, s->Ct))) return rc;
+    if ((rc = asb_gemm_tn(ctx, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout))) return rc;
+    if ((rc = asb_gemm_tn(ctx, s->Ct, K, s->Ct, K, n3, (int)K, (int)K, Mout))) return rc;
     if (normX2_local) return dot_to_host(ctx, s, ctx->X, ctx->X, (long long)n3 * ctx->Fp, normX2_local);
     return ASB_OK;
 }
@@ -362,7 +270,7 @@ extern "C" int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const doubl
     if (M_dev) ASB_HIP(ctx, hipMemcpyAsync(s->M, M_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_bcd, dim3(1), dim3(1024), (K + 16) * sizeof(double), ctx->stream, s->Wfk, s->P, s->M, F, K);
     ASB_CHECK_LAUNCH(ctx);
-    int rc = gemm_tn(ctx, s, s->Wfk, K, s->Wfk, K, F, K, K, s->G);
+    int rc = asb_gemm_tn(ctx, s->Wfk, K, s->Wfk, K, F, K, K, s->G);
     if (rc) return rc;
     hipLaunchKernelGGL(k_centres, dim3(K), dim3(256), 0, ctx->stream, s->C, (long long)ctx->n_loc, (long long)ctx->v0,
                        s->cen_idx, s->cen_val);
@@ -398,7 +306,7 @@ extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, i
     const int pg = (int)((kn + 255) / 256 < 4096 ? (kn + 255) / 256 : 4096);
     for (int it = 0; it < n_iter; ++it) {
         hipLaunchKernelGGL(k_admm_rhs, dim3(eg), dim3(256), 0, ctx->stream, s->c, s->Z, s->U, rho, n, s->rhs);
-        int rc = gemm_tn(ctx, s, s->Ginv, K, s->rhs, n3, K, (int)K, (int)n3, s->C);      // C = (G + rho I)^-1 rhs
+        int rc = asb_gemm_tn(ctx, s->Ginv, K, s->rhs, n3, K, (int)K, (int)n3, s->C);      // C = (G + rho I)^-1 rhs
         if (rc) return rc;
         hipLaunchKernelGGL(k_admm_prox, dim3(pg), dim3(256), 0, ctx->stream, s->C, s->Z, s->U, s->Lambda, 1.0 / rho, kn);
     }

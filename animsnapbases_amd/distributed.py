@@ -122,6 +122,10 @@ class Comm(object):
         dev = self._dev if on_device else torch.device("cpu")
         return (torch.zeros(F * K, dtype=torch.float64, device=dev), torch.zeros(K * K, dtype=torch.float64, device=dev))
 
+    def new_buffer(self, n, on_device):
+        torch = self._need_torch()
+        return torch.zeros(int(n), dtype=torch.float64, device=self.exchange_device(on_device))
+
     def allreduce_tensor(self, t):
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

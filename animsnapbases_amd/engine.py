@@ -247,6 +247,20 @@ class HipEngine(object):
         return C, W
 
     # ------------------------------------------------------------------ post-processing
+    def components_upload(self, comps_loc):
+        comps_loc = np.ascontiguousarray(comps_loc, dtype=np.float64)
+        assert comps_loc.ndim == 3 and comps_loc.shape[1:] == (self.n_loc, 3)
+        self._ck(self.lib.asb_components_upload(self.h, ptr(comps_loc), comps_loc.shape[0]))
+        self.K = int(comps_loc.shape[0])
+
+    def orth_gram(self, G_dev_ptr=None):
+        self._ck(self.lib.asb_orth_gram(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
+
+    def orth_apply(self, G_dev_ptr=None):
+        sing = np.empty((3, self.K))
+        self._ck(self.lib.asb_orth_apply(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None, ptr(sing)))
+        return sing
+
     def components_post(self, unscale, pre_scale_factor, invMassL_loc=None):
         out = np.empty((self.K, self.n_loc, 3))
         if invMassL_loc is not None:

@@ -301,25 +301,40 @@ class posComponents:  # Components == bases
 
     @log_time("")
     def post_process_components(self):
-        """posComponents.py:274-302."""
+        """posComponents.py:274-302 on the device-resident basis: un-scale and add the mean
+        (:279-282), per-dimension `orth` (:284-287: Gram -> K x K eigen-solve -> U = A V S^-1, the
+        partial Gram matrices all-reduced over ranks), mass un-weighting (:289-292), then the
+        reference's printed checks."""
         print("Post-processing pos components ...")
         snaps = self.pos_snapshots
         eng, comm = snaps._engine, snaps._comm
         v0, n_loc = snaps._shards[comm.rank]
-        inv = None
-        if self.param.q_massWeight and not self.param.q_orthogonal:
-            assert snaps.nVerts == snaps.invMassL.shape[0]
-            inv = snaps.invMassL[v0:v0 + n_loc]
         if not self._comps_on_device:
-            raise NotImplementedError("post-processing host-assigned comps is not supported; "
-                                      "run extract_k_components first")
-        loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, inv)
-        self._comps = comm.all_gather_rows(loc, snaps.nVerts, axis=1)
+            if self._comps is None:
+                raise ValueError("no components: run compute_components_store_singvalues first")
+            eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))      # caller-assigned comps
+            self._comps_on_device = True
+        loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None)
         if self.param.q_orthogonal:
-            raise NotImplementedError("q_orthogonal: device orthogonalisation is not built yet (SURVEY.md 8f-1)")
+            Gbuf = None
+            if comm.world > 1:
+                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange)
+            eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+            if Gbuf is not None:
+                comm.allreduce_tensor(Gbuf)
+            self.ortho_sing_vals = eng.orth_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+            loc = None
+        if self.param.q_massWeight:
+            assert snaps.nVerts == snaps.invMassL.shape[0]
+            loc = eng.components_post(False, 1.0, snaps.invMassL[v0:v0 + n_loc])
+        if loc is None:
+            loc = eng.results(want_comps=True, want_weigs=False)["comps"]
+        self._comps = comm.all_gather_rows(loc, snaps.nVerts, axis=1)
 
         testSparsity(self.comps)
         test_linear_dependency(self.comps, 3, self.numComp)
+        if self.param.q_orthogonal:
+            self.is_utmu_orthogonal()
         print("... Volkwein (" + str(self.param.q_massWeight) + ")... standerized (" + str(self.param.q_standarize) +
               ")... support (" + str(self.support) + "), orthogonalized (" + str(self.param.q_orthogonal) + ").")
 
@@ -327,8 +342,11 @@ class posComponents:  # Components == bases
     def is_utmu_orthogonal(self):
         """posComponents.py:304-313."""
         print('... testing M orthogonality, U^T M U = I (K x K) ...', end='', flush=True)
+        mass = self.pos_snapshots.mass
+        if mass is None:        # (the reference needs q_massWeight here; without masses check U^T U = I)
+            mass = np.ones(self.comps.shape[1])
         for l in range(self.comps.shape[2]):
-            Mu_l = self.comps[:, :, l].T * self.pos_snapshots.mass[:, None]
+            Mu_l = self.comps[:, :, l].T * mass[:, None]
             utMu_l = dot(self.comps[:, :, l], Mu_l)
             assert allclose(utMu_l, eye(self.comps.shape[0]))
         print('(True).')

@@ -164,6 +164,17 @@ int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
                         const double* invMassL_loc, double* comps_out);
 
+/* :284-287 `comps[:,:,l] = orth(comps[:,:,l].T).T` (scipy's SVD-based orth) per dimension,
+ * as Gram (MFMA) -> K x K Jacobi eigen-solve -> U = A V S^-1, all on the device (K <= 128).
+ * asb_orth_gram: this shard's three K x K Gram matrices into G_dev (3*K*K doubles, caller's
+ * device buffer to be all-reduced over ranks) or into the context when NULL.
+ * asb_orth_apply: finishes with the (summed) Gram matrices; sing_out (host, 3*K, optional).
+ * Fails with ASB_ERR_NUMERIC when a slice is rank deficient (orth would drop vectors). */
+int asb_orth_gram(asb_ctx* ctx, double* G_dev);
+int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out);
+/* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
+int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
+
 /* ------------------------------------------------ SPLOCS refinement ----------- */
 /* posComponents.splocs_glob_optimization, snapbases/posComponents.py:132-189.
  * State after a residual-mode deflation: C = comps, W = weigs, U = 0 (:135-139).  One outer

@@ -372,3 +372,50 @@ def test_multirank_splocs_on_one_gpu():
         assert cen.tolist() == s["idx"].tolist()
         assert np.allclose(trace, s["trace"], rtol=1e-8)
         assert relerr(C, s["C"]) < 1e-8
+
+
+def _slice_signs(got, ref):
+    """orth / qr columns carry LAPACK's arbitrary sign per (component, dimension)."""
+    out = got.copy()
+    for k in range(got.shape[0]):
+        for l in range(3):
+            if np.dot(out[k, :, l], ref[k, :, l]) < 0:
+                out[k, :, l] *= -1
+    return out
+
+
+def test_orthogonal_post_process_vs_reference_golden():
+    """q_standarize + q_orthogonal + q_massWeight against the reference's post-processed basis.
+    Global-support components have an arbitrary sign and `+ mean` is applied before `orth`, so the
+    reference's own signs are installed first (comps setter -> device upload)."""
+    g = load_golden("pca_global_avg_mass_orth")
+    param = _param(g)
+    assert param.q_orthogonal and param.q_massWeight
+    snaps, comp = _run(g["verts"], g["tris"], param, g["mass"])
+    comps, _ = align_signs(comp.comps, comp.weigs, g["comps"])
+    assert relerr(comps, g["comps"]) < TOL
+    comp.comps = comps                                  # caller-assigned basis: uploaded by post_process
+    comp.post_process_components()                      # also runs the U^T M U = I assertion (:299)
+    got = _slice_signs(comp.comps, g["comps_post"])
+    assert relerr(got, g["comps_post"]) < 1e-8
+    assert relerr(comp.test_basesSingVals(), g["bases_sing_vals"]) < 1e-8
+    M = orc.utmu(comp.comps, g["mass"])
+    assert np.allclose(M, np.eye(comp.numComp)[None], atol=1e-9)
+
+
+def test_orthogonal_vs_oracle_local_support():
+    """Local support has canonical signs: deflation -> unscale -> orth on the device vs scipy's orth."""
+    rest_v, tris = orc.synth_mesh(14, 20, seed=12)
+    verts = orc.synth_snapshots(rest_v, 50, rank=8, seed=12, kind="bumps")
+    K = 10
+    param = _param(vertPos_numComponents=K, q_support="local", vertPos_smooth_max_dist=0.4, q_orthogonal=True)
+    snaps, comp = _run(verts, tris, param)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris)
+    d = orc.extract_k_components(pre["snapTensor"], K, "local", geo, 0.1, 0.4)
+    comp.post_process_components()
+    ref = orc.post_process_components(d["comps"], pre["pre_scale_factor"], pre["mean"], orthogonal=True)
+    got = _slice_signs(comp.comps, ref)
+    assert relerr(got, ref) < 1e-7
+    for l in range(3):
+        assert np.allclose(comp.comps[:, :, l] @ comp.comps[:, :, l].T, np.eye(K), atol=1e-10)

@@ -85,6 +85,9 @@ class ThreadComm(object):
         return (torch.zeros(F * K, dtype=torch.float64, device=self._dev),
                 torch.zeros(K * K, dtype=torch.float64, device=self._dev))
 
+    def new_buffer(self, n, on_device):
+        return self._torch.zeros(int(n), dtype=self._torch.float64, device=self._dev)
+
     def global_argmax(self, idx, val):
         allv = self.hub.exchange(self.rank, (val.copy(), idx.copy()))
         best = np.empty(idx.shape[0], dtype=np.int64)
