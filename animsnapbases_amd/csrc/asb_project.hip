@@ -667,13 +667,8 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     hipLaunchKernelGGL(k_build_wt, dim3(64), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, k0, ncols, (int)ctx->Fp,
                        ctx->Wt, ctx->wn2t);
     ASB_CHECK_LAUNCH(ctx);
-    size_t slot;
-    int rc = prof_begin(ctx, slot);
-    if (rc) return rc;
-    launch_project(ctx, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc);
+    launch_project(ctx, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc);      // HIP-event bracketed per kernel launch
     ASB_CHECK_LAUNCH(ctx);
-    rc = prof_end(ctx, slot);
-    if (rc) return rc;
     if (k0 > 0) hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)k0), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
@@ -707,9 +702,12 @@ static int launch_project_lds(asb_ctx* ctx, int ncols, double* out) {
     ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
     for (int sw = 0; sw < nsweep; ++sw) {
         const int c0 = sw * cs, c1 = (c0 + cs < NC) ? c0 + cs : NC;
+        size_t slot;
+        if ((rc = prof_begin(ctx, slot))) return rc;
         hipLaunchKernelGGL(k_project_lds, dim3(grid), dim3(1024), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, c0 * 16,
                            (c1 - c0) * 16, ctx->Wt, ctx->wn2t, ncols, out, rows, ctx->ypart, sw == 0 ? 1 : 0,
                            sw == nsweep - 1 ? 1 : 0, ctx->tile_counter + sw);
+        if ((rc = prof_end(ctx, slot))) return rc;
     }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -725,6 +723,8 @@ static void launch_project(asb_ctx* ctx, int ncols, double* out) {
     if (grid > nwg) grid = nwg;
     if (grid < 1) grid = 1;
     const long long rows = 3 * ctx->n_loc;
+    size_t slot;
+    (void)prof_begin(ctx, slot);
     if (NC <= 16)
         hipLaunchKernelGGL((k_project_mfma<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
                            (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
@@ -734,6 +734,7 @@ static void launch_project(asb_ctx* ctx, int ncols, double* out) {
     else
         hipLaunchKernelGGL((k_project_mfma<8, 16>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
                            (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
+    (void)prof_end(ctx, slot);
 }
 
 // out_rows (ncols, 3 n_loc) = X . Wfk[:, k0:k0+ncols]   (raw products, used for c = W^T X of SPLOCS)

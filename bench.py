@@ -148,8 +148,19 @@ def main():
         # one launch per PANEL of up to 16 components) or k_stream (residual mode: one per component).
         # algorithmic bytes per launch = 24 * n_loc * F (c = 1: one read of the shard)
         stats = eng.deflate_stats()
+        # HBM traffic from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected
+        # as the microarch guide prescribes; tools/summarise_pmc.py -> profiles/*_pmc_traffic.json).  Per pass over
+        # the shard: k_project_lds takes ceil(F/1008) sweep launches per pass.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if getattr(eng, "mode", 0) == 1 and "k_project_lds" in pm and (N, F, world) == (100000, 2000, 1):
+                traffic = pm["k_project_lds"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
-        alg_bytes = 24.0 * n_loc * F
+        nsweep = -(-((F + 15) // 16) // 63) if getattr(eng, "mode", 0) == 1 else 1     # k_project_lds launches per pass
+        alg_bytes = 24.0 * n_loc * F / nsweep
         avg_ms = kern_ms / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
         out = {
@@ -161,8 +172,8 @@ def main():
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": ("k_project_mfma<8,16> (f64-MFMA panel projection, one read of X per panel)"
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": ("k_project_lds (f64-MFMA panel projection; %d sweep launches = one read of X per panel)" % nsweep
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
                          "launches": launches,
