@@ -58,7 +58,14 @@ PROTOTYPES = {
     "asb_components_post": (c_int, [ctypes.c_void_p, c_int, c_dbl, c_dp, c_dp]),
     "asb_orth_gram": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_orth_apply": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "asb_components_download": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
+    "asb_pod_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "asb_pod_basis": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64]),
+    "asb_snapshots_affine": (c_int, [ctypes.c_void_p, c_dbl, c_int, c_dp]),
+    "asb_qr_apply": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_deim_step": (c_int, [ctypes.c_void_p, c_i64, c_dp, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+    "asb_deim_row": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_splocs_begin": (c_int, [ctypes.c_void_p]),
     "asb_splocs_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.POINTER(c_dbl)]),
     "asb_splocs_weights": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp]),

@@ -1,0 +1,329 @@
+"""``nonlinearSnapshots`` / ``constraintsComponents`` -- mirror of the reference classes
+(snapbases/nonlinear_snapshots.py, snapbases/constraintsComponents.py) for the part of them
+that BASELINE config 5 names: constraint-projection snapshots -> standardise -> POD
+(``pod_vectorized``) -> post-processing -> DEIM interpolation points -> ``.npz``.
+
+Device work (csrc/asb_pod.hip): the (3ep x F) snapshot matrix stays in HBM in the same
+row layout as the position path; its Gram matrix A^T A is accumulated with f64 MFMA over
+the row shard (partial Gram matrices all-reduced over ranks with RCCL), the K leading
+left singular vectors are formed by the deflation's projection kernel, QR per dimension is
+CholeskyQR2, and each DEIM step's residual GEMV + arg-max runs on the shard.
+Host work, by design: the F x F symmetric eigen-solve (LAPACK ``eigh``) and DEIM's k x k
+interpolation solves (``numpy.linalg.lstsq`` -- the very routine the reference calls at
+constraintsComponents.py:829, so the coefficients match it).
+
+Other basis types of the reference (``pod`` per-(p,d) torch SVD, ``pca_blocks``,
+``pca_blocks_with_St``, geometric / block DEIM, polyscope views) are out of scope
+ and raise ``NotImplementedError``.
+"""
+import csv
+import os
+import sys
+
+import numpy as np
+
+from .distributed import Comm
+from .engine import HipEngine
+from .utils import log_time, testSparsity, test_linear_dependency
+
+constProj_output_directory = ""
+
+
+class nonlinearSnapshots:
+    """Constraint-projection snapshots: F frames of (e*p, 3) (nonlinear_snapshots.py:17-53)."""
+
+    def __init__(self, param, *, frames=None, test_frames=None, engine=None, comm=None, mass=None):
+        self.snapshots_file = ""
+        self.rest_shape = ""
+        self.dim = 0
+        self.mass_file = ""
+        self.frs = 0
+        self.constraintsSize = 0
+        self.num_constained_elements = 0
+        self.mean = None
+        self.pre_scale_factor = 1
+        self.mass = None
+        self.massL = None
+        self.invMassL = None
+        self._snapTensor = None
+        self.test_snapTensor = None
+        self.param = param
+        self._frames, self._test_frames, self._preset_mass = frames, test_frames, mass
+        self._engine, self._comm = engine, comm if comm is not None else Comm()
+        self._shards = None
+
+    # the prepared tensor lives on the device; (F, ep, 3) on read
+    @property
+    def snapTensor(self):
+        if self._snapTensor is None and self._engine is not None and self._engine.n_loc:
+            loc = self._engine.download_snapshots()
+            self._snapTensor = self._comm.all_gather_rows(loc, self.frames_rows, axis=1)
+        return self._snapTensor
+
+    @snapTensor.setter
+    def snapTensor(self, v):
+        self._snapTensor = v
+
+    def config(self):
+        """nonlinear_snapshots.py:55-71."""
+        global constProj_output_directory
+        p = self.param
+        self.snapshots_file = getattr(p, "constProj_input_snapshots_pattern", "")
+        self.rest_shape = p.constProj_rest_shape
+        self.dim = getattr(p, "constProj_dim", 3)
+        self.mass_file = getattr(p, "constProj_masses_file", "")
+        self.frs = p.constProj_numFrames
+        self.constraintsSize = p.constProj_p_size
+        self.ele_type = getattr(p, "constProj_element_type", "")
+        constProj_output_directory = getattr(p, "constProj_output_directory", "")
+
+    @log_time(constProj_output_directory)
+    def snapshots_prepare(self):
+        """nonlinear_snapshots.py:74-96: read, optional sqrt-mass weighting, standardise -- on the GPU."""
+        X = self.read()
+        if self._engine is None:
+            dev, stream = 0, None
+            if self._comm.world > 1:
+                import torch
+                dev, stream = torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream
+            self._engine = HipEngine(dev, stream)
+        eng, comm = self._engine, self._comm
+        self.frames_rows = X.shape[1]
+        massL = None
+        if self.param.constProj_massWeight:
+            self.load_factorize_masses()
+            assert X.shape[1] == self.massL.shape[0]
+            massL = self.massL
+        v0, n_loc = comm.my_shard(X.shape[1])
+        self._shards = comm.shards(X.shape[1])
+        eng.upload(X, v0, n_loc, massL)
+        if self.param.constProj_standarize:
+            self.standarize()
+        print('nonlinearSnapshots ready ... Volkwein (' + str(self.param.constProj_massWeight) + '), standarized (' +
+              str(self.param.constProj_standarize) + ').')
+
+    @log_time(constProj_output_directory)
+    def read(self, file_type=".npz"):
+        """nonlinear_snapshots.py:99-173 ('.npz' keyed by the frame number; per-frame '.bin' files are the
+        PD recorder's other format and out of scope)."""
+        p = self.param
+        if self._frames is not None:
+            X = np.asarray(self._frames, dtype=np.float64)
+            self.test_snapTensor = self._test_frames
+        else:
+            if file_type != ".npz":
+                raise NotImplementedError("only the .npz snapshot container is supported")
+            data = np.load(self.snapshots_file, allow_pickle=True)
+            inc = p.constProj_frame_increment
+            X = np.stack([data[str(i)] for i in range(0, self.frs * inc, inc)]).astype(np.float64)
+            jump = getattr(p, "constProj_train_test_jump", None)
+            if jump:
+                self.test_snapTensor = np.stack([data[str(j)] for j in range(jump, self.frs * inc, inc)])
+        self.frs = X.shape[0]
+        self.num_constained_elements = X.shape[1] // self.constraintsSize
+        print("loaded snapshots size", X.shape)
+        print("No. constrained verts: ", self.num_constained_elements)
+        return X
+
+    def load_factorize_masses(self):
+        """nonlinear_snapshots.py:178-265 builds per-row masses from vertex masses and the element type with
+        libigl (absent here); this build takes the per-row mass vector directly (``mass=`` / a .npy file).
+        massL = sqrt(mass), invMassL = 1 / massL (:259-262 for a diagonal matrix)."""
+        m = self._preset_mass
+        if m is None:
+            if not self.mass_file or not os.path.exists(self.mass_file):
+                raise NotImplementedError("element masses from the mesh need libigl (out of scope); pass mass=")
+            m = np.load(self.mass_file)
+        self.mass = np.asarray(m, dtype=np.float64)
+        self.massL = np.sqrt(self.mass)
+        self.invMassL = 1.0 / self.massL
+
+    def standarize(self):
+        """nonlinear_snapshots.py:268-288."""
+        eng, comm = self._engine, self._comm
+        if self.rest_shape not in ("first", "average"):
+            print('Error! unknown rest shape: ', self.rest_shape)
+            sys.exit(1)
+        local_sum = eng.center(0 if self.rest_shape == "first" else 1, True)
+        self.mean = comm.all_gather_rows(eng.get_mean(), self.frames_rows, axis=0)
+        count = float(self.frs) * float(self.frames_rows) * 3.0
+        mu = comm.allreduce_sum(local_sum)[0] / count
+        var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
+        self.pre_scale_factor = 1 / np.sqrt(var)
+        eng.scale(self.pre_scale_factor)
+        self._snapTensor = None
+
+
+class constraintsComponents:  # Components == bases
+    def __init__(self, param, nonlinear_snapshots=None):
+        global constProj_output_directory
+        constProj_output_directory = getattr(param, "constProj_output_directory", "")
+        self.basesType = ""
+        self.numComp = 0
+        self.support = ""
+        self.storeSingVal = False
+        self.nonlinearSnapshots = nonlinear_snapshots if nonlinear_snapshots is not None else nonlinearSnapshots(param)
+        self.param = param
+        self._comps = None
+        self._comps_on_device = False
+        self.weigs = None
+        self.fileNameBases = ""
+        self.fileName_geom_points = ""
+        self.file_name_sing = ""
+        self.geom_interpol_verts = []
+        self.geom_alpha = None
+        self.geom_alpha_ranges = None
+        self.geom_Pt = None
+        self.St = None
+        self.singular_values = None
+
+    @property
+    def comps(self):
+        if self._comps is None and self._comps_on_device:
+            ns = self.nonlinearSnapshots
+            loc = ns._engine.results_comps()
+            self._comps = ns._comm.all_gather_rows(loc, ns.frames_rows, axis=1)
+        return self._comps
+
+    @comps.setter
+    def comps(self, v):
+        self._comps = v
+        self._comps_on_device = False
+
+    def config(self, fileNameBases="p_nl_", fileName_geom_points="p_nl_interpol_points_",
+               file_name_sing="_constrprojBases_pcaExtraction_singValues"):
+        """constraintsComponents.py:61-74 (the weighted S^T operator is only read when configured: it feeds
+        the out-of-scope 'with_St' variants)."""
+        p = self.param
+        self.basesType = getattr(p, "constProj_bases_interpolation_type", "")
+        self.support = getattr(p, "constProj_support", "global")
+        self.storeSingVal = getattr(p, "constProj_store_sing_val", False)
+        self.fileNameBases = fileNameBases
+        self.fileName_geom_points = fileName_geom_points
+        self.file_name_sing = file_name_sing
+
+    @log_time(constProj_output_directory)
+    def compute_components_store_singvalues(self):
+        """constraintsComponents.py:108-153."""
+        p = self.param
+        kind = p.constProj_basis_type
+        if kind != "pod_vectorized":
+            if kind in ("pod", "pca_blocks", "pca_blocks_with_St"):
+                raise NotImplementedError("constProj_basis_type %r is out of scope of this build (SURVEY.md section 2 #3); "
+                                          "only 'pod_vectorized' runs on the GPU" % kind)
+            raise ValueError("Uknown basis type: ", kind)
+        headerSing = ['component', 'singVal']
+        file_name = os.path.join(p.constProj_output_directory, p.name + "_" + p.constProj_name + self.file_name_sing)
+        rank0 = self.nonlinearSnapshots._comm.rank == 0
+        if self.storeSingVal and rank0:
+            with open(file_name + '.csv', 'w', encoding='UTF8') as singFile:
+                writer = csv.writer(singFile)
+                writer.writerow(headerSing)
+                self.compute_pod_for_vectorized_nonlinear_snapshots_tensor(writer)
+        else:
+            self.compute_pod_for_vectorized_nonlinear_snapshots_tensor(None)
+
+    @log_time(constProj_output_directory)
+    def compute_pod_for_vectorized_nonlinear_snapshots_tensor(self, writer=None):
+        """constraintsComponents.py:298-320: svd(A), A = R.reshape(F,-1).T (3ep x F), through the Gram matrix."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        F = ns.frs
+        if comm.world > 1:
+            Gbuf = comm.new_buffer(F * F, eng.device_exchange)
+            eng.pod_gram(Gbuf.data_ptr(), to_host=False)
+            comm.allreduce_tensor(Gbuf)                      # partial Gram matrices: RCCL all-reduce
+            G = Gbuf.cpu().numpy().reshape(F, F)
+        else:
+            G = eng.pod_gram()
+        G = 0.5 * (G + G.T)
+        lam, V = np.linalg.eigh(G)                           # host LAPACK on F x F; ascending
+        lam, V = lam[::-1], V[:, ::-1]
+        S = np.sqrt(np.maximum(lam, 0.0))
+        self.singular_values = S
+        if writer is not None:
+            for ai, bi in zip(range(1, S.shape[0] + 1), S):
+                writer.writerow([ai, bi])
+        K = min(int(self.param.deim_desired_num_components), F)
+        eng.pod_basis(np.ascontiguousarray(V[:, :K]), S[:K])
+        self._comps, self._comps_on_device = None, True
+        self.numComp = K
+
+    @log_time(constProj_output_directory)
+    def post_process_components(self):
+        """constraintsComponents.py:415-446."""
+        p = self.param
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        v0, n_loc = ns._shards[comm.rank]
+        if not self._comps_on_device:
+            eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))
+            self._comps_on_device = True
+        if p.constProj_standarize:
+            eng.components_post(True, ns.pre_scale_factor, None)
+            eng.snapshots_affine(1.0 / ns.pre_scale_factor, True, None)        # also restore the snapshots (:424-428)
+            ns._snapTensor = None
+        if p.constProj_orthogonal:
+            for _ in range(2):                                                 # CholeskyQR2
+                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.world > 1 else None
+                eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+                if Gbuf is not None:
+                    comm.allreduce_tensor(Gbuf)
+                eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+        if p.constProj_massWeight:
+            assert ns.frames_rows == ns.invMassL.shape[0]
+            eng.components_post(False, 1.0, ns.invMassL[v0:v0 + n_loc])
+            eng.snapshots_affine(1.0, False, ns.invMassL[v0:v0 + n_loc])
+            ns._snapTensor = None
+        self._comps = None
+        print("Post-processing, Undo standardization: ", p.constProj_standarize, ". Orthogonal-ized",
+              p.constProj_orthogonal, ". Mass weighting", p.constProj_massWeight, ", and bases shape",
+              (self.numComp, ns.frames_rows, 3))
+
+    def deim(self):
+        """constraintsComponents.py:797-860.  Residual GEMV + arg-max on the GPU shard(s); the k x k
+        interpolation solves on the host with ``np.linalg.lstsq`` exactly as the reference (:829)."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        p_size = ns.constraintsSize
+        K = self.numComp
+        test_linear_dependency(self.comps.swapaxes(0, 1), 3, K)
+        rows = np.zeros((K, K, 3))          # rows[m, j, i] = V[Pt[m], j, i]
+        Pt, e_points, e_range = [], [], []
+        for k in range(K):
+            coef = None
+            if k > 0:
+                coef = np.empty((3, k))
+                for i in range(3):
+                    coef[i] = np.linalg.lstsq(rows[:k, :k, i], rows[:k, k, i], rcond=None)[0]
+            idx, val = eng.deim_step(k, coef)
+            if comm.world > 1:
+                idx = int(comm.global_argmax(np.array([idx]), np.array([val]))[0])
+                val = float(comm.allreduce_max(val)[0])
+            if k > 0 and not val > 0.0:
+                print("ERROR!: zero residual!!")
+                return
+            row = eng.deim_row(idx)
+            if comm.world > 1:
+                row = comm.allreduce_sum(np.zeros((K, 3)) if row is None else row).reshape(K, 3)
+            rows[k] = row
+            alpha = idx // p_size
+            print(k, alpha)
+            Pt.append(idx)
+            e_points.append(alpha)
+            e_range.append(k + 1)
+        self.geom_Pt = np.array(Pt)
+        self.geom_alpha = np.array(e_points)
+        self.geom_alpha_ranges = np.array(e_range)
+        self.geom_interpol_verts = np.array(self.geom_interpol_verts)
+        print("Regular Deim interpolation, used", self.geom_alpha.shape[0], "constrained elements")
+
+    @log_time(constProj_output_directory)
+    def store_components_n_interpol_points(self):
+        """constraintsComponents.py:596-613: the .npz the PD simulator loads (Simulators.py:179-188)."""
+        print('Storing bases and interpolation points to one file ...', end='', flush=True)
+        data = {"components": self.comps, "interpol_alphas": self.geom_alpha, "Pt": self.geom_Pt,
+                "interpol_verts": self.geom_interpol_verts, "interpol_alpha_ranges": self.geom_alpha_ranges}
+        np.savez(os.path.join(self.param.constProj_output_directory,
+                              "components_interpol_alphas_interpol_verts_interpol_alpha_ranges.npz"), **data)
+        print("done!")

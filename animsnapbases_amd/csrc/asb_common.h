@@ -98,6 +98,7 @@ struct asb_ctx {
     double* ovec = nullptr;       // (3, K, K) eigenvectors
     double* osing = nullptr;      // (3, K) singular values
     double* la_vtmp = nullptr;
+    double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
 
     // ---- profiling of the dominant streaming kernel ----

@@ -326,3 +326,11 @@ extern "C" int asb_components_upload(asb_ctx* ctx, const double* comps_host, int
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }
+
+extern "C" int asb_components_download(asb_ctx* ctx, double* comps_out) {
+    if (!ctx || !ctx->comps || !comps_out) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipMemcpyAsync(comps_out, ctx->comps, (size_t)ctx->K * 3 * ctx->n_loc * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}

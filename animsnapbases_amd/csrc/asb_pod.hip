@@ -1,0 +1,221 @@
+// Constraint-projection bases (config 5): Gram-form POD, CholeskyQR2, and the device half of
+// DEIM -- constraintsComponents.compute_pod_for_vectorized_nonlinear_snapshots_tensor
+// (snapbases/constraintsComponents.py:298-320), post_process_components (:415-446) and deim
+// (:797-860) of the reference.  gfx950 only.
+//
+// POD: the reference takes the SVD of A = (3ep x F).  Here G = A^T A (F x F) is accumulated with
+// f64 MFMA over the row shard (all-reduced over ranks by the caller), its eigen-pairs give S and V
+// (host LAPACK for the F x F problem -- the O(3ep F^2) work is on the device), and the K leading
+// left vectors are U_K = A V_K S_K^-1, 16 columns per pass over A with the deflation's projection
+// kernel.  Rows r = 3e + d are exactly the (F, ep, 3) -> (3ep, F) reshape of the reference.
+#include "asb_kernels.h"
+
+int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows,
+                        const double* col_scale);
+
+// G = X^T X over this shard's rows (F x F) into G_dev (caller's device buffer, to be all-reduced) or
+// G_host (single rank convenience; synchronises)
+extern "C" int asb_pod_gram(asb_ctx* ctx, double* G_dev, double* G_host) {
+    if (!ctx || !ctx->X) return ASB_ERR_ARG;
+    const int64_t F = ctx->F;
+    int rc;
+    double* G = G_dev;
+    if (!G) {
+        if ((rc = asb_alloc(ctx, &ctx->pod_g, (size_t)F * F))) return rc;
+        G = ctx->pod_g;
+    }
+    if ((rc = asb_gemm_tn(ctx, ctx->X, ctx->Fp, ctx->X, ctx->Fp, 3 * ctx->n_loc, (int)F, (int)F, G))) return rc;
+    if (G_host) {
+        ASB_HIP(ctx, hipMemcpyAsync(G_host, G, (size_t)F * F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ASB_OK;
+}
+
+// comps[i] = X . V[:, i] / sigma[i]   for i < K   (V host (F x K) row-major, sigma host (K))
+extern "C" int asb_pod_basis(asb_ctx* ctx, const double* V, const double* sigma, int64_t K) {
+    if (!ctx || !ctx->X || !V || !sigma || K < 1) return ASB_ERR_ARG;
+    const int64_t F = ctx->F, n3 = 3 * ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_v, (size_t)F * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_s, (size_t)K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+    ctx->K = K;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->pod_v, V, (size_t)F * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->pod_s, sigma, (size_t)K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    for (int64_t k0 = 0; k0 < K; k0 += 16) {
+        const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
+        if ((rc = asb_project_columns(ctx, ctx->pod_v, K, k0, nc, ctx->comps + (size_t)k0 * n3, ctx->pod_s))) return rc;
+    }
+    return ASB_OK;
+}
+
+// X <- (X * inv_scale + mean) * rowscale     (:421-428, :440-443: the reference also restores
+// nonlinearSnapshots.snapTensor); rowscale host (n_loc) or NULL
+__global__ __launch_bounds__(256) void k_affine_rows(double* __restrict__ X, long long nrows, int F, int Fp, double inv_scale,
+                                                     const double* __restrict__ mean, const double* __restrict__ rowscale) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (long long r = (long long)blockIdx.x * 4 + wid; r < nrows; r += (long long)gridDim.x * 4) {
+        double* row = X + r * Fp;
+        const double m = mean ? mean[r] : 0.0, rs = rowscale ? rowscale[r / 3] : 1.0;
+        for (int f = lane; f < F; f += 64) row[f] = (row[f] * inv_scale + m) * rs;
+    }
+}
+
+extern "C" int asb_snapshots_affine(asb_ctx* ctx, double inv_scale, int add_mean, const double* rowscale) {
+    if (!ctx || !ctx->X) return ASB_ERR_ARG;
+    if (add_mean && !ctx->have_mean) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_snapshots_affine: no mean on the device");
+    const double* rs = nullptr;
+    int rc;
+    if (rowscale) {
+        if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->s_dev, rowscale, (size_t)ctx->n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        rs = ctx->s_dev;
+    }
+    long long want = (ctx->n_loc * 3 + 3) / 4;
+    const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_affine_rows, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc * 3, (int)ctx->F,
+                       (int)ctx->Fp, inv_scale, add_mean ? ctx->mean : nullptr, rs);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// CholeskyQR: Tt[k][j] = (L^-1)[j][k] with G = L L^T, so that Q = A L^-T = A . Tt   (one block, K <= 128)
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_tinv(const double* __restrict__ G, int K, double* __restrict__ Tt,
+                                                   int* __restrict__ status) {
+    extern __shared__ double L[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < K * K; e += nt) L[e] = G[e];
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        const double d = L[j * K + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) status[0] = 1;
+            return;
+        }
+        const double sq = sqrt(d);
+        __syncthreads();
+        for (int i = j + tid; i < K; i += nt) L[i * K + j] = (i == j) ? sq : L[i * K + j] / sq;
+        __syncthreads();
+        for (int e = tid; e < (K - j - 1) * (K - j - 1); e += nt) {
+            const int i = j + 1 + e / (K - j - 1), c = j + 1 + e % (K - j - 1);
+            if (c <= i) L[i * K + c] -= L[i * K + j] * L[c * K + j];
+        }
+        __syncthreads();
+    }
+    // column c of T = L^-1 by forward substitution: T[i][c] for i >= c
+    for (int c = tid; c < K; c += nt) {
+        for (int i = 0; i < K; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int j = c; j < i; ++j) s -= L[i * K + j] * Tt[(long long)c * K + j];      // Tt[c][j] = T[j][c]
+            Tt[(long long)c * K + i] = (i < c) ? 0.0 : s / L[i * K + i];
+        }
+    }
+}
+
+// one CholeskyQR pass per dimension with the (all-reduced) Gram matrices of asb_orth_gram:
+// comps[:,:,l] <- (A_l L^-T)^T.  Call twice (Gram, apply, Gram, apply) for CholeskyQR2.
+extern "C" int asb_qr_apply(asb_ctx* ctx, const double* G_dev) {
+    if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, n = ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
+    if (G_dev) ASB_HIP(ctx, hipMemcpyAsync(ctx->og, G_dev, (size_t)3 * K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+    const size_t lds = (size_t)K * K * sizeof(double);
+    if (lds > 48 * 1024) ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_chol_tinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int l = 0; l < 3; ++l) {
+        double* Tt = ctx->ovec + (size_t)l * K * K;
+        hipLaunchKernelGGL(k_chol_tinv, dim3(1), dim3(256), lds, ctx->stream, ctx->og + (size_t)l * K * K, (int)K, Tt, ctx->la_status);
+        ASB_CHECK_LAUNCH(ctx);
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, Tt, K, K, (int)n, (int)K, ctx->comps2 + l, 3, 3 * n))) return rc;
+    }
+    int st[4];
+    ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st[0]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "QR: a coordinate slice of the basis is rank deficient");
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// DEIM, device half (:820-836): r[e,i] = sum_{j<k} coef[i][j] V[e,j,i] - V[e,k,i],  idx = argmax_e sum_i r^2.
+// V[e,j,i] = comps[j][3e+i].  The k x k interpolation solves stay on the host (numpy lstsq, the
+// routine the reference calls), fed by asb_deim_row.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict__ comps, long long n_vert, int k,
+                                                       const double* __restrict__ coef, long long v0,
+                                                       double* __restrict__ pmax, long long* __restrict__ pidx) {
+    extern __shared__ double cf[];          // 3 * k
+    __shared__ double sh_d[256];
+    __shared__ long long sh_i[256];
+    for (int q = threadIdx.x; q < 3 * k; q += blockDim.x) cf[q] = coef[q];
+    __syncthreads();
+    const long long stride = 3 * n_vert;
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_vert; e += (long long)gridDim.x * blockDim.x) {
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        for (int j = 0; j < k; ++j) {
+            const double* p = comps + (long long)j * stride + 3 * e;
+            r0 += cf[j] * p[0]; r1 += cf[k + j] * p[1]; r2 += cf[2 * k + j] * p[2];
+        }
+        const double* q = comps + (long long)k * stride + 3 * e;
+        r0 -= q[0]; r1 -= q[1]; r2 -= q[2];
+        const double en = r0 * r0 + r1 * r1 + r2 * r2;
+        if (am_better(en, e, be, bi)) { be = en; bi = e; }
+    }
+    sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o && am_better(sh_d[threadIdx.x + o], sh_i[threadIdx.x + o], sh_d[threadIdx.x], sh_i[threadIdx.x])) {
+            sh_d[threadIdx.x] = sh_d[threadIdx.x + o];
+            sh_i[threadIdx.x] = sh_i[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = v0 + sh_i[0]; }
+}
+
+// shard arg-max of the DEIM residual of basis vector k given the interpolation coefficients
+// coef (host, 3 x k; NULL for k = 0); returns the global row index and its residual energy.
+extern "C" int asb_deim_step(asb_ctx* ctx, int64_t k, const double* coef, int64_t* idx_out, double* val_out) {
+    if (!ctx || !ctx->comps || k < 0 || k >= ctx->K || !idx_out) return ASB_ERR_ARG;
+    if (k > 0 && !coef) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_coef, (size_t)3 * ctx->K))) return rc;
+    if (k > 0) ASB_HIP(ctx, hipMemcpyAsync(ctx->pod_coef, coef, (size_t)3 * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    long long want = (ctx->n_loc + 255) / 256;
+    const int grid = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(k_deim_residual, dim3(grid), dim3(256), (size_t)(3 * k + 1) * sizeof(double), ctx->stream, ctx->comps,
+                       (long long)ctx->n_loc, (int)k, ctx->pod_coef, (long long)ctx->v0, ctx->pmax, ctx->pidx);
+    ASB_CHECK_LAUNCH(ctx);
+    std::vector<double> hm(grid);
+    std::vector<long long> hi(grid);
+    ASB_HIP(ctx, hipMemcpyAsync(hm.data(), ctx->pmax, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(hi.data(), ctx->pidx, grid * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int b = 0; b < grid; ++b)
+        if (hm[b] > be || (hm[b] == be && hi[b] < bi)) { be = hm[b]; bi = hi[b]; }
+    *idx_out = bi;
+    if (val_out) *val_out = be;
+    return ASB_OK;
+}
+
+// row_out (K, 3): V[gidx, :, :] = comps[:, 3*(gidx - v0) + i]  (only on the rank that owns gidx; others get rc 1)
+extern "C" int asb_deim_row(asb_ctx* ctx, int64_t gidx, double* row_out) {
+    if (!ctx || !ctx->comps || !row_out) return ASB_ERR_ARG;
+    if (gidx < ctx->v0 || gidx >= ctx->v0 + ctx->n_loc) return 1;
+    const long long e = gidx - ctx->v0;
+    ASB_HIP(ctx, hipMemcpy2DAsync(row_out, 3 * sizeof(double), ctx->comps + 3 * e, (size_t)3 * ctx->n_loc * sizeof(double),
+                                  3 * sizeof(double), (size_t)ctx->K, hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NWV * 64) void k_project_mfma(
 // B-operand panel from a frame-major (F x ldw) matrix: columns k0 .. k0+ncols-1, unit norms
 __global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ Wfk, long long ldw, long long k0,
                                                      int ncols, int F, int Fp, double* __restrict__ Wt,
-                                                     double* __restrict__ wn2) {
+                                                     double* __restrict__ wn2, const double* __restrict__ col_scale) {
     const long long total = (long long)Fp * ASB_PANEL_COLS;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ 
         const long long f = i / ASB_PANEL_COLS;
         Wt[i] = (t < ncols && f < F) ? Wfk[f * ldw + k0 + t] : 0.0;
     }
-    if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS) wn2[threadIdx.x] = 1.0;
+    if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS)
+        wn2[threadIdx.x] = (col_scale && (int)threadIdx.x < ncols) ? col_scale[k0 + threadIdx.x] : 1.0;
 }
 
 // --------------------------------------------------------------------------------------
@@ -737,13 +738,15 @@ static void launch_project(asb_ctx* ctx, int ncols, double* out) {
     (void)prof_end(ctx, slot);
 }
 
-// out_rows (ncols, 3 n_loc) = X . Wfk[:, k0:k0+ncols]   (raw products, used for c = W^T X of SPLOCS)
-int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows) {
+// out_rows (ncols, 3 n_loc) = X . Wfk[:, k0:k0+ncols] / col_scale[k0 + t]   (col_scale NULL: raw products;
+// used for c = W^T X of SPLOCS and for the POD back-projection U = A V S^-1)
+int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows,
+                        const double* col_scale) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->Wt, (size_t)ctx->Fp * ASB_PANEL_COLS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->wn2t, (size_t)ASB_PANEL_COLS))) return rc;
     hipLaunchKernelGGL(k_build_wt_fk, dim3(64), dim3(256), 0, ctx->stream, Wfk, (long long)ldw, (long long)k0, ncols,
-                       (int)ctx->F, (int)ctx->Fp, ctx->Wt, ctx->wn2t);
+                       (int)ctx->F, (int)ctx->Fp, ctx->Wt, ctx->wn2t, col_scale);
     launch_project(ctx, ncols, out_rows);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;

@@ -15,7 +15,8 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // defined in asb_project.hip
-int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows);
+int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows,
+                        const double* col_scale);
 
 // --------------------------------------------------------------------------------------
 // k_bcd: the block-coordinate-descent sweep over the K weight columns (:144-156), one block.
@@ -290,7 +291,7 @@ extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, i
     // c = W^T X  (K x 3n): the deflation's projection kernel, 16 columns per pass over X
     for (int64_t k0 = 0; k0 < K; k0 += 16) {
         const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
-        int rc = asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3);
+        int rc = asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3, nullptr);
         if (rc) return rc;
     }
     ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));

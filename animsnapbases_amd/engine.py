@@ -247,6 +247,48 @@ class HipEngine(object):
         return C, W
 
     # ------------------------------------------------------------------ post-processing
+    # ------------------------------------------------------------------ POD / QR / DEIM (config 5)
+    def pod_gram(self, G_dev_ptr=None, to_host=True):
+        G = np.empty((self.F, self.F)) if to_host else None
+        self._ck(self.lib.asb_pod_gram(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None, ptr(G)))
+        return G
+
+    def pod_basis(self, V, sigma):
+        V = np.ascontiguousarray(V, dtype=np.float64)
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        assert V.shape == (self.F, sigma.shape[0])
+        self._ck(self.lib.asb_pod_basis(self.h, ptr(V), ptr(sigma), sigma.shape[0]))
+        self.K = int(sigma.shape[0])
+
+    def snapshots_affine(self, inv_scale, add_mean, rowscale_loc=None):
+        if rowscale_loc is not None:
+            rowscale_loc = np.ascontiguousarray(rowscale_loc, dtype=np.float64)
+        self._ck(self.lib.asb_snapshots_affine(self.h, float(inv_scale), int(bool(add_mean)), ptr(rowscale_loc)))
+
+    def qr_apply(self, G_dev_ptr=None):
+        self._ck(self.lib.asb_qr_apply(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
+
+    def deim_step(self, k, coef=None):
+        if coef is not None:
+            coef = np.ascontiguousarray(coef, dtype=np.float64)
+            assert coef.shape == (3, k)
+        i, v = ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_deim_step(self.h, int(k), ptr(coef), ctypes.byref(i), ctypes.byref(v)))
+        return i.value, v.value
+
+    def deim_row(self, gidx):
+        row = np.empty((self.K, 3))
+        rc = self.lib.asb_deim_row(self.h, int(gidx), ptr(row))
+        if rc == 1:
+            return None
+        self._ck(rc)
+        return row
+
+    def results_comps(self):
+        out = np.empty((self.K, self.n_loc, 3))
+        self._ck(self.lib.asb_components_download(self.h, ptr(out)))
+        return out
+
     def components_upload(self, comps_loc):
         comps_loc = np.ascontiguousarray(comps_loc, dtype=np.float64)
         assert comps_loc.ndim == 3 and comps_loc.shape[1:] == (self.n_loc, 3)

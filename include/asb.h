@@ -172,8 +172,31 @@ int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
  * Fails with ASB_ERR_NUMERIC when a slice is rank deficient (orth would drop vectors). */
 int asb_orth_gram(asb_ctx* ctx, double* G_dev);
 int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out);
+/* the device-resident basis (K, n_loc, 3) to the host */
+int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
 int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
+
+/* ------------------------------------------------ constraint-projection bases (config 5) ---- */
+/* compute_pod_for_vectorized_nonlinear_snapshots_tensor, snapbases/constraintsComponents.py:298-320:
+ * the reference takes svd(A), A = (3ep x F).  asb_pod_gram: G = A^T A (F x F) of this shard (f64 MFMA)
+ * into G_dev (caller's device buffer, all-reduced over ranks by the caller) and/or G_host.
+ * The F x F eigen-problem is solved by the caller (LAPACK); asb_pod_basis then forms the K leading left
+ * vectors  comps[i] = A V[:, i] / sigma[i]  (V host F x K, sigma host K) as the device-resident basis. */
+int asb_pod_gram(asb_ctx* ctx, double* G_dev, double* G_host);
+int asb_pod_basis(asb_ctx* ctx, const double* V, const double* sigma, int64_t K);
+/* :421-428 / :440-443 the reference also restores the snapshot tensor:
+ * X <- (X * inv_scale + mean) * rowscale[v]   (rowscale host n_loc or NULL) */
+int asb_snapshots_affine(asb_ctx* ctx, double inv_scale, int add_mean, const double* rowscale);
+/* :430-433 `qr(comps[:,:,l].T, mode='economic')[0].T`: one CholeskyQR pass per dimension with the
+ * Gram matrices of asb_orth_gram (NULL: the context's).  Call gram/apply twice (CholeskyQR2). K <= 128. */
+int asb_qr_apply(asb_ctx* ctx, const double* G_dev);
+/* deim, :797-860, device half: residual r = V[:, :k] coef - v_k per dimension and its arg-max over this
+ * shard (global row index).  coef: host (3, k), NULL for k = 0.  The k x k interpolation solves stay with
+ * the caller (numpy lstsq, as in the reference :829), fed by asb_deim_row. */
+int asb_deim_step(asb_ctx* ctx, int64_t k, const double* coef, int64_t* idx_out, double* val_out);
+/* V[gidx, :, :] -> row_out (K, 3); returns 1 (and writes nothing) when another rank owns gidx */
+int asb_deim_row(asb_ctx* ctx, int64_t gidx, double* row_out);
 
 /* ------------------------------------------------ SPLOCS refinement ----------- */
 /* posComponents.splocs_glob_optimization, snapbases/posComponents.py:132-189.

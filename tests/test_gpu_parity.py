@@ -419,3 +419,85 @@ def test_orthogonal_vs_oracle_local_support():
     assert relerr(got, ref) < 1e-7
     for l in range(3):
         assert np.allclose(comp.comps[:, :, l] @ comp.comps[:, :, l].T, np.eye(K), atol=1e-10)
+
+
+def _cparam(K, orth, tmp, std=True):
+    return types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=0, constProj_p_size=1,
+                                 constProj_massWeight=False, constProj_standarize=std, constProj_orthogonal=orth,
+                                 constProj_basis_type="pod_vectorized", deim_desired_num_components=K,
+                                 constProj_store_sing_val=True, constProj_output_directory=str(tmp), name="c5",
+                                 constProj_name="verts")
+
+
+def _run_constraints(frames, K, orth, tmp):
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    param = _cparam(K, orth, tmp)
+    ns = nonlinearSnapshots(param, frames=frames)
+    ns.config()
+    ns.snapshots_prepare()
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.compute_components_store_singvalues()
+    return ns, cc
+
+
+@pytest.mark.parametrize("name", ["pod_deim_small", "pod_deim_small_qr"])
+def test_pod_deim_vs_reference_golden(name, tmp_path):
+    """Config-5 path (standardise -> pod_vectorized -> post-process [-> qr] -> DEIM) against the reference."""
+    g = load_golden(name)
+    K, orth = int(g["K"]), bool(g["orthogonal"])
+    ns, cc = _run_constraints(g["frames"], K, orth, tmp_path)
+    assert relerr(ns.snapTensor, g["snapTensor"]) < 1e-12
+    S = cc.singular_values
+    big = g["S"] > 1e-6 * g["S"][0]           # the Gram route resolves sigma down to ~1e-8 sigma_max
+    assert relerr(S[big], g["S"][big]) < 1e-9
+    comps = cc.comps.copy()
+    for k in range(K):                        # singular vectors: arbitrary sign
+        if np.vdot(comps[k], g["comps"][k]) < 0:
+            comps[k] *= -1
+    assert relerr(comps, g["comps"]) < 1e-8
+    lines = open(str(tmp_path / "c5_verts_constrprojBases_pcaExtraction_singValues.csv")).read().splitlines()
+    assert lines[0] == "component,singVal" and len(lines) == 1 + g["frames"].shape[0]
+    # install the reference's signs, post-process, DEIM
+    cc.comps = comps
+    cc.post_process_components()
+    got = _slice_signs(cc.comps, g["comps_post"]) if orth else cc.comps
+    assert relerr(got, g["comps_post"]) < 1e-8
+    assert relerr(ns.snapTensor, g["snapTensor_post"]) < 1e-12
+    if orth:
+        cc.comps = got                        # DEIM depends on the column signs only through r -> |r|^2: unaffected,
+    cc._comps_on_device or cc.post_process_components   # (no-op guard)
+    if orth:
+        ns._engine.components_upload(np.ascontiguousarray(got))
+        cc._comps, cc._comps_on_device = got, True
+    cc.deim()
+    assert cc.geom_Pt.tolist() == g["Pt"].tolist()
+    assert cc.geom_alpha.tolist() == g["alpha"].tolist()
+    assert cc.geom_alpha_ranges.tolist() == g["alpha_ranges"].tolist()
+    cc.store_components_n_interpol_points()
+    z = np.load(str(tmp_path / "components_interpol_alphas_interpol_verts_interpol_alpha_ranges.npz"))
+    assert sorted(z.files) == sorted(["components", "interpol_alphas", "Pt", "interpol_verts", "interpol_alpha_ranges"])
+
+
+def test_pod_deim_vs_oracle_medium(tmp_path):
+    rng = np.random.default_rng(17)
+    ep, F, K = 3000, 96, 24
+    modes = rng.normal(size=(30, ep, 3))
+    coef = rng.normal(size=(F, 30)) * (0.75 ** np.arange(30))[None]
+    frames = 0.2 + np.tensordot(coef, modes, (1, 0)) + 1e-6 * rng.normal(size=(F, ep, 3))
+    ns, cc = _run_constraints(frames, K, False, tmp_path)
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    pod = orc.pod_vectorized(pre["snapTensor"], K)
+    assert relerr(cc.singular_values[:K], pod["S"][:K]) < 1e-10
+    comps = cc.comps.copy()
+    for k in range(K):
+        if np.vdot(comps[k], pod["comps"][k]) < 0:
+            comps[k] *= -1
+    assert relerr(comps, pod["comps"]) < 1e-7
+    cc.comps = comps
+    cc.post_process_components()
+    post, _ = orc.post_process_constraint_components(pod["comps"], pre["snapTensor"], pre["pre_scale_factor"], pre["mean"])
+    assert relerr(cc.comps, post) < 1e-7
+    cc.deim()
+    dm = orc.deim(post, 1)
+    assert cc.geom_Pt.tolist() == dm["Pt"].tolist()
