@@ -464,10 +464,7 @@ def test_pod_deim_vs_reference_golden(name, tmp_path):
     got = _slice_signs(cc.comps, g["comps_post"]) if orth else cc.comps
     assert relerr(got, g["comps_post"]) < 1e-8
     assert relerr(ns.snapTensor, g["snapTensor_post"]) < 1e-12
-    if orth:
-        cc.comps = got                        # DEIM depends on the column signs only through r -> |r|^2: unaffected,
-    cc._comps_on_device or cc.post_process_components   # (no-op guard)
-    if orth:
+    if orth:        # install the reference's column signs before DEIM (the residuals depend on them)
         ns._engine.components_upload(np.ascontiguousarray(got))
         cc._comps, cc._comps_on_device = got, True
     cc.deim()
@@ -501,3 +498,38 @@ def test_pod_deim_vs_oracle_medium(tmp_path):
     cc.deim()
     dm = orc.deim(post, 1)
     assert cc.geom_Pt.tolist() == dm["Pt"].tolist()
+
+
+def test_multirank_pod_deim_on_one_gpu(tmp_path):
+    """Config-5 path over 2 row shards on one GPU: Gram all-reduce, sharded back-projection, global DEIM arg-max."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, constraintsComponents, nonlinearSnapshots
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(23)
+    ep, F, K = 1501, 64, 12
+    frames = 0.1 + np.tensordot(rng.normal(size=(F, 20)) * (0.7 ** np.arange(20))[None], rng.normal(size=(20, ep, 3)), (1, 0)) \
+        + 1e-6 * rng.normal(size=(F, ep, 3))
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            param = _cparam(K, True, tmp_path)
+            param.constProj_store_sing_val = False
+            ns = nonlinearSnapshots(param, frames=frames, engine=HipEngine(0, stream=0), comm=comm)
+            ns.config()
+            ns.snapshots_prepare()
+            cc = constraintsComponents(param, ns)
+            cc.config()
+            cc.compute_components_store_singvalues()
+            cc.post_process_components()
+            cc.deim()
+        return cc.singular_values.copy(), cc.comps.copy(), cc.geom_Pt.copy()
+
+    outs = run_ranks(2, rank_fn)
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    pod = orc.pod_vectorized(pre["snapTensor"], K)
+    for S, comps, Pt in outs:
+        assert relerr(S[:K], pod["S"][:K]) < 1e-10
+        for l in range(3):       # orthonormal per dimension after CholeskyQR2
+            assert np.allclose(comps[:, :, l] @ comps[:, :, l].T, np.eye(K), atol=1e-10)
+        assert Pt.tolist() == outs[0][2].tolist() and len(set(Pt.tolist())) == K
