@@ -68,7 +68,8 @@ struct asb_ctx {
     double* wn2t = nullptr;      // (16) |w_t|^2 of the panel
     double* candR = nullptr;     // (m_cap, 3, Fp) exact residual rows of the candidates
     double* cand_e = nullptr;    // (m_cap)
-    double* cand_c = nullptr;    // (m_cap, 3) scratch
+    double* cand_c = nullptr;    // (16, m_cap, 3) in-panel coefficients of the candidates
+    double* slab_scratch = nullptr;
     long long* cand_idx = nullptr;
     double* cpmax = nullptr;     // partial records of passes over the candidate buffer
     long long* cpidx = nullptr;

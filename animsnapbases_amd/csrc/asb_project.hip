@@ -19,6 +19,7 @@
 // HBM traffic: one read of X per PANEL instead of a read + write of R per COMPONENT.
 #include "asb_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -793,6 +794,202 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     return ASB_OK;
 }
 
+// --------------------------------------------------------------------------------------
+// Panel inner loop, read-only form.  The candidate rows stay at their panel-start state R0; because
+// the panel's weights are mutually orthogonal, R_s^(t) . w_t = R0_s . w_t, so one step only needs
+//   k_cand_dots : c_t[s] = R0_s . w_t / |w_t|^2 for every candidate (kept in cand_c), energies
+//                 e_s -= |w_t|^2 |c_t[s]|^2 (relative to the EXACT panel-start energies), arg-max partials
+//   k_pick_panel: the winner's current slab rebuilt explicitly, R0_b - sum_{t'<t} c_t'[b] w_t', then the
+//                 3x3 Gram / Jacobi / w_t exactly as k_pick does
+// -- half the L2 traffic of updating every candidate row, and no dependent write/read of the rows.
+// --------------------------------------------------------------------------------------
+template <int T, int E2>
+__global__ __launch_bounds__((T >= 256 ? T : 256)) void k_cand_dots(
+    const double* __restrict__ R0, const double* __restrict__ wk, const double* __restrict__ scal_k, int t_panel,
+    long long m_cap, double* __restrict__ cand_c, double* __restrict__ energy, double* __restrict__ pmax,
+    long long* __restrict__ pidx, double* __restrict__ psum, int F2, const PanelState* __restrict__ panel) {
+    if (panel->done) return;
+    constexpr int BLOCK = (T >= 256 ? T : 256);
+    constexpr int VPB = BLOCK / T;
+    constexpr int NW = T / 64;
+    const int tid = threadIdx.x, g = tid / T, t = tid % T, wig = t >> 6, lane = tid & 63;
+    __shared__ double red[VPB][NW][3];
+    __shared__ double lead_e[VPB];
+    __shared__ long long lead_i[VPB];
+    const long long n = panel->n_cand;
+    double2 w[E2];
+#pragma unroll
+    for (int i = 0; i < E2; ++i) {
+        const int j = t + i * T;
+        w[i] = (j < F2) ? reinterpret_cast<const double2*>(wk)[j] : make_double2(0.0, 0.0);
+    }
+    const double wn2 = scal_k[1];
+    double bmax = -1.0;
+    long long bidx = 0x7fffffffffffffffLL;
+    for (long long base = (long long)blockIdx.x * VPB; base < n; base += (long long)gridDim.x * VPB) {
+        const long long s = base + g;
+        const bool valid = s < n;
+        const double2* row = reinterpret_cast<const double2*>(R0) + (valid ? s : 0) * 3 * (long long)F2;
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int i = 0; i < E2; ++i) {
+                const int j = t + i * T;
+                const double2 x = (valid && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
+                acc[d] += x.x * w[i].x + x.y * w[i].y;
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[d] = wave_sum(acc[d]);
+        if (NW > 1) {
+            __syncthreads();
+            if (lane == 0) { red[g][wig][0] = acc[0]; red[g][wig][1] = acc[1]; red[g][wig][2] = acc[2]; }
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) sum += red[g][q][d];
+                acc[d] = sum;
+            }
+        }
+        if (t == 0 && valid) {
+            double* c = cand_c + ((long long)t_panel * m_cap + s) * 3;
+            c[0] = acc[0] / wn2; c[1] = acc[1] / wn2; c[2] = acc[2] / wn2;
+            double e = energy[s] - (acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]) / wn2;
+            if (e < 0.0) e = 0.0;
+            energy[s] = e;
+            if (am_better(e, s, bmax, bidx)) { bmax = e; bidx = s; }
+        }
+    }
+    if (t == 0) { lead_e[g] = bmax; lead_i[g] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        double be = lead_e[0];
+        long long bi = lead_i[0];
+#pragma unroll
+        for (int q = 1; q < VPB; ++q)
+            if (am_better(lead_e[q], lead_i[q], be, bi)) { be = lead_e[q]; bi = lead_i[q]; }
+        pmax[blockIdx.x] = be; pidx[blockIdx.x] = bi; psum[blockIdx.x] = 0.0;
+    }
+}
+
+// one block of 1024 threads; thread tid owns frames f = tid + 1024 i (i < 2) of the three rows when
+// Fp <= 2048, otherwise the explicit slab goes through a global scratch row
+#define ASB_PP_T 1024
+#define ASB_PP_E 2
+__global__ __launch_bounds__(ASB_PP_T) void k_pick_panel(const double* __restrict__ R0, const double* __restrict__ cand_c,
+                                                         long long m_cap, const double* pmax, const long long* pidx,
+                                                         int nblk, int F, int Fp, double* __restrict__ W,
+                                                         double* __restrict__ scal, long long k, long long k0,
+                                                         PanelState* __restrict__ panel,
+                                                         const long long* __restrict__ cand_idx,
+                                                         double* __restrict__ scratch) {
+    __shared__ double sh_d[ASB_PP_T];
+    __shared__ long long sh_i[ASB_PP_T];
+    __shared__ double u_sh[4];
+    __shared__ double cprev[16 * 3];
+    if (panel->done) return;
+    const int tid = threadIdx.x;
+    // arg-max over the block partials of the last candidate pass
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int b = tid; b < nblk; b += ASB_PP_T)
+        if (am_better(pmax[b], pidx[b], be, bi)) { be = pmax[b]; bi = pidx[b]; }
+    sh_d[tid] = be; sh_i[tid] = bi;
+    __syncthreads();
+    for (int o = ASB_PP_T / 2; o > 0; o >>= 1) {
+        if (tid < o && am_better(sh_d[tid + o], sh_i[tid + o], sh_d[tid], sh_i[tid])) { sh_d[tid] = sh_d[tid + o]; sh_i[tid] = sh_i[tid + o]; }
+        __syncthreads();
+    }
+    be = sh_d[0]; bi = sh_i[0];
+    __syncthreads();
+    if (!(be > panel->theta + panel->margin) || bi >= panel->n_cand || cand_idx[bi] < 0) {
+        if (tid == 0) panel->done = 1;
+        return;
+    }
+    const int tp = (int)(k - k0);
+    if (tid < tp * 3) cprev[tid] = cand_c[((long long)(tid / 3) * m_cap + bi) * 3 + (tid % 3)];
+    __syncthreads();
+    const double* r0 = R0 + bi * 3 * (long long)Fp;
+    const bool in_regs = Fp <= ASB_PP_T * ASB_PP_E;
+    const int iters = in_regs ? ASB_PP_E : (Fp + ASB_PP_T - 1) / ASB_PP_T;
+    double x[3][ASB_PP_E];
+    double gsum[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int i = 0; i < iters; ++i) {
+        const int f = tid + ASB_PP_T * i;
+        double a = 0.0, b = 0.0, c = 0.0;
+        if (f < Fp) {
+            a = r0[f]; b = r0[Fp + f]; c = r0[2 * Fp + f];
+            for (int q = 0; q < tp; ++q) {
+                const double wq = W[(k0 + q) * Fp + f];
+                a -= cprev[3 * q] * wq; b -= cprev[3 * q + 1] * wq; c -= cprev[3 * q + 2] * wq;
+            }
+            if (!in_regs) { scratch[f] = a; scratch[Fp + f] = b; scratch[2 * Fp + f] = c; }
+        }
+        if (in_regs && i < ASB_PP_E) { x[0][i] = a; x[1][i] = b; x[2][i] = c; }
+        if (f < F) {
+            gsum[0] += a * a; gsum[1] += a * b; gsum[2] += a * c;
+            gsum[3] += b * b; gsum[4] += b * c; gsum[5] += c * c;
+        }
+    }
+    block_sum<6>(gsum, sh_d);
+    if (tid == 0) {
+        double lam, u0, u1, u2;
+        eig3_top(gsum[0], gsum[1], gsum[2], gsum[3], gsum[4], gsum[5], lam, u0, u1, u2);
+        u_sh[0] = u0; u_sh[1] = u1; u_sh[2] = u2; u_sh[3] = lam;
+    }
+    __syncthreads();
+    const double u0 = u_sh[0], u1 = u_sh[1], u2 = u_sh[2];
+    double* wk = W + k * (long long)Fp;
+    double wn[1] = {0.0};
+#pragma unroll 2
+    for (int i = 0; i < iters; ++i) {
+        const int f = tid + ASB_PP_T * i;
+        if (f < Fp) {
+            double wv = 0.0;
+            if (f < F)
+                wv = (in_regs && i < ASB_PP_E) ? (u0 * x[0][i] + u1 * x[1][i] + u2 * x[2][i])
+                                                : (u0 * scratch[f] + u1 * scratch[Fp + f] + u2 * scratch[2 * Fp + f]);
+            wk[f] = wv;
+            wn[0] += wv * wv;
+        }
+    }
+    block_sum<1>(wn, sh_d);
+    if (tid == 0) {
+        scal[k * 4 + 0] = sqrt(fmax(u_sh[3], 0.0));
+        scal[k * 4 + 1] = wn[0];
+        scal[k * 4 + 2] = __longlong_as_double(cand_idx[bi]);
+        panel->committed = k - k0 + 1;
+    }
+}
+
+template <int T, int E2>
+static void launch_cand_dots_te(asb_ctx* ctx, int grid, long long k, int t_panel) {
+    constexpr int BLOCK = (T >= 256 ? T : 256);
+    hipLaunchKernelGGL((k_cand_dots<T, E2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->candR, ctx->W + k * ctx->Fp,
+                       ctx->scal + k * 4, t_panel, (long long)ctx->m_cap, ctx->cand_c, ctx->cand_e, ctx->cpmax, ctx->cpidx,
+                       ctx->cpsum, (int)(ctx->Fp / 2), ctx->pstate);
+}
+template <int E2>
+static void launch_cand_dots_e(asb_ctx* ctx, int T, int grid, long long k, int t_panel) {
+    switch (T) {
+        case 64: launch_cand_dots_te<64, E2>(ctx, grid, k, t_panel); break;
+        case 128: launch_cand_dots_te<128, E2>(ctx, grid, k, t_panel); break;
+        case 256: launch_cand_dots_te<256, E2>(ctx, grid, k, t_panel); break;
+        case 512: launch_cand_dots_te<512, E2>(ctx, grid, k, t_panel); break;
+        default: launch_cand_dots_te<1024, E2>(ctx, grid, k, t_panel); break;
+    }
+}
+static void launch_cand_dots(asb_ctx* ctx, const StreamCfg& c, int grid, long long k, int t_panel) {
+    switch (c.E2) {
+        case 4: launch_cand_dots_e<4>(ctx, c.T, grid, k, t_panel); break;
+        case 8: launch_cand_dots_e<8>(ctx, c.T, grid, k, t_panel); break;
+        default: launch_cand_dots_e<16>(ctx, c.T, grid, k, t_panel); break;
+    }
+}
+
 #define ASB_MARGIN_REL 1.0e-11
 
 static int hist_grid(const asb_ctx* ctx) {
@@ -891,7 +1088,8 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_run: bad range k0=%lld steps=%d", (long long)k0, steps);
     const StreamCfg c = ctx->cfg;
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ctx->m_cap * 3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ASB_PANEL_COLS * ctx->m_cap * 3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->slab_scratch, (size_t)3 * ctx->Fp))) return rc;
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(1), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
@@ -903,14 +1101,13 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     }
     for (int t = 0; t < steps; ++t) {
         const long long k = k0 + t;
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, ctx->stream, ctx->candR, ctx->cpmax, ctx->cpidx, ctx->cpsum,
-                           ctx->cnblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
-                           (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k, (long long)ctx->K, 0, ctx->pstate,
-                           ctx->cand_idx, (long long)k0);
-        StreamArgs a{ctx->candR, ctx->W + k * ctx->Fp, ctx->scal + k * 4, nullptr, ctx->cand_c, ctx->cand_e,
-                     ctx->cpmax, ctx->cpidx, ctx->cpsum, (long long)ctx->m_cap, ctx->pstate};
-        launch_stream(ctx, c, true, grid, a);
-        ctx->cnblk = grid;
+        hipLaunchKernelGGL(k_pick_panel, dim3(1), dim3(ASB_PP_T), 0, ctx->stream, ctx->candR, ctx->cand_c, (long long)ctx->m_cap,
+                           ctx->cpmax, ctx->cpidx, ctx->cnblk, (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k,
+                           (long long)k0, ctx->pstate, ctx->cand_idx, ctx->slab_scratch);
+        if (t + 1 < steps) {          // the last step's dots would only feed a pick that never runs
+            launch_cand_dots(ctx, c, grid, k, t);
+            ctx->cnblk = grid;
+        }
     }
     ASB_CHECK_LAUNCH(ctx);
     PanelState h;
@@ -921,8 +1118,13 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     if (getenv("ASB_DEBUG_PANELS")) {
         double sc[8];
         (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[asb] panel at k=%lld: n_cand=%lld committed=%lld theta=%.6f tau=%.6f\n", (long long)k0, h.n_cand,
-                h.committed, h.theta, sc[SC_TAU]);
+        std::vector<double> ce((size_t)h.n_cand);
+        (void)hipMemcpy(ce.data(), ctx->cand_e, ce.size() * sizeof(double), hipMemcpyDeviceToHost);
+        std::sort(ce.begin(), ce.end());
+        const size_t m = ce.size();
+        fprintf(stderr, "[asb] panel at k=%lld: n_cand=%lld committed=%lld theta=%.3f | candidate energies after the run: "
+                        "max %.3f, 2nd %.3f, median %.3f, min %.3f\n", (long long)k0, h.n_cand, h.committed, h.theta,
+                m ? ce[m - 1] : 0.0, m > 1 ? ce[m - 2] : 0.0, m ? ce[m / 2] : 0.0, m ? ce[0] : 0.0);
     }
     return ASB_OK;
 }
