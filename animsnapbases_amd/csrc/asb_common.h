@@ -80,6 +80,7 @@ struct asb_ctx {
     double* gram = nullptr;      // (K, 16) w_j . w_panel
     double* ypart = nullptr;     // partial 16x16 tiles between sweeps of k_project_lds
     unsigned int* tile_counter = nullptr;
+    double* Wq = nullptr;        // (Fp/16, 4, 16, 4) panel in MFMA lane order (k_project_l2)
     int project_kernel = 2;      // 1: k_project_mfma (register-resident Wt), 2: k_project_lds
     long long* ctmp = nullptr;   // compaction scratch
     long long* ccnt = nullptr;

@@ -611,6 +611,72 @@ __global__ __launch_bounds__(1024) void k_project_lds(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_project_l2: single sweep over the FULL rows.  The B operand comes from L2 instead of LDS: the panel
+// is stored in MFMA-lane order, Wq[chunk][g][i][j] = W_panel[16*chunk + 4g + j][i], so a lane fetches its four
+// B values of a chunk with one 32-byte load -- the same instruction count as the A operand -- and the
+// 256 KB panel stays L2-resident.  No LDS, no partial tiles, one launch per pass; whole rows are streamed
+// (the access pattern measured at 5.7 TB/s by tools/probe_stream_patterns.hip).
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_wq(const double* __restrict__ Wt, int Fp, double* __restrict__ Wq) {
+    const long long total = (long long)Fp * 16;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 3), i = (int)((e >> 2) & 15), g = (int)((e >> 6) & 3);
+        const long long chunk = e >> 8;
+        Wq[e] = Wt[(chunk * 16 + 4 * g + j) * ASB_PANEL_COLS + i];
+    }
+}
+
+__global__ __launch_bounds__(512) void k_project_l2(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    int ncols, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+    const long long ntiles = (rows + 15) / 16;
+    const int nchunk = Fp / 16;
+    const double4* wq = reinterpret_cast<const double4*>(Wq) + (g * 16 + i);      // chunk c: wq[64 * c]
+    for (;;) {
+        unsigned int t = 0;
+        if (l == 0) t = atomicAdd(counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((long long)t >= ntiles) break;
+        long long r = (long long)t * 16 + i;
+        if (r >= rows) r = rows - 1;
+        const double4* xp = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);  // chunk c: xp[4 * c]
+        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#define ASB_MFMA4B(xv, bv)                                                          \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).x, (bv).x, acc, 0, 0, 0);       \
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).y, (bv).y, acc2, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).z, (bv).z, acc, 0, 0, 0);       \
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).w, (bv).w, acc2, 0, 0, 0);
+        int c = 0;
+        double4 a0, a1, a2, a3;
+        if (nchunk >= 4) { a0 = xp[0]; a1 = xp[4]; a2 = xp[8]; a3 = xp[12]; }
+        for (; c + 8 <= nchunk; c += 4) {
+            const double4 b0 = wq[64 * c], b1 = wq[64 * (c + 1)], b2 = wq[64 * (c + 2)], b3 = wq[64 * (c + 3)];
+            const double4 n0 = xp[4 * (c + 4)], n1 = xp[4 * (c + 5)], n2 = xp[4 * (c + 6)], n3 = xp[4 * (c + 7)];
+            ASB_MFMA4B(a0, b0) ASB_MFMA4B(a1, b1) ASB_MFMA4B(a2, b2) ASB_MFMA4B(a3, b3)
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        }
+        if (c + 4 <= nchunk) {
+            const double4 b0 = wq[64 * c], b1 = wq[64 * (c + 1)], b2 = wq[64 * (c + 2)], b3 = wq[64 * (c + 3)];
+            ASB_MFMA4B(a0, b0) ASB_MFMA4B(a1, b1) ASB_MFMA4B(a2, b2) ASB_MFMA4B(a3, b3)
+            c += 4;
+        }
+        for (; c < nchunk; ++c) {
+            const double4 x = xp[4 * c], b = wq[64 * c];
+            ASB_MFMA4B(x, b)
+        }
+        acc += acc2;
+        if (i < ncols) {
+            const double inv = wn2[i];
+            double* dst = comps + (long long)i * comp_stride + (long long)t * 16 + g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((long long)t * 16 + g + 4 * q < rows) dst[4 * q] = acc[q] / inv;
+        }
+    }
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
                                                 double* __restrict__ scal) {
@@ -715,7 +781,29 @@ static int launch_project_lds(asb_ctx* ctx, int ncols, double* out) {
     return ASB_OK;
 }
 
+static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
+    const long long rows = 3 * ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq, (size_t)ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq);
+    ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
+    const long long ntiles = (rows + 15) / 16;
+    long long wantb = (ntiles + 7) / 8;
+    const int grid = (int)(wantb < 2 * ctx->n_cu ? wantb : 2 * ctx->n_cu);
+    size_t slot;
+    if ((rc = prof_begin(ctx, slot))) return rc;
+    hipLaunchKernelGGL(k_project_l2, dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq, ctx->wn2t,
+                       ncols, out, rows, ctx->tile_counter);
+    if ((rc = prof_end(ctx, slot))) return rc;
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 static void launch_project(asb_ctx* ctx, int ncols, double* out) {
+    if (ctx->project_kernel == 3) {
+        if (launch_project_l2(ctx, ncols, out) == ASB_OK) return;
+    }
     if (ctx->project_kernel == 2 && ctx->Fp <= 16 * 63 * 16) {
         if (launch_project_lds(ctx, ncols, out) == ASB_OK) return;
     }
@@ -756,8 +844,10 @@ int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0
 int asb_project_begin(asb_ctx* ctx, int64_t K) {
     const size_t rows = (size_t)ctx->n_loc * 3;
     int rc;
-    ctx->m_target = ctx->n_loc < 1024 ? ctx->n_loc : 1024;
-    ctx->m_cap = ctx->n_loc < 2048 ? ctx->n_loc : 2048;
+    int64_t mt = 768;      // ~16-step panels on flat (random) energy landscapes at the least candidate traffic (tools/sweep_m.sh)
+    if (const char* e = getenv("ASB_M_TARGET")) mt = atoll(e) > 16 ? atoll(e) : 16;      // tuning knob (candidates per panel)
+    ctx->m_target = ctx->N_glob < mt ? ctx->N_glob : mt;
+    ctx->m_cap = ctx->N_glob < 2 * mt ? ctx->N_glob : 2 * mt;
     if ((rc = asb_alloc(ctx, &ctx->energy, (size_t)ctx->n_loc))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->W, (size_t)K * ctx->Fp))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * rows))) return rc;
