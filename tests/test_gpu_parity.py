@@ -533,3 +533,43 @@ def test_multirank_pod_deim_on_one_gpu(tmp_path):
         for l in range(3):       # orthonormal per dimension after CholeskyQR2
             assert np.allclose(comps[:, :, l] @ comps[:, :, l].T, np.eye(K), atol=1e-10)
         assert Pt.tolist() == outs[0][2].tolist() and len(set(Pt.tolist())) == K
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,F,K", [(3, 5, 2), (1, 7, 1), (40, 1, 1), (17, 33, 9)])
+def test_tiny_and_ragged_shapes(N, F, K, mode):
+    """Edge shapes: fewer vertices than a wave, one frame, one vertex, F and N not multiples of anything."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(N * 100 + F)
+    X = rng.normal(size=(F, N, 3))
+    e = HipEngine(0)
+    e.upload(X, 0, N)
+    e.deflate_begin(K, False, mode)
+    e.run_global(0, K)
+    r = e.results()
+    e.close()
+    ref = orc.extract_k_components(X, K)
+    assert r["idx"].tolist() == ref["idx"].tolist()
+    comps, weigs = align_signs(r["comps"], r["weigs"], ref["comps"])
+    assert relerr(comps, ref["comps"]) < 1e-9 and relerr(weigs, ref["weigs"]) < 1e-9
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rank_exhausted_does_not_hang(mode):
+    """More components than the data's rank (F = 4 frames, K = 8): the residual collapses to rounding noise; the
+    reference keeps going on noise (or NaN).  The device path must return (finite or not) or raise -- never hang."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(4, 30, 3))
+    e = HipEngine(0)
+    e.upload(X, 0, 30)
+    e.deflate_begin(8, False, mode)
+    try:
+        e.run_global(0, 8)
+        r = e.results()
+        ref = orc.extract_k_components(X, 8)
+        assert r["idx"][:4].tolist() == ref["idx"][:4].tolist()      # the meaningful part agrees
+    except RuntimeError as ex:
+        assert "no progress" in str(ex) or "status -5" in str(ex)
+    finally:
+        e.close()
