@@ -627,11 +627,14 @@ __global__ __launch_bounds__(256) void k_build_wq(const double* __restrict__ Wt,
     }
 }
 
+// NT row tiles (of 16 rows) per wave share every B load; G chunks per register group (double-buffered).
+template <int NT, int G>
 __global__ __launch_bounds__(512) void k_project_l2(
     const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
     int ncols, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
     const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
-    const long long ntiles = (rows + 15) / 16;
+    constexpr int TR = 16 * NT;
+    const long long ntiles = (rows + TR - 1) / TR;
     const int nchunk = Fp / 16;
     const double4* wq = reinterpret_cast<const double4*>(Wq) + (g * 16 + i);      // chunk c: wq[64 * c]
     for (;;) {
@@ -639,40 +642,76 @@ __global__ __launch_bounds__(512) void k_project_l2(
         if (l == 0) t = atomicAdd(counter, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         if ((long long)t >= ntiles) break;
-        long long r = (long long)t * 16 + i;
-        if (r >= rows) r = rows - 1;
-        const double4* xp = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);  // chunk c: xp[4 * c]
-        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#define ASB_MFMA4B(xv, bv)                                                          \
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).x, (bv).x, acc, 0, 0, 0);       \
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).y, (bv).y, acc2, 0, 0, 0);     \
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).z, (bv).z, acc, 0, 0, 0);       \
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).w, (bv).w, acc2, 0, 0, 0);
-        int c = 0;
-        double4 a0, a1, a2, a3;
-        if (nchunk >= 4) { a0 = xp[0]; a1 = xp[4]; a2 = xp[8]; a3 = xp[12]; }
-        for (; c + 8 <= nchunk; c += 4) {
-            const double4 b0 = wq[64 * c], b1 = wq[64 * (c + 1)], b2 = wq[64 * (c + 2)], b3 = wq[64 * (c + 3)];
-            const double4 n0 = xp[4 * (c + 4)], n1 = xp[4 * (c + 5)], n2 = xp[4 * (c + 6)], n3 = xp[4 * (c + 7)];
-            ASB_MFMA4B(a0, b0) ASB_MFMA4B(a1, b1) ASB_MFMA4B(a2, b2) ASB_MFMA4B(a3, b3)
-            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        const double4* xp[NT];                                                     // chunk c: xp[m][4 * c]
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            long long r = (long long)t * TR + 16 * m + i;
+            if (r >= rows) r = rows - 1;
+            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
         }
-        if (c + 4 <= nchunk) {
-            const double4 b0 = wq[64 * c], b1 = wq[64 * (c + 1)], b2 = wq[64 * (c + 2)], b3 = wq[64 * (c + 3)];
-            ASB_MFMA4B(a0, b0) ASB_MFMA4B(a1, b1) ASB_MFMA4B(a2, b2) ASB_MFMA4B(a3, b3)
-            c += 4;
+        d4 acc[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+        double4 a[NT][G], bq[G], an[NT][G], bn[G];
+        int c = 0;
+        if (nchunk >= G) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                bq[q] = wq[64 * q];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) a[m][q] = xp[m][4 * q];
+            }
+        }
+#define ASB_GROUP_MFMA(AA, BB)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < G; ++q) {                                                   \
+        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].x, BB[q].x, acc[m], 0, 0, 0);       \
+        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].y, BB[q].y, acc[m], 0, 0, 0);       \
+        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].z, BB[q].z, acc[m], 0, 0, 0);       \
+        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].w, BB[q].w, acc[m], 0, 0, 0);       \
+    }
+        // while the MFMAs of group c issue, the A (HBM) and B (L2) operands of group c+G are in flight
+        for (; c + 2 * G <= nchunk; c += G) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                bn[q] = wq[64 * (c + G + q)];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) an[m][q] = xp[m][4 * (c + G + q)];
+            }
+            ASB_GROUP_MFMA(a, bq)
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                bq[q] = bn[q];
+#pragma unroll
+                for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
+            }
+        }
+        if (c + G <= nchunk) {
+            ASB_GROUP_MFMA(a, bq)
+            c += G;
         }
         for (; c < nchunk; ++c) {
-            const double4 x = xp[4 * c], b = wq[64 * c];
-            ASB_MFMA4B(x, b)
+            const double4 bb = wq[64 * c];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                const double4 x = xp[m][4 * c];
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, bb.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, bb.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.z, bb.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.w, bb.w, acc[m], 0, 0, 0);
+            }
         }
-        acc += acc2;
         if (i < ncols) {
             const double inv = wn2[i];
-            double* dst = comps + (long long)i * comp_stride + (long long)t * 16 + g;
+            double* dst = comps + (long long)i * comp_stride + (long long)t * TR + g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((long long)t * 16 + g + 4 * q < rows) dst[4 * q] = acc[q] / inv;
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((long long)t * TR + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = acc[m][q] / inv;
         }
     }
 }
@@ -788,13 +827,22 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq);
     ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
-    const long long ntiles = (rows + 15) / 16;
+    const int variant = ctx->l2_variant;
+    const int NT = variant == 0 ? 2 : (variant == 1 ? 3 : 4);
+    const long long ntiles = (rows + 16 * NT - 1) / (16 * NT);
     long long wantb = (ntiles + 7) / 8;
-    const int grid = (int)(wantb < 2 * ctx->n_cu ? wantb : 2 * ctx->n_cu);
+    const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
     size_t slot;
     if ((rc = prof_begin(ctx, slot))) return rc;
-    hipLaunchKernelGGL(k_project_l2, dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq, ctx->wn2t,
-                       ncols, out, rows, ctx->tile_counter);
+    if (variant == 0)
+        hipLaunchKernelGGL((k_project_l2<2, 4>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 1)
+        hipLaunchKernelGGL((k_project_l2<3, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else
+        hipLaunchKernelGGL((k_project_l2<4, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     if ((rc = prof_end(ctx, slot))) return rc;
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;

@@ -154,12 +154,14 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            if getattr(eng, "mode", 0) == 1 and "k_project_lds" in pm and (N, F, world) == (100000, 2000, 1):
-                traffic = pm["k_project_lds"]["hbm_bytes"]
+            kname = {2: "k_project_lds", 3: "k_project_l2<4, 2>"}.get(pk)
+            if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1):
+                traffic = pm[kname]["hbm_bytes"]
         except Exception:
             traffic = None
         mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
-        nsweep = -(-((F + 15) // 16) // 63) if getattr(eng, "mode", 0) == 1 else 1     # k_project_lds launches per pass
+        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
+        nsweep = -(-((F + 15) // 16) // 63) if (getattr(eng, "mode", 0) == 1 and pk == 2) else 1   # k_project_lds: sweeps per pass
         alg_bytes = 24.0 * n_loc * F / nsweep
         avg_ms = kern_ms / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
@@ -173,7 +175,8 @@ def main():
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": ("k_project_lds (f64-MFMA panel projection; %d sweep launches = one read of X per panel)" % nsweep
+                         "kernel": ({2: "k_project_lds", 3: "k_project_l2<4,2>"}.get(pk, "k_project_mfma") +
+                                    " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
                          "launches": launches,

@@ -40,6 +40,35 @@ __global__ __launch_bounds__(1024) void k_tile(const double* __restrict__ X, lon
     if (s == 12345.678) out[0] = s;
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+// same tile pattern, double-buffered groups of 4 chunks, plus NM f64 MFMAs per chunk (B from a register)
+template <int NM>
+__global__ __launch_bounds__(512) void k_tile_mfma(const double* __restrict__ X, long long rows, int Fp, unsigned* counter, double* out) {
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+    const long long ntiles = rows / 16;
+    d4 acc = {0, 0, 0, 0};
+    const double b = 1.0 + l * 1e-3;
+    for (;;) {
+        unsigned t = 0;
+        if (l == 0) t = atomicAdd(counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= ntiles) break;
+        const double4* xp = reinterpret_cast<const double4*>(X + ((long long)t * 16 + i) * Fp + 4 * g);
+        const int nchunk = Fp / 16;
+        double4 a0 = xp[0], a1 = xp[4], a2 = xp[8], a3 = xp[12];
+        for (int c = 0; c + 8 <= nchunk; c += 4) {
+            const double4 n0 = xp[4 * (c + 4)], n1 = xp[4 * (c + 5)], n2 = xp[4 * (c + 6)], n3 = xp[4 * (c + 7)];
+#define USE(v) { if (NM >= 1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((v).x, b, acc, 0, 0, 0); \
+                 if (NM >= 2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((v).y, b, acc, 0, 0, 0); \
+                 if (NM >= 4) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64((v).z, b, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f64_16x16x4f64((v).w, b, acc, 0, 0, 0); } \
+                 if (NM == 0) acc[0] += (v).x + (v).y + (v).z + (v).w; else if (NM < 4) acc[1] += (v).z + (v).w + (NM < 2 ? (v).y : 0.0); }
+            USE(a0) USE(a1) USE(a2) USE(a3)
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678) out[0] = acc[0];
+}
+
 int main() {
     const long long rows = 300000; const int Fp = 2000;
     double* X; double* out; unsigned* cnt;
@@ -61,6 +90,14 @@ int main() {
         RUN(4, 0, 1984, "tile G=4  full rows (1984 frames)")
         RUN(8, 0, 1984, "tile G=8  full rows")
         RUN(16, 0, 1984, "tile G=16 full rows (112 chunks)")
+    }
+#define RUNM(NM, LABEL) { CK(hipMemset(cnt, 0, 64)); CK(hipEventRecord(e0)); k_tile_mfma<NM><<<512, 512>>>(X, rows, Fp, cnt, out); \
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); report(LABEL, ms, rows * (double)Fp * 8.0); }
+    for (int rep = 0; rep < 2; ++rep) {
+        RUNM(0, "tile dbuf, no MFMA")
+        RUNM(1, "tile dbuf, 1 MFMA / chunk")
+        RUNM(2, "tile dbuf, 2 MFMA / chunk")
+        RUNM(4, "tile dbuf, 4 MFMA / chunk (as k_project)")
     }
     return 0;
 }
