@@ -573,3 +573,41 @@ def test_rank_exhausted_does_not_hang(mode):
         assert "no progress" in str(ex) or "status -5" in str(ex)
     finally:
         e.close()
+
+
+def test_multirank_from_device_shards_like_bench():
+    """bench.py's multi-rank data path: every rank adopts its OWN device-resident shard (from_device) and the
+    projection-mode deflation runs over the shards; result == the single-rank run on the concatenated tensor."""
+    import contextlib
+    import io
+    import torch
+    from animsnapbases_amd import HipEngine, partition, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    F, N, K, world = 48, 6001, 20, 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    Xfull = torch.rand((F, N, 3), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    torch.cuda.synchronize()
+    param = _param(vertPos_numComponents=K)
+
+    def rank_fn(rank, comm):
+        v0, n = partition(N, world)[rank]
+        shard = Xfull[:, v0:v0 + n, :].contiguous()
+        torch.cuda.synchronize()
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_device(shard.data_ptr(), F, n, rest_shape="first", standarize=True,
+                                             engine=HipEngine(0, stream=0), comm=comm, keepalive=shard)
+            comp = posComponents(param, snaps)
+            comp.compute_components_store_singvalues()
+        assert snaps.nVerts == N and snaps._shards == partition(N, world)
+        return comp.selected_vertices.copy(), comp.weigs.copy(), comp.measures_at_largeDeforVerts.copy(), comp.comps.copy()
+
+    outs = run_ranks(world, rank_fn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        one = posSnapshots.from_device(Xfull.data_ptr(), F, N, rest_shape="first", standarize=True)
+        c1 = posComponents(param, one)
+        c1.compute_components_store_singvalues()
+    for idx, weigs, meas, comps in outs:
+        assert idx.tolist() == c1.selected_vertices.tolist()
+        assert relerr(weigs, c1.weigs) < 1e-10 and relerr(meas, c1.measures_at_largeDeforVerts) < 1e-9
+        assert relerr(comps, c1.comps) < 1e-10
