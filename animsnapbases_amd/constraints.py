@@ -9,8 +9,9 @@ the row shard (partial Gram matrices all-reduced over ranks with RCCL), the K le
 left singular vectors are formed by the deflation's projection kernel, QR per dimension is
 CholeskyQR2, and each DEIM step's residual GEMV + arg-max runs on the shard.
 Host work, by design: the F x F symmetric eigen-solve (LAPACK ``eigh``) and DEIM's k x k
-interpolation solves (``numpy.linalg.lstsq`` -- the very routine the reference calls at
-constraintsComponents.py:829, so the coefficients match it).
+interpolation solves (an O(k^2) bordered-inverse update whose residual is checked every step;
+``numpy.linalg.lstsq``, the routine the reference calls at constraintsComponents.py:829, is
+the fallback).
 
 Other basis types of the reference (``pod`` per-(p,d) torch SVD, ``pca_blocks``,
 ``pca_blocks_with_St``, geometric / block DEIM, polyscope views) are out of scope
@@ -282,7 +283,8 @@ class constraintsComponents:  # Components == bases
 
     def deim(self):
         """constraintsComponents.py:797-860.  Residual GEMV + arg-max on the GPU shard(s); the k x k
-        interpolation solves on the host with ``np.linalg.lstsq`` exactly as the reference (:829)."""
+        interpolation solves on the host (bordered inverse, verified per step, ``np.linalg.lstsq`` -- the
+        reference's call at :829 -- as fallback)."""
         ns = self.nonlinearSnapshots
         eng, comm = ns._engine, ns._comm
         p_size = ns.constraintsSize
@@ -290,12 +292,43 @@ class constraintsComponents:  # Components == bases
         test_linear_dependency(self.comps.swapaxes(0, 1), 3, K)
         rows = np.zeros((K, K, 3))          # rows[m, j, i] = V[Pt[m], j, i]
         Pt, e_points, e_range = [], [], []
+        # The reference solves the growing k x k system from scratch with lstsq at every step (O(K^4) in all).
+        # Here the inverse of V[Pt,:k,i] is carried along by the bordering (Schur-complement) update, O(k^2)
+        # per step, and checked: if the solve's residual is not at rounding level the step falls back to lstsq.
+        Minv = [np.zeros((0, 0)) for _ in range(3)]
         for k in range(K):
             coef = None
             if k > 0:
                 coef = np.empty((3, k))
                 for i in range(3):
-                    coef[i] = np.linalg.lstsq(rows[:k, :k, i], rows[:k, k, i], rcond=None)[0]
+                    M, b = rows[:k, :k, i], rows[:k, k, i]
+                    if Minv[i].shape[0] == k - 1:          # grow the inverse by the point / vector added last step
+                        if k == 1:
+                            Minv[i] = np.array([[1.0 / M[0, 0]]]) if M[0, 0] != 0 else None
+                        else:
+                            A_inv = Minv[i]
+                            bcol, crow, d = M[:k - 1, k - 1], M[k - 1, :k - 1], M[k - 1, k - 1]
+                            u = A_inv @ bcol
+                            sch = d - crow @ u
+                            if sch != 0 and np.isfinite(sch):
+                                w = crow @ A_inv
+                                new = np.empty((k, k))
+                                new[:k - 1, :k - 1] = A_inv + np.outer(u, w) / sch
+                                new[:k - 1, k - 1] = -u / sch
+                                new[k - 1, :k - 1] = -w / sch
+                                new[k - 1, k - 1] = 1.0 / sch
+                                Minv[i] = new
+                            else:
+                                Minv[i] = None
+                    x = Minv[i] @ b if (Minv[i] is not None and Minv[i].shape[0] == k) else None
+                    if x is None or not np.all(np.isfinite(x)) or \
+                            np.linalg.norm(M @ x - b) > 1e-10 * (np.linalg.norm(b) + np.linalg.norm(M) * np.linalg.norm(x)):
+                        x = np.linalg.lstsq(M, b, rcond=None)[0]             # the reference's call (:829)
+                        try:
+                            Minv[i] = np.linalg.inv(M)
+                        except np.linalg.LinAlgError:
+                            Minv[i] = np.linalg.pinv(M)
+                    coef[i] = x
             idx, val = eng.deim_step(k, coef)
             if comm.world > 1:
                 idx = int(comm.global_argmax(np.array([idx]), np.array([val]))[0])
