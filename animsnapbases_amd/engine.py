@@ -247,6 +247,14 @@ class HipEngine(object):
         return C, W
 
     # ------------------------------------------------------------------ post-processing
+    # ------------------------------------------------------------------ ingest
+    def align_frames(self, frames, rigid=True):
+        """Rigid Procrustes alignment of every frame to frame 0; returns (aligned (F,N,3) f64, T (F,4,4))."""
+        fr = np.array(frames, dtype=np.float64, order="C", copy=True)
+        T = np.empty((fr.shape[0], 4, 4))
+        self._ck(self.lib.asb_align_frames(self.h, ptr(fr), fr.shape[0], fr.shape[1], int(bool(rigid)), ptr(T)))
+        return fr, T
+
     # ------------------------------------------------------------------ POD / QR / DEIM (config 5)
     def pod_gram(self, G_dev_ptr=None, to_host=True):
         G = np.empty((self.F, self.F)) if to_host else None

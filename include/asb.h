@@ -177,6 +177,12 @@ int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
 int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
 
+/* ------------------------------------------------ snapshot ingest --------------- */
+/* align, utils/process.py:235-250 (find_rbm_procrustes :210-234 + transform :196-208 per frame): every
+ * frame is moved onto frame 0 by the rigid-body motion of the orthogonal Procrustes problem.
+ * frames: host (F, N, 3) float64, overwritten; T_out: optional host (F, 4, 4) matrices. */
+int asb_align_frames(asb_ctx* ctx, double* frames, int64_t F, int64_t N, int rigid, double* T_out);
+
 /* ------------------------------------------------ constraint-projection bases (config 5) ---- */
 /* compute_pod_for_vectorized_nonlinear_snapshots_tensor, snapbases/constraintsComponents.py:298-320:
  * the reference takes svd(A), A = (3ep x F).  asb_pod_gram: G = A^T A (F x F) of this shard (f64 MFMA)

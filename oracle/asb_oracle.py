@@ -491,3 +491,35 @@ def synth_snapshots(rest, F, rank=10, noise=1e-4, seed=0, mode_scale=0.02, decay
     coef = rng.normal(size=(F, rank)) * (decay ** np.arange(rank))[None, :]
     X = rest[None] + np.tensordot(coef, modes, (1, 0)) + noise * rng.normal(size=(F, N, 3))
     return X
+
+
+# --------------------------------------------------------------------------------------
+# snapshot ingest   (utils/process.py)
+# --------------------------------------------------------------------------------------
+def find_rbm_procrustes(frompts, topts, rigid):
+    """utils/process.py:210-234 -- rigid-body motion [R | t] (4x4) moving frompts onto topts."""
+    t0, t1 = frompts.mean(0), topts.mean(0)
+    M = np.dot((topts - t1).T, frompts - t0)
+    U, _, Vt = np.linalg.svd(M)
+    R = np.dot(U, Vt)
+    if np.linalg.det(R) < 0:
+        R *= -1
+    T0 = np.eye(4)
+    if rigid:
+        T0[:3, :3] = R
+    T0[:3, 3] = t1 - np.dot(R, t0)
+    return T0
+
+
+def rbm_transform(v, M):
+    """utils/process.py:196-208 for a 4x4 M (homogenise, multiply, de-homogenise)."""
+    v1 = np.concatenate([v, np.ones(v.shape[:-1] + (1,), dtype=v.dtype)], axis=-1).reshape(-1, 4)
+    out = v1 @ M.T
+    return (out[:, :3] / out[:, 3:4]).reshape(v.shape)
+
+
+def align_frames(verts, rigid):
+    """utils/process.py:241-246 -- every frame onto frame 0; float32 result like the reference."""
+    v0 = verts[0]
+    Ts = [find_rbm_procrustes(v, v0, rigid) for v in verts]
+    return np.array([rbm_transform(v, M) for v, M in zip(verts, Ts)], np.float32), np.array(Ts)

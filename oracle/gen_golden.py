@@ -230,14 +230,75 @@ CASES = {
 }
 
 
+def _ingest(work):
+    # ingest: .off loading, pre-processing, rigid Procrustes alignment (utils/process.py)
+    import utils.process as rp
+    rng = np.random.default_rng(21)
+    rest, tris = orc.synth_mesh(6, 9, seed=9)
+    extra = rest[:4] * 0.1 + 2.0                         # a small disconnected component (4 vertices, 2 triangles)
+    rest2 = np.vstack([rest, extra])
+    n0 = rest.shape[0]
+    tris2 = np.vstack([tris, [[n0, n0 + 1, n0 + 2], [n0 + 1, n0 + 2, n0 + 3], [0, 0, 1]]])   # + a zero-area triangle
+    offdir = os.path.join(work, "off")
+    os.makedirs(offdir)
+    raw = []
+    for f in range(7):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = 0.4 * f
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        vf = (rest2 + 0.02 * f * rng.normal(size=rest2.shape) * (np.arange(rest2.shape[0]) % 3 == 0)[:, None]) @ Rm.T \
+            + rng.normal(size=3)
+        raw.append(vf)
+        with open(os.path.join(offdir, "frame_%d.off" % f), "w") as fh:
+            fh.write("OFF\n# comment line\n%d %d 0\n" % (vf.shape[0], tris2.shape[0]))
+            for v in vf:
+                fh.write("%.9f %.9f %.9f\n" % tuple(v))
+            for t in tris2:
+                fh.write("3 %d %d %d\n" % tuple(t))
+    loaded = [rp.load_off(os.path.join(offdir, "frame_%d.off" % f), no_colors=True) for f in range(7)]
+    verts_all = np.array([l[0] for l in loaded], np.float32)
+    class _PtpArray(np.ndarray):      # the reference calls ndarray.ptp (gone in NumPy 2): give the INPUT that method
+        def ptp(self, *a, **k):
+            return np.ptp(np.asarray(self), *a, **k)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        pv, pt, removed, pmean, pscale = rp.preprocess_mesh_animation(verts_all.copy().view(_PtpArray), loaded[0][1])
+    pv, pmean = np.asarray(pv), np.asarray(pmean)
+    out = {}
+    for rigid in (True, False):
+        v0 = pv[0]
+        Ts, new = [], []
+        for v in pv:
+            M = rp.find_rbm_procrustes(v, v0, rigid)
+            Ts.append(M)
+            new.append(rp.transform(v, M))
+        out["aligned_rigid%d" % int(rigid)] = np.array(new, np.float32)
+        out["T_rigid%d" % int(rigid)] = np.array(Ts)
+    np.savez_compressed(os.path.join(OUT, "ingest_small.npz"), off_verts=np.array([l[0] for l in loaded]),
+                        off_tris=loaded[0][1], pre_verts=pv, pre_tris=pt, pre_removed=removed, pre_mean=pmean,
+                        pre_scale=np.array(pscale), **out)
+    for f in range(7):
+        with open(os.path.join(offdir, "frame_%d.off" % f)) as fh:
+            pass
+    np.savez_compressed(os.path.join(OUT, "ingest_small_off.npz"),
+                        **{"frame_%d" % f: np.array(open(os.path.join(offdir, "frame_%d.off" % f)).read()) for f in range(7)})
+    print("wrote ingest_small")
+
+
 def main():
+    """`python oracle/gen_golden.py` regenerates every fixture; `... ingest` only the ingest one.  The ingest
+    functions of the reference (utils/process.py) call `ndarray.ptp` / `np.asfarray`, which NumPy 2 removed, so that
+    fixture is generated with the image's other interpreter: `/opt/conda/bin/python3.9 oracle/gen_golden.py ingest`
+    (NumPy 1.26)."""
+    only = sys.argv[1:] or None
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as work:
         os.chdir(work)                             # log_time writes function_timings.txt into cwd
         try:
-            for name, (rings, segs, F, rank, kind, seed, over, with_mass) in CASES.items():
+            for name, (rings, segs, F, rank, kind, seed, over, with_mass) in (CASES.items() if only is None else []):
                 rest, tris = orc.synth_mesh(rings, segs, seed=seed)
                 noise = 1e-4 if "nostd" not in name else 1e-3
                 verts = orc.synth_snapshots(rest, F, rank=rank, noise=noise, seed=seed, kind=kind)
@@ -257,6 +318,10 @@ def main():
                                        if k != "vertPos_output_directory"},
                                     **res)
                 print("wrote", name, "idx", res["idx"].tolist())
+            if only is not None and "ingest" not in only:
+                return
+            if only is not None:
+                return _ingest(work)
             # config-5 style: POD + DEIM on constraint-projection snapshots
             rng = np.random.default_rng(11)
             ep, F, K = 120, 24, 8
@@ -268,6 +333,8 @@ def main():
                 np.savez_compressed(os.path.join(OUT, nm + ".npz"), frames=frames, K=np.array(K),
                                     p=np.array(1), orthogonal=np.array(orth), **res)
                 print("wrote", nm, "Pt", res["Pt"].tolist())
+            if np.lib.NumpyVersion(np.__version__) < '2.0.0':
+                _ingest(work)
         finally:
             os.chdir(cwd)
 
