@@ -60,6 +60,8 @@ PROTOTYPES = {
     "asb_orth_apply": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_components_download": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
+    "asb_geodesic_setup": (c_int, [ctypes.c_void_p, c_int, c_int] + [c_dp] * 14),
+    "asb_geodesic_solve": (c_int, [ctypes.c_void_p, c_dp, c_int, c_dbl, c_dp, c_dp]),
     "asb_align_frames": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_int, c_dp]),
     "asb_pod_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_pod_basis": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64]),

@@ -26,6 +26,7 @@ struct StreamCfg {
 };
 
 struct asb_splocs;
+struct asb_geo;
 
 struct asb_ctx {
     int dev = 0;
@@ -90,6 +91,9 @@ struct asb_ctx {
     int64_t n_panels = 0, n_refresh = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
+    asb_geo* geo = nullptr;         // device geodesics (asb_geodesic.hip)
+    long long* geo_src = nullptr;
+    double* geo_out = nullptr;
 
     // ---- small dense linear algebra scratch (asb_linalg.hip) ----
     double* la_part = nullptr;
@@ -114,6 +118,7 @@ struct asb_ctx {
 int asb_project_begin(asb_ctx* ctx, int64_t K);
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
 void asb_splocs_free(asb_ctx* ctx);
+void asb_geo_free(asb_ctx* ctx);
 // small dense linear algebra on the device (asb_linalg.hip)
 // out[i*so_i + j*so_j] = sum_r A[r*lda + i*sa] * B[r*ldb + j]   (f64 MFMA; contraction index r slow in A and B)
 int asb_gemm_tn_s(asb_ctx* ctx, const double* A, long long lda, long long sa, const double* B, long long ldb, long long Rn,

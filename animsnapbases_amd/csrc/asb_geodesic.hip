@@ -1,0 +1,283 @@
+// Heat-method geodesics on the device -- GeodesicDistanceComputation.__call__,
+// utils/support.py:173-208 of the reference, for up to 64 source vertices at a time.
+//
+// The reference factorises (A - tL) and L once with SuperLU and back-substitutes per source.  Here the two SPD
+// systems are solved by Jacobi-preconditioned conjugate gradients for 64 right-hand sides together: vectors are
+// (N x 64) node-major, so one wave owns a matrix row and its 64 lanes are the 64 systems -- every neighbour fetch
+// is one contiguous 512-byte line.  Gradient, normalisation and divergence are two more SpMMs with the operators
+// assembled on the host (geodesic.py).  L is singular (constants): CG stays in the range for the consistent
+// right-hand side and the constant is fixed afterwards by phi -= min(phi), exactly as the reference does (:206).
+#include "asb_kernels.h"
+
+#define GB 64     // right-hand sides per batch = lanes of a wave
+
+struct asb_csr {
+    int rows = 0, cols = 0;
+    long long nnz = 0;
+    int* rowptr = nullptr;
+    int* colidx = nullptr;
+    double* vals = nullptr;
+};
+
+struct asb_geo {
+    int n = 0, m3 = 0;                 // vertices, 3 * triangles
+    asb_csr heat, lap, grad, div;      // A - tL, -L, G (3M x N), D (N x 3M)
+    double *dheat = nullptr, *dlap = nullptr;      // diagonals (Jacobi)
+    double *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *z = nullptr, *g = nullptr, *b = nullptr;
+    double *part = nullptr, *sc = nullptr;         // (nblk, 64) partial sums; scalars rz[64], alpha[64], ...
+    int nblk = 0;
+};
+
+// Y = A X  (+ optional per-column partial sums of X .* Y for CG's p^T A p)
+__global__ __launch_bounds__(256) void k_spmm64(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                const double* __restrict__ vals, int rows, const double* __restrict__ X,
+                                                double* __restrict__ Y, double* __restrict__ part_xy) {
+    __shared__ double sh[4][GB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double acc_dot = 0.0;
+    for (int r = blockIdx.x * 4 + wid; r < rows; r += gridDim.x * 4) {
+        double y = 0.0;
+        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) y += vals[j] * X[(long long)colidx[j] * GB + lane];
+        Y[(long long)r * GB + lane] = y;
+        if (part_xy) acc_dot += y * X[(long long)r * GB + lane];
+    }
+    if (part_xy) {
+        sh[wid][lane] = acc_dot;
+        __syncthreads();
+        if (wid == 0) part_xy[(long long)blockIdx.x * GB + lane] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    }
+}
+
+// alpha = rz / sum(part pAp);  x += alpha p;  r -= alpha Ap;  z = r / diag;  partial r.z (and r.r in part2)
+__global__ __launch_bounds__(256) void k_cg_update(int rows, int nblk_in, const double* __restrict__ part_pap,
+                                                   const double* __restrict__ rz, const double* __restrict__ diag,
+                                                   double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                                   const double* __restrict__ ap, double* __restrict__ z,
+                                                   double* __restrict__ part_rz, double* __restrict__ part_rr) {
+    __shared__ double sh[2][4][GB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double pap = 0.0;
+    for (int q = 0; q < nblk_in; ++q) pap += part_pap[(long long)q * GB + lane];
+    const double a = (pap != 0.0) ? rz[lane] / pap : 0.0;
+    double s_rz = 0.0, s_rr = 0.0;
+    for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
+        const long long e = (long long)i * GB + lane;
+        x[e] += a * p[e];
+        const double rn = r[e] - a * ap[e];
+        r[e] = rn;
+        const double zn = rn / diag[i];
+        z[e] = zn;
+        s_rz += rn * zn;
+        s_rr += rn * rn;
+    }
+    sh[0][wid][lane] = s_rz; sh[1][wid][lane] = s_rr;
+    __syncthreads();
+    if (wid == 0) {
+        part_rz[(long long)blockIdx.x * GB + lane] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+        part_rr[(long long)blockIdx.x * GB + lane] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+    }
+}
+
+// beta = rz_new / rz;  p = z + beta p;  block 0 publishes rz_new and rr
+__global__ __launch_bounds__(256) void k_cg_direction(int rows, int nblk_in, const double* __restrict__ part_rz,
+                                                      const double* __restrict__ part_rr, double* __restrict__ rz,
+                                                      double* __restrict__ rr, const double* __restrict__ z,
+                                                      double* __restrict__ p, int first) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double rzn = 0.0, rrn = 0.0;
+    for (int q = 0; q < nblk_in; ++q) { rzn += part_rz[(long long)q * GB + lane]; rrn += part_rr[(long long)q * GB + lane]; }
+    const double old = rz[lane];
+    const double beta = (first || old == 0.0) ? 0.0 : rzn / old;
+    for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
+        const long long e = (long long)i * GB + lane;
+        p[e] = z[e] + beta * p[e];
+    }
+    __threadfence();
+    if (blockIdx.x == gridDim.x - 1 && wid == 0) { rz[GB + lane] = rzn; rr[lane] = rrn; }     // staged: see k_cg_commit
+}
+
+__global__ void k_cg_commit(double* __restrict__ rz) { rz[threadIdx.x] = rz[GB + threadIdx.x]; }
+
+// z = r / diag, partial r.z / r.r  (start of CG with x = 0, r = b)
+__global__ __launch_bounds__(256) void k_cg_start(int rows, const double* __restrict__ diag, const double* __restrict__ r,
+                                                  double* __restrict__ z, double* __restrict__ part_rz,
+                                                  double* __restrict__ part_rr) {
+    __shared__ double sh[2][4][GB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double s_rz = 0.0, s_rr = 0.0;
+    for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
+        const long long e = (long long)i * GB + lane;
+        const double rn = r[e], zn = rn / diag[i];
+        z[e] = zn;
+        s_rz += rn * zn; s_rr += rn * rn;
+    }
+    sh[0][wid][lane] = s_rz; sh[1][wid][lane] = s_rr;
+    __syncthreads();
+    if (wid == 0) {
+        part_rz[(long long)blockIdx.x * GB + lane] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+        part_rr[(long long)blockIdx.x * GB + lane] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+    }
+}
+
+// X_f = -grad / |grad| per triangle (rows 3t..3t+2) and column
+__global__ __launch_bounds__(256) void k_normalise_field(double* __restrict__ g, int ntri) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int t = blockIdx.x * 4 + wid; t < ntri; t += gridDim.x * 4) {
+        double* q = g + (long long)3 * t * GB + lane;
+        const double a = q[0], b = q[GB], c = q[2 * GB];
+        const double len = sqrt(a * a + b * b + c * c);
+        q[0] = -a / len; q[GB] = -b / len; q[2 * GB] = -c / len;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_vec(double* __restrict__ x, long long n, double a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= a;
+}
+
+// b[idx[c]][c] = 1 for the batch's sources (others 0)
+__global__ void k_set_sources(double* __restrict__ b, const long long* __restrict__ idx, int nsrc) {
+    const int c = threadIdx.x;
+    if (c < nsrc) b[idx[c] * GB + c] = 1.0;
+}
+
+// phi[:, c] -= min(phi[:, c]); out (nsrc, n) source-major
+__global__ __launch_bounds__(256) void k_shift_min_out(const double* __restrict__ phi, int n, int nsrc,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    double m = 1.0e300;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmin(m, phi[(long long)i * GB + c]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmin(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    m = sh[0];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[(long long)c * n + i] = phi[(long long)i * GB + c] - m;
+    (void)nsrc;
+}
+
+// ------------------------------------------------------------------------------------- host
+static int upload_csr(asb_ctx* ctx, asb_csr& A, int rows, int cols, const int* rowptr, const int* colidx, const double* vals) {
+    A.rows = rows; A.cols = cols; A.nnz = rowptr[rows];
+    int rc;
+    if ((rc = asb_alloc(ctx, &A.rowptr, (size_t)rows + 1))) return rc;
+    if ((rc = asb_alloc(ctx, &A.colidx, (size_t)A.nnz))) return rc;
+    if ((rc = asb_alloc(ctx, &A.vals, (size_t)A.nnz))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(A.rowptr, rowptr, ((size_t)rows + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(A.colidx, colidx, (size_t)A.nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(A.vals, vals, (size_t)A.nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return ASB_OK;
+}
+
+// operators in CSR (int32 indices): heat = A - tL (n x n), lap = -L (n x n), grad (3M x n), div (n x 3M); diagonals of the two SPD ones
+extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_rp, const int* heat_ci, const double* heat_v,
+                                  const int* lap_rp, const int* lap_ci, const double* lap_v, const int* grad_rp,
+                                  const int* grad_ci, const double* grad_v, const int* div_rp, const int* div_ci,
+                                  const double* div_v, const double* heat_diag, const double* lap_diag) {
+    if (!ctx || n < 1 || m3 < 3) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));
+    if (!ctx->geo) ctx->geo = new asb_geo();
+    asb_geo* G = ctx->geo;
+    G->n = n; G->m3 = m3;
+    int rc;
+    if ((rc = upload_csr(ctx, G->heat, n, n, heat_rp, heat_ci, heat_v))) return rc;
+    if ((rc = upload_csr(ctx, G->lap, n, n, lap_rp, lap_ci, lap_v))) return rc;
+    if ((rc = upload_csr(ctx, G->grad, m3, n, grad_rp, grad_ci, grad_v))) return rc;
+    if ((rc = upload_csr(ctx, G->div, n, m3, div_rp, div_ci, div_v))) return rc;
+    if ((rc = asb_alloc(ctx, &G->dheat, (size_t)n))) return rc;
+    if ((rc = asb_alloc(ctx, &G->dlap, (size_t)n))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(G->dheat, heat_diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(G->dlap, lap_diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const size_t nv = (size_t)n * GB;
+    double** vecs[] = {&G->x, &G->r, &G->p, &G->ap, &G->z, &G->b};
+    for (auto v : vecs)
+        if ((rc = asb_alloc(ctx, v, nv))) return rc;
+    if ((rc = asb_alloc(ctx, &G->g, (size_t)m3 * GB))) return rc;
+    G->nblk = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
+    if ((rc = asb_alloc(ctx, &G->part, (size_t)3 * G->nblk * GB))) return rc;
+    if ((rc = asb_alloc(ctx, &G->sc, (size_t)4 * GB))) return rc;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// x <- A^-1 b by Jacobi-PCG on all 64 columns (b is consumed: it becomes the residual buffer)
+static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, double* b, double* x, int nsrc, double tol,
+                int max_iter, int* iters_out) {
+    const int n = G->n, nb = G->nblk;
+    double *part_pap = G->part, *part_rz = G->part + (size_t)nb * GB, *part_rr = G->part + (size_t)2 * nb * GB;
+    double *rz = G->sc, *rr = G->sc + 2 * GB;       // rz[0..63] current, rz[64..127] staged; rr[0..63]
+    ASB_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * GB * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(G->sc, 0, (size_t)4 * GB * sizeof(double), ctx->stream));
+    double* r = b;
+    hipLaunchKernelGGL(k_cg_start, dim3(nb), dim3(256), 0, ctx->stream, n, diag, r, G->z, part_rz, part_rr);
+    hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 1);
+    hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
+    double rr0[GB], rrk[GB];
+    ASB_HIP(ctx, hipMemcpyAsync(rr0, rr, sizeof(rr0), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int it = 0;
+    for (; it < max_iter;) {
+        for (int q = 0; q < 25 && it < max_iter; ++q, ++it) {
+            hipLaunchKernelGGL(k_spmm64, dim3(nb), dim3(256), 0, ctx->stream, A.rowptr, A.colidx, A.vals, n, G->p, G->ap, part_pap);
+            hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_pap, rz, diag, x, r, G->p, G->ap, G->z,
+                               part_rz, part_rr);
+            hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 0);
+            hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
+        }
+        ASB_CHECK_LAUNCH(ctx);
+        ASB_HIP(ctx, hipMemcpyAsync(rrk, rr, sizeof(rrk), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool done = true;
+        for (int c = 0; c < nsrc; ++c)
+            if (!(rrk[c] <= tol * tol * rr0[c])) done = false;
+        if (done) break;
+    }
+    if (iters_out) *iters_out = it;
+    return ASB_OK;
+}
+
+// distances from each of nsrc (<= 64) source vertices: out (nsrc, n), host.  iters (optional): CG iterations of the two solves.
+extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters) {
+    if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !out) return ASB_ERR_ARG;
+    asb_geo* G = ctx->geo;
+    const int n = G->n;
+    int rc;
+    if ((rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
+    long long* src_dev = nullptr;
+    if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
+    src_dev = ctx->geo_src;
+    ASB_HIP(ctx, hipMemcpyAsync(src_dev, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    // heat step: (A - tL) u = delta
+    ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
+    int it1 = 0, it2 = 0;
+    if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 20000, &it1))) return rc;
+    // gradient, normalise, divergence
+    const int gb = (G->m3 + 3) / 4 < 1024 ? (G->m3 + 3) / 4 : 1024;
+    hipLaunchKernelGGL(k_spmm64, dim3(gb), dim3(256), 0, ctx->stream, G->grad.rowptr, G->grad.colidx, G->grad.vals, G->m3, G->x, G->g,
+                       (double*)nullptr);
+    hipLaunchKernelGGL(k_normalise_field, dim3(gb), dim3(256), 0, ctx->stream, G->g, G->m3 / 3);
+    hipLaunchKernelGGL(k_spmm64, dim3(G->nblk), dim3(256), 0, ctx->stream, G->div.rowptr, G->div.colidx, G->div.vals, n, G->g, G->b,
+                       (double*)nullptr);
+    ASB_CHECK_LAUNCH(ctx);
+    // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
+    if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 50000, &it2))) return rc;
+    // phi = -y; phi -= min(phi)  ==  max(y) - y : done by negating in place first
+    hipLaunchKernelGGL(k_scale_vec, dim3(G->nblk), dim3(256), 0, ctx->stream, G->x, (long long)n * GB, -1.0);
+    if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;
+    hipLaunchKernelGGL(k_shift_min_out, dim3(nsrc), dim3(256), 0, ctx->stream, G->x, n, nsrc, ctx->geo_out);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(out, ctx->geo_out, (size_t)nsrc * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (iters) { iters[0] = it1; iters[1] = it2; }
+    return ASB_OK;
+}
+
+void asb_geo_free(asb_ctx* ctx) {
+    if (ctx->geo) {
+        delete ctx->geo;
+        ctx->geo = nullptr;
+    }
+}

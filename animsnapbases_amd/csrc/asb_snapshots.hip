@@ -161,6 +161,7 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
         *slot = nullptr;
     }
     asb_splocs_free(ctx);
+    asb_geo_free(ctx);
     for (auto& e : ctx->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);

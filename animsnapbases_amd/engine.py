@@ -247,6 +247,32 @@ class HipEngine(object):
         return C, W
 
     # ------------------------------------------------------------------ post-processing
+    # ------------------------------------------------------------------ device geodesics
+    def geodesic_setup(self, heat, lap, grad, div):
+        """heat, lap, grad, div: scipy CSR matrices (float64)."""
+        keep = []
+
+        def csr(m):
+            m = m.tocsr()
+            m.sort_indices()
+            rp, ci, v = m.indptr.astype(np.int32), m.indices.astype(np.int32), np.ascontiguousarray(m.data, dtype=np.float64)
+            keep.extend([rp, ci, v])
+            return [rp.ctypes.data, ci.ctypes.data, v.ctypes.data]
+
+        n, m3 = heat.shape[0], grad.shape[0]
+        dh = np.ascontiguousarray(heat.diagonal(), dtype=np.float64)
+        dl = np.ascontiguousarray(lap.diagonal(), dtype=np.float64)
+        args = csr(heat) + csr(lap) + csr(grad) + csr(div) + [dh.ctypes.data, dl.ctypes.data]
+        self._ck(self.lib.asb_geodesic_setup(self.h, int(n), int(m3), *args))
+        self._geo_n = n
+
+    def geodesic_solve(self, sources, tol=1e-13):
+        src = np.ascontiguousarray(sources, dtype=np.int64)
+        out = np.empty((src.shape[0], self._geo_n))
+        it = (ctypes.c_int * 2)()
+        self._ck(self.lib.asb_geodesic_solve(self.h, ptr(src), int(src.shape[0]), float(tol), ptr(out), it))
+        return out, (it[0], it[1])
+
     # ------------------------------------------------------------------ ingest
     def align_frames(self, frames, rigid=True):
         """Rigid Procrustes alignment of every frame to frame 0; returns (aligned (F,N,3) f64, T (F,4,4))."""

@@ -49,7 +49,9 @@ class GeodesicDistanceComputation(object):
     """Callable: ``phi = geo(idx)`` -> (N,) geodesic distance from vertex ``idx``
     (shifted so that min(phi) == 0, utils/support.py:206)."""
 
-    def __init__(self, verts, tris, m=10.0):
+    def __init__(self, verts, tris, m=10.0, engine=None, tol=1e-13):
+        """engine: a HipEngine to run the solves on the GPU (``asb_geodesic_*``: batched Jacobi-PCG, 64 sources
+        at a time, relative residual ``tol``); None = host SuperLU like the reference."""
         verts = np.asarray(verts, dtype=np.float64)
         tris = np.asarray(tris, dtype=np.int64)
         n, M = verts.shape[0], tris.shape[0]
@@ -87,7 +89,16 @@ class GeodesicDistanceComputation(object):
         h = np.mean([_vlen(e01), _vlen(e12), _vlen(e20)])
         t = m * h ** 2
         L, vert_area = cotan_laplacian(verts, tris)
-        self._heat = splu((sparse.diags(vert_area) - t * L).tocsc())
+        self._A_heat = (sparse.diags(vert_area) - t * L).tocsr()
+        self._L = L
+        self._engine = None
+        self.last_iterations = None
+        if engine is not None:          # device backend: batched Jacobi-PCG instead of the SuperLU factorisations
+            engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D)
+            self._engine = engine
+            self._tol = tol
+            return
+        self._heat = splu(self._A_heat.tocsc())
         self._poisson = splu(L.tocsc())
 
     def _field(self, U):
@@ -99,6 +110,8 @@ class GeodesicDistanceComputation(object):
         return phi - phi.min(axis=0)
 
     def __call__(self, idx):
+        if self._engine is not None:
+            return self.solve_many([int(idx)])[0]
         u0 = np.zeros(self.n)
         u0[idx] = 1.0
         return self._field(self._heat.solve(u0))
@@ -108,6 +121,14 @@ class GeodesicDistanceComputation(object):
         distinct vertex set (repeated indices are solved once)."""
         idxs = np.asarray(idxs, dtype=np.int64)
         uniq, inv = np.unique(idxs, return_inverse=True)
+        if self._engine is not None:
+            parts, its = [], []
+            for b in range(0, uniq.size, 64):
+                phi, it = self._engine.geodesic_solve(uniq[b:b + 64], self._tol)
+                parts.append(phi)
+                its.append(it)
+            self.last_iterations = its
+            return np.ascontiguousarray(np.concatenate(parts, axis=0)[inv])
         E = np.zeros((self.n, uniq.size))
         E[uniq, np.arange(uniq.size)] = 1.0
         phi = self._field(self._heat.solve(E))

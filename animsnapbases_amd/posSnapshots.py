@@ -138,7 +138,8 @@ class posSnapshots:
         # geodesics on the NON-weighted shape (:96-99); host SciPy
         if self.tris is not None and self.verts is not None:
             shape0 = self.verts[0] if self.rest_shape == "first" else np.mean(self.verts, axis=0)
-            self.compute_geodesic_distance = GeodesicDistanceComputation(shape0, self.tris)
+            on_dev = os.environ.get("ASB_GEODESIC", "host") == "device" or getattr(self, "geodesic_backend", "host") == "device"
+            self.compute_geodesic_distance = GeodesicDistanceComputation(shape0, self.tris, engine=eng if on_dev else None)
 
         if standarize:
             self.standarize(_local_sum=local_sum)

@@ -177,6 +177,19 @@ int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
 int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
 
+/* ------------------------------------------------ geodesics on the device (optional) ---- */
+/* GeodesicDistanceComputation, utils/support.py:139-208, with the two SuperLU solves replaced by
+ * Jacobi-PCG for up to 64 sources at a time.  Operators (host CSR, int32 indices), assembled by the caller
+ * from the mesh: heat = A - tL, lap = -L (both n x n, SPD / SPSD), grad (m3 x n), div (n x m3), and the
+ * diagonals of heat and lap. */
+int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_rp, const int* heat_ci, const double* heat_v,
+                       const int* lap_rp, const int* lap_ci, const double* lap_v, const int* grad_rp,
+                       const int* grad_ci, const double* grad_v, const int* div_rp, const int* div_ci,
+                       const double* div_v, const double* heat_diag, const double* lap_diag);
+/* distances (min-shifted, :206) from nsrc <= 64 sources: out host (nsrc, n); tol = relative residual of the
+ * CG solves; iters (optional, 2 ints) = iterations of the heat and the Poisson solve */
+int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters);
+
 /* ------------------------------------------------ snapshot ingest --------------- */
 /* align, utils/process.py:235-250 (find_rbm_procrustes :210-234 + transform :196-208 per frame): every
  * frame is moved onto frame 0 by the rigid-body motion of the orthogonal Procrustes problem.

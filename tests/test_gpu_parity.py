@@ -611,3 +611,29 @@ def test_multirank_from_device_shards_like_bench():
         assert idx.tolist() == c1.selected_vertices.tolist()
         assert relerr(weigs, c1.weigs) < 1e-10 and relerr(meas, c1.measures_at_largeDeforVerts) < 1e-9
         assert relerr(comps, c1.comps) < 1e-10
+
+
+def test_device_geodesics_vs_superlu():
+    """Heat-method geodesics with batched Jacobi-PCG on the device vs the SuperLU path (reference's solver)."""
+    from animsnapbases_amd import GeodesicDistanceComputation, HipEngine
+    V, T = orc.synth_mesh(30, 44, seed=2)           # 1322 vertices
+    host = GeodesicDistanceComputation(V, T)
+    e = HipEngine(0)
+    dev = GeodesicDistanceComputation(V, T, engine=e)
+    src = [0, 5, 77, 640, 1321] + list(range(100, 170))       # 75 sources: two device batches
+    a, b = host.solve_many(src), dev.solve_many(src)
+    assert relerr(b, a) < 1e-8
+    assert relerr(dev(640), host(640)) < 1e-8
+    assert all(it[0] > 0 and it[1] > 0 for it in dev.last_iterations)
+    o = orc.Geodesics(V, T)
+    assert relerr(dev(77), o(77)) < 1e-8
+    e.close()
+
+
+def test_local_support_with_device_geodesics(monkeypatch):
+    monkeypatch.setenv("ASB_GEODESIC", "device")
+    g = load_golden("pca_local_small")
+    snaps, comp = _run(g["verts"], g["tris"], _param(g))
+    assert snaps.compute_geodesic_distance._engine is not None
+    assert comp.selected_vertices.tolist() == g["idx"].tolist()
+    assert relerr(comp.comps, g["comps"]) < 1e-7 and relerr(comp.weigs, g["weigs"]) < TOL
