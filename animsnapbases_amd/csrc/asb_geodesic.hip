@@ -53,12 +53,15 @@ __global__ __launch_bounds__(256) void k_cg_update(int rows, int nblk_in, const 
                                                    const double* __restrict__ rz, const double* __restrict__ diag,
                                                    double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
                                                    const double* __restrict__ ap, double* __restrict__ z,
-                                                   double* __restrict__ part_rz, double* __restrict__ part_rr) {
+                                                   double* __restrict__ part_rz, double* __restrict__ part_rr, double tol2) {
     __shared__ double sh[2][4][GB];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double pap = 0.0;
     for (int q = 0; q < nblk_in; ++q) pap += part_pap[(long long)q * GB + lane];
-    const double a = (pap != 0.0) ? rz[lane] / pap : 0.0;
+    // a column that has reached the tolerance (or was zero from the start) is frozen: it must not keep dividing
+    // by a vanishing p^T A p while the other columns still iterate
+    const bool active = rz[lane] > tol2 * rz[3 * GB + lane] && pap > 0.0;
+    const double a = active ? rz[lane] / pap : 0.0;
     double s_rz = 0.0, s_rr = 0.0;
     for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
         const long long e = (long long)i * GB + lane;
@@ -82,18 +85,22 @@ __global__ __launch_bounds__(256) void k_cg_update(int rows, int nblk_in, const 
 __global__ __launch_bounds__(256) void k_cg_direction(int rows, int nblk_in, const double* __restrict__ part_rz,
                                                       const double* __restrict__ part_rr, double* __restrict__ rz,
                                                       double* __restrict__ rr, const double* __restrict__ z,
-                                                      double* __restrict__ p, int first) {
+                                                      double* __restrict__ p, int first, double tol2) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double rzn = 0.0, rrn = 0.0;
     for (int q = 0; q < nblk_in; ++q) { rzn += part_rz[(long long)q * GB + lane]; rrn += part_rr[(long long)q * GB + lane]; }
     const double old = rz[lane];
-    const double beta = (first || old == 0.0) ? 0.0 : rzn / old;
+    const double beta = (first || old == 0.0 || !(old > tol2 * rz[3 * GB + lane])) ? 0.0 : rzn / old;
     for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
         const long long e = (long long)i * GB + lane;
         p[e] = z[e] + beta * p[e];
     }
     __threadfence();
-    if (blockIdx.x == gridDim.x - 1 && wid == 0) { rz[GB + lane] = rzn; rr[lane] = rrn; }     // staged: see k_cg_commit
+    if (blockIdx.x == gridDim.x - 1 && wid == 0) {       // staged: see k_cg_commit
+        rz[GB + lane] = rzn;
+        rr[lane] = rrn;
+        if (first) rz[3 * GB + lane] = rzn;               // r0.z0 of the column: the freeze reference
+    }
 }
 
 __global__ void k_cg_commit(double* __restrict__ rz) { rz[threadIdx.x] = rz[GB + threadIdx.x]; }
@@ -207,40 +214,61 @@ static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, 
                 int max_iter, int* iters_out) {
     const int n = G->n, nb = G->nblk;
     double *part_pap = G->part, *part_rz = G->part + (size_t)nb * GB, *part_rr = G->part + (size_t)2 * nb * GB;
-    double *rz = G->sc, *rr = G->sc + 2 * GB;       // rz[0..63] current, rz[64..127] staged; rr[0..63]
+    double *rz = G->sc, *rr = G->sc + 2 * GB;       // rz[0..63] current, [64..127] staged, [192..255] initial; rr = sc[128..191]
+    const double tol2 = tol * tol;
     ASB_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * GB * sizeof(double), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(G->sc, 0, (size_t)4 * GB * sizeof(double), ctx->stream));
     double* r = b;
     hipLaunchKernelGGL(k_cg_start, dim3(nb), dim3(256), 0, ctx->stream, n, diag, r, G->z, part_rz, part_rr);
-    hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 1);
+    hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 1, tol2);
     hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
     double rr0[GB], rrk[GB];
     ASB_HIP(ctx, hipMemcpyAsync(rr0, rr, sizeof(rr0), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int it = 0;
+    for (int c = 0; c < GB; ++c) rrk[c] = rr0[c];
+    int it = 0, stalled = 0;
+    double prev[GB];
+    for (int c = 0; c < GB; ++c) prev[c] = rr0[c];
     for (; it < max_iter;) {
         for (int q = 0; q < 25 && it < max_iter; ++q, ++it) {
             hipLaunchKernelGGL(k_spmm64, dim3(nb), dim3(256), 0, ctx->stream, A.rowptr, A.colidx, A.vals, n, G->p, G->ap, part_pap);
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_pap, rz, diag, x, r, G->p, G->ap, G->z,
-                               part_rz, part_rr);
-            hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 0);
+                               part_rz, part_rr, tol2);
+            hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 0, tol2);
             hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
         }
         ASB_CHECK_LAUNCH(ctx);
         ASB_HIP(ctx, hipMemcpyAsync(rrk, rr, sizeof(rrk), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        bool done = true;
+        // stop at the requested relative residual, or when rounding has been reached: no column still above the
+        // tolerance has set a new best residual for 200 iterations (CG on these systems floors near eps * cond)
+        bool done = true, progress = false;
         for (int c = 0; c < nsrc; ++c)
-            if (!(rrk[c] <= tol * tol * rr0[c])) done = false;
+            if (!(rrk[c] <= tol * tol * rr0[c])) {
+                done = false;
+                if (rrk[c] < 0.9 * prev[c]) progress = true;
+            }
         if (done) break;
+        if (progress) {
+            stalled = 0;
+            for (int c = 0; c < nsrc; ++c) prev[c] = rrk[c] < prev[c] ? rrk[c] : prev[c];
+        } else if (++stalled >= 8) {      // 200 iterations without a new best residual anywhere
+            break;
+        }
     }
     if (iters_out) *iters_out = it;
+    // loud failure instead of silently wrong distances: Jacobi-PCG is only adequate for well-shaped meshes
+    for (int c = 0; c < nsrc; ++c)
+        if (!(rrk[c] <= 1e-16 * rr0[c]))      // relative residual 1e-8 is the least we accept
+            ASB_FAIL(ctx, ASB_ERR_NUMERIC, "device geodesics: PCG stopped at relative residual %.2e after %d iterations "
+                     "(badly conditioned mesh); use the host SuperLU backend", sqrt(rrk[c] / (rr0[c] > 0 ? rr0[c] : 1.0)), it);
     return ASB_OK;
 }
 
 // distances from each of nsrc (<= 64) source vertices: out (nsrc, n), host.  iters (optional): CG iterations of the two solves.
 extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters) {
     if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !out) return ASB_ERR_ARG;
+    if (!(tol >= 1e-14)) tol = 1e-14;      // below the rounding floor CG only wanders (and can blow up)
     asb_geo* G = ctx->geo;
     const int n = G->n;
     int rc;
@@ -253,7 +281,7 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
     ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
     int it1 = 0, it2 = 0;
-    if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 20000, &it1))) return rc;
+    if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1))) return rc;
     // gradient, normalise, divergence
     const int gb = (G->m3 + 3) / 4 < 1024 ? (G->m3 + 3) / 4 : 1024;
     hipLaunchKernelGGL(k_spmm64, dim3(gb), dim3(256), 0, ctx->stream, G->grad.rowptr, G->grad.colidx, G->grad.vals, G->m3, G->x, G->g,
@@ -263,7 +291,7 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
                        (double*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
-    if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 50000, &it2))) return rc;
+    if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2))) return rc;
     // phi = -y; phi -= min(phi)  ==  max(y) - y : done by negating in place first
     hipLaunchKernelGGL(k_scale_vec, dim3(G->nblk), dim3(256), 0, ctx->stream, G->x, (long long)n * GB, -1.0);
     if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;

@@ -8,8 +8,14 @@ sparse matrices G (3M x N) and D (N x 3M), so one query is two SuperLU solves an
 sparse mat-vecs, and ``solve_many`` answers K queries with multi-right-hand-side solves
 (what one SPLOCS outer iteration needs, posComponents.py:158-165).
 
-SURVEY.md 8(f)-3 ranks a device PCG as a later row; until then this host stage is the
-Amdahl term of the local / SPLOCS modes and is reported as such.
+SURVEY.md 8(f)-3 asks for a device solver.  ``engine=`` switches the two solves to batched
+Jacobi-preconditioned CG on the GPU (csrc/asb_geodesic.hip, 64 sources per batch).  It is
+EXPERIMENTAL and opt-in (``ASB_GEODESIC=device``): it matches SuperLU to 1e-11 on well-shaped
+meshes of ~1e3 vertices, but the Jacobi preconditioner needs thousands of iterations on large or
+badly shaped meshes (measured: 14 290-vertex lat-long sphere, > 1 s per solve against 4 ms for
+SuperLU) and raises rather than returning unconverged distances.  A multigrid / incomplete-Cholesky
+preconditioner is what the row still needs; host SuperLU stays the default and is the Amdahl term
+of the local / SPLOCS modes.
 """
 import numpy as np
 from scipy import sparse
