@@ -109,7 +109,10 @@ class GeodesicDistanceComputation(object):
         # solutions agree with the default ordering (what the reference uses) to 4e-13
         kw = dict(permc_spec="MMD_AT_PLUS_A", options=dict(SymmetricMode=True))
         self._heat = splu(self._A_heat.tocsc(), **kw)
-        self._poisson = splu(L.tocsc(), **kw)
+        try:
+            self._poisson = splu(L.tocsc(), **kw)
+        except RuntimeError:            # L is singular (constants): on some (tiny) meshes this ordering meets an exact
+            self._poisson = splu(L.tocsc())     # zero pivot; the default ordering is what the reference factorises
 
     def _field(self, U):
         """U: (n,) or (n,k) heat solutions -> distances, same shape."""
