@@ -314,6 +314,29 @@ extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_ou
     return ASB_OK;
 }
 
+// T = 1.5 I - 0.5 G (one Newton-Schulz / Loewdin step towards G = I)
+__global__ __launch_bounds__(256) void k_newton_schulz_T(double* __restrict__ G, int n) {
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) G[e] = ((e / n == e % n) ? 1.5 : 0.0) - 0.5 * G[e];
+}
+
+// Second pass of the orthogonalisation.  U = A V S^-1 from the Gram route is orthonormal only to eps * cond(A)^2; with
+// the Gram matrices of that U (asb_orth_gram again, all-reduced) one symmetric Newton-Schulz step U <- U (1.5 I - 0.5 U^T U)
+// squares the defect (1e-10 -> 1e-20) and, being symmetric, does not rotate U away from the singular vectors scipy's orth returns.
+extern "C" int asb_orth_refine(asb_ctx* ctx, const double* G_dev) {
+    if (!ctx || !ctx->comps || !ctx->oct || !ctx->comps2) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, n = ctx->n_loc;
+    int rc;
+    if (G_dev) ASB_HIP(ctx, hipMemcpyAsync(ctx->og, G_dev, (size_t)3 * K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int l = 0; l < 3; ++l) {
+        double* Gl = ctx->og + (size_t)l * K * K;
+        hipLaunchKernelGGL(k_newton_schulz_T, dim3(1), dim3(256), 0, ctx->stream, Gl, (int)K);
+        ASB_CHECK_LAUNCH(ctx);
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, Gl, K, K, (int)n, (int)K, ctx->comps2 + l, 3, 3 * n))) return rc;
+    }
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+
 // replaces the device-resident basis by a host array (K, n_loc, 3) (a caller-assigned `comps`)
 extern "C" int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K) {
     if (!ctx || !ctx->X || !comps_host || K < 1) return ASB_ERR_ARG;

@@ -337,6 +337,9 @@ class HipEngine(object):
         self._ck(self.lib.asb_orth_apply(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None, ptr(sing)))
         return sing
 
+    def orth_refine(self, G_dev_ptr=None):
+        self._ck(self.lib.asb_orth_refine(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
+
     def components_post(self, unscale, pre_scale_factor, invMassL_loc=None):
         out = np.empty((self.K, self.n_loc, 3))
         if invMassL_loc is not None:

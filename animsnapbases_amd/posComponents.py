@@ -323,6 +323,11 @@ class posComponents:  # Components == bases
             if Gbuf is not None:
                 comm.allreduce_tensor(Gbuf)
             self.ortho_sing_vals = eng.orth_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+            # the Gram route leaves U^T U = I + O(eps cond^2): one Newton-Schulz step with the Gram of U removes it
+            eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+            if Gbuf is not None:
+                comm.allreduce_tensor(Gbuf)
+            eng.orth_refine(Gbuf.data_ptr() if Gbuf is not None else None)
             loc = None
         if self.param.q_massWeight:
             assert snaps.nVerts == snaps.invMassL.shape[0]

@@ -169,9 +169,13 @@ int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
  * asb_orth_gram: this shard's three K x K Gram matrices into G_dev (3*K*K doubles, caller's
  * device buffer to be all-reduced over ranks) or into the context when NULL.
  * asb_orth_apply: finishes with the (summed) Gram matrices; sing_out (host, 3*K, optional).
- * Fails with ASB_ERR_NUMERIC when a slice is rank deficient (orth would drop vectors). */
+ * Fails with ASB_ERR_NUMERIC when a slice is rank deficient (orth would drop vectors).
+ * asb_orth_refine: second pass -- with the Gram matrices of the basis asb_orth_apply left (asb_orth_gram again,
+ * summed), one symmetric Newton-Schulz step U <- U (1.5 I - 0.5 U^T U): squares the eps * cond^2 orthogonality
+ * defect of the Gram route, so U^T U = I holds to round-off like scipy's SVD-based orth. */
 int asb_orth_gram(asb_ctx* ctx, double* G_dev);
 int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out);
+int asb_orth_refine(asb_ctx* ctx, const double* G_dev);
 /* the device-resident basis (K, n_loc, 3) to the host */
 int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
