@@ -84,7 +84,7 @@ class nonlinearSnapshots:
         X = self.read()
         if self._engine is None:
             dev, stream = 0, None
-            if self._comm.world > 1:
+            if self._comm.multi:
                 import torch
                 dev, stream = torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream
             self._engine = HipEngine(dev, stream)
@@ -230,7 +230,7 @@ class constraintsComponents:  # Components == bases
         ns = self.nonlinearSnapshots
         eng, comm = ns._engine, ns._comm
         F = ns.frs
-        if comm.world > 1:
+        if comm.multi:
             Gbuf = comm.new_buffer(F * F, eng.device_exchange)
             eng.pod_gram(Gbuf.data_ptr(), to_host=False)
             comm.allreduce_tensor(Gbuf)                      # partial Gram matrices: RCCL all-reduce
@@ -266,7 +266,7 @@ class constraintsComponents:  # Components == bases
             ns._snapTensor = None
         if p.constProj_orthogonal:
             for _ in range(2):                                                 # CholeskyQR2
-                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.world > 1 else None
+                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.multi else None
                 eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
                 if Gbuf is not None:
                     comm.allreduce_tensor(Gbuf)
@@ -330,14 +330,14 @@ class constraintsComponents:  # Components == bases
                             Minv[i] = np.linalg.pinv(M)
                     coef[i] = x
             idx, val = eng.deim_step(k, coef)
-            if comm.world > 1:
+            if comm.multi:
                 idx = int(comm.global_argmax(np.array([idx]), np.array([val]))[0])
                 val = float(comm.allreduce_max(val)[0])
             if k > 0 and not val > 0.0:
                 print("ERROR!: zero residual!!")
                 return
             row = eng.deim_row(idx)
-            if comm.world > 1:
+            if comm.multi:
                 row = comm.allreduce_sum(np.zeros((K, 3)) if row is None else row).reshape(K, 3)
             rows[k] = row
             alpha = idx // p_size

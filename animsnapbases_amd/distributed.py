@@ -9,6 +9,8 @@ all-gather of ``[energy, idx, 3 x F slab]`` records (<= 48 KB at F = 2000), plus
 all-reduces during standardisation and one all-reduce of the K residual norms at the end.
 The snapshot tensor itself never moves.
 """
+import os
+
 import numpy as np
 
 
@@ -25,10 +27,15 @@ def partition(N, world):
 
 
 class Comm(object):
-    def __init__(self, group=None, force_single=False):
+    def __init__(self, group=None, force_single=False, force_collectives=None):
+        """force_collectives (default: env ASB_FORCE_COLLECTIVES=1): take the multi-rank code path -- every
+        collective really issued -- even when the process group has a single rank.  That is how the RCCL wiring
+        (device tensors, stream ordering against the engine's kernels) is tested on a one-GPU box."""
         self.group = group
         self.dist = None
         self.rank, self.world = 0, 1
+        if force_collectives is None:
+            force_collectives = os.environ.get("ASB_FORCE_COLLECTIVES", "0") == "1"
         if not force_single:
             try:
                 import torch.distributed as dist
@@ -38,9 +45,10 @@ class Comm(object):
                 self.dist = dist
                 self.rank = dist.get_rank(group)
                 self.world = dist.get_world_size(group)
+        self.multi = self.world > 1 or bool(force_collectives and self.dist is not None)
         self._torch = None
         self._dev = None
-        if self.world > 1:
+        if self.multi:
             import torch
 
             self._torch = torch
@@ -58,7 +66,7 @@ class Comm(object):
     def allreduce_sum(self, values):
         """Sum of a small float64 vector over ranks (returned as ndarray)."""
         a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
-        if self.world == 1:
+        if not self.multi:
             return a
         t = self._torch.from_numpy(a).to(self._dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -66,7 +74,7 @@ class Comm(object):
 
     def allreduce_max(self, values):
         a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
-        if self.world == 1:
+        if not self.multi:
             return a
         t = self._torch.from_numpy(a).to(self._dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -75,7 +83,7 @@ class Comm(object):
     def all_gather_ints(self, values):
         """(world, len(values)) int64 array of every rank's small integer vector."""
         a = np.atleast_1d(np.asarray(values, dtype=np.int64)).copy()
-        if self.world == 1:
+        if not self.multi:
             return a[None]
         t = self._torch.from_numpy(a).to(self._dev)
         out = self._torch.empty(self.world * a.shape[0], dtype=self._torch.int64, device=self._dev)
@@ -95,7 +103,7 @@ class Comm(object):
         return self._dev if on_device else torch.device("cpu")
 
     def all_gather_into(self, out, inp):
-        if self.world == 1:
+        if not self.multi:
             out.copy_(inp)
             return
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
@@ -127,12 +135,12 @@ class Comm(object):
         return torch.zeros(int(n), dtype=torch.float64, device=self.exchange_device(on_device))
 
     def allreduce_tensor(self, t):
-        if self.world > 1:
+        if self.multi:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def global_argmax(self, idx, val):
         """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties."""
-        if self.world == 1:
+        if not self.multi:
             return idx
         torch = self._torch
         loc = torch.from_numpy(np.stack([val, idx.astype(np.float64)])).to(self._dev)
@@ -147,7 +155,7 @@ class Comm(object):
 
     def all_gather_rows(self, local, N, axis):
         """Concatenates per-rank blocks along ``axis`` (block sizes follow ``partition``)."""
-        if self.world == 1:
+        if not self.multi:
             return local
         torch = self._torch
         shards = self.shards(N)
@@ -162,5 +170,5 @@ class Comm(object):
         return np.moveaxis(np.concatenate(parts, axis=0), 0, axis)
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             self.dist.barrier(group=self.group)

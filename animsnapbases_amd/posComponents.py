@@ -118,16 +118,16 @@ class posComponents:  # Components == bases
         eng.deflate_begin(K, local, _lib.DEFLATE_PROJECT if mode == "project" else _lib.DEFLATE_RESIDUAL)
         v0, n_loc = snaps._shards[comm.rank]
 
-        if comm.world == 1 and not local and not self._stepwise_panels:
+        if not comm.multi and not local and not self._stepwise_panels:
             eng.run_global(0, K)
         elif mode == "project":
             self._project_multirank(K)
         else:
             rec = recs = None
-            if comm.world > 1:
+            if comm.multi:
                 rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
             for k in range(K):
-                if comm.world > 1:
+                if comm.multi:
                     eng.local_best(k, rec.data_ptr())
                     comm.all_gather_records(rec, recs)
                     eng.pick(k, recs.data_ptr(), comm.world)
@@ -203,7 +203,7 @@ class posComponents:  # Components == bases
                 if stalled > 3:
                     raise ArithmeticError("deflation made no progress at component %d" % k)
                 e, g = eng.panel_refresh(k)
-                both = comm.allreduce_max(np.eye(comm.world)[comm.rank] * e) if comm.world > 1 else np.array([e])
+                both = comm.allreduce_max(np.eye(comm.world)[comm.rank] * e) if comm.multi else np.array([e])
                 gids = comm.all_gather_ints([g])[:, 0]
                 order = sorted(range(comm.world), key=lambda r: (-both[r], gids[r]))
                 forced_next = int(gids[order[0]])
@@ -232,13 +232,13 @@ class posComponents:  # Components == bases
             raise ValueError("SPLOCS needs the mesh triangles (geodesic support maps)")
         eng.splocs_begin()
         Pbuf = Mbuf = None
-        if comm.world > 1:
+        if comm.multi:
             Pbuf, Mbuf = comm.new_gram_buffers(F, K, eng.device_exchange)
 
         def gram(want_norm=False):
             nx = eng.splocs_gram(Pbuf.data_ptr() if Pbuf is not None else None,
                                  Mbuf.data_ptr() if Mbuf is not None else None, want_norm)
-            if comm.world > 1:                 # partial Gram matrices: RCCL all-reduce (sum) over the ranks
+            if comm.multi:                 # partial Gram matrices: RCCL all-reduce (sum) over the ranks
                 comm.allreduce_tensor(Pbuf)
                 comm.allreduce_tensor(Mbuf)
             return nx
@@ -251,7 +251,7 @@ class posComponents:  # Components == bases
         trace, centres = [], []
         for it in range(num_iters_max):
             cidx, cval = eng.splocs_weights(*ptrs())                          # :144-156, :161
-            if comm.world > 1:
+            if comm.multi:
                 cidx = comm.global_argmax(cidx, cval)
             missing = [int(i) for i in dict.fromkeys(cidx.tolist()) if int(i) not in phi_cache]
             if missing:
@@ -317,7 +317,7 @@ class posComponents:  # Components == bases
         loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None)
         if self.param.q_orthogonal:
             Gbuf = None
-            if comm.world > 1:
+            if comm.multi:
                 Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange)
             eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
             if Gbuf is not None:

@@ -96,7 +96,7 @@ class posSnapshots:
         self.read()
         if self._engine is None:
             dev, stream = 0, None
-            if self._comm.world > 1:
+            if self._comm.multi:
                 import torch
                 dev = torch.cuda.current_device()
                 stream = torch.cuda.current_stream().cuda_stream
@@ -116,7 +116,7 @@ class posSnapshots:
         if self._device_data is not None:
             ptr_, F, N = self._device_data
             # the adopted tensor IS this rank's shard; global N is the sum over ranks
-            counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * N) if comm.world > 1 else np.array([N])
+            counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * N) if comm.multi else np.array([N])
             self._shards = []
             v0 = 0
             for n in counts.astype(np.int64):

@@ -73,6 +73,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    # native libraries (RCCL prints a version banner) write to fd 1: keep the real stdout for the ONE JSON line
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,9 +88,13 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ASB_FORCE_COLLECTIVES=1 (with --gpus 1): single-rank RCCL group, multi-rank protocol -- measures what the
+    # per-panel collectives and their host synchronisation cost on top of the kernels
+    forced = os.environ.get("ASB_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from animsnapbases_amd import Comm, partition, posComponents, posSnapshots
@@ -118,7 +127,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         eng.sync()
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,6 +161,7 @@ def main():
         # as the microarch guide prescribes; tools/summarise_pmc.py -> profiles/*_pmc_traffic.json).  Per pass over
         # the shard: k_project_lds takes ceil(F/1008) sweep launches per pass.
         traffic = None
+        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             kname = {2: "k_project_lds", 3: "k_project_l2<4, 2>"}.get(pk)
@@ -160,7 +170,6 @@ def main():
         except Exception:
             traffic = None
         mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
-        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
         nsweep = -(-((F + 15) // 16) // 63) if (getattr(eng, "mode", 0) == 1 and pk == 2) else 1   # k_project_lds: sweeps per pass
         alg_bytes = 24.0 * n_loc * F / nsweep
         avg_ms = kern_ms / max(launches, 1)
@@ -172,7 +181,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config4: synthetic U[-1,1) %d verts x %d frames, greedy-deflation PCA K=%d, "
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
-                       "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world},
+                       "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": ({2: "k_project_lds", 3: "k_project_l2<4,2>"}.get(pk, "k_project_mfma") +
@@ -184,8 +193,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, N, K, args.cpu_budget)
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,6 +31,7 @@ class ThreadComm(object):
         import torch
 
         self.hub, self.rank, self.world = hub, rank, hub.world
+        self.multi = self.world > 1
         self._torch = torch
         self._dev = torch.device("cuda", 0)
 
