@@ -18,10 +18,12 @@ Other basis types of the reference (``pod`` per-(p,d) torch SVD, ``pca_blocks``,
  and raise ``NotImplementedError``.
 """
 import csv
+from concurrent.futures import ThreadPoolExecutor
 import os
 import sys
 
 import numpy as np
+from scipy.linalg import eigh_tridiagonal
 
 from .distributed import Comm
 from .engine import HipEngine
@@ -230,22 +232,41 @@ class constraintsComponents:  # Components == bases
         ns = self.nonlinearSnapshots
         eng, comm = ns._engine, ns._comm
         F = ns.frs
+        K = min(int(self.param.deim_desired_num_components), F)
+        Gbuf = None
         if comm.multi:
             Gbuf = comm.new_buffer(F * F, eng.device_exchange)
             eng.pod_gram(Gbuf.data_ptr(), to_host=False)
             comm.allreduce_tensor(Gbuf)                      # partial Gram matrices: RCCL all-reduce
-            G = Gbuf.cpu().numpy().reshape(F, F)
+        on_dev = os.environ.get("ASB_POD_EIG", getattr(self, "pod_eig", "device")) == "device"
+        if on_dev and (Gbuf is None or Gbuf.is_cuda):
+            # F x F eigen-problem: Householder tridiagonalisation + back-transformation on the device (asb_eig.hip,
+            # ordered reductions -> identical on every rank), LAPACK MRRR on the tridiagonal matrix in between
+            if Gbuf is None:
+                eng.pod_gram(to_host=False)
+            gp = Gbuf.data_ptr() if Gbuf is not None else None
+            d, e = eng.sym_tridiag(F, gp)
+            if F > 2:
+                # the full spectrum (only the CSV / `singular_values` need it) is computed by a second LAPACK call
+                # in a worker thread while the K leading vectors are found and back-transformed
+                with ThreadPoolExecutor(1) as pool:
+                    all_vals = pool.submit(eigh_tridiagonal, d, e, eigvals_only=True, lapack_driver='sterf')
+                    _, Z = eigh_tridiagonal(d, e, select='i', select_range=(F - K, F - 1), lapack_driver='stemr')
+                    V = eng.sym_backtransform(F, Z[:, ::-1], gp)
+                    lam = all_vals.result()[::-1]
+            else:
+                lam, V = np.linalg.eigh(np.diag(d) + np.diag(e, 1) + np.diag(e, -1))
+                lam, V = lam[::-1], V[:, ::-1][:, :K]
         else:
-            G = eng.pod_gram()
-        G = 0.5 * (G + G.T)
-        lam, V = np.linalg.eigh(G)                           # host LAPACK on F x F; ascending
-        lam, V = lam[::-1], V[:, ::-1]
+            G = Gbuf.cpu().numpy().reshape(F, F) if Gbuf is not None else eng.pod_gram()
+            G = 0.5 * (G + G.T)
+            lam, V = np.linalg.eigh(G)                       # host LAPACK on F x F; ascending
+            lam, V = lam[::-1], V[:, ::-1]
         S = np.sqrt(np.maximum(lam, 0.0))
         self.singular_values = S
         if writer is not None:
             for ai, bi in zip(range(1, S.shape[0] + 1), S):
                 writer.writerow([ai, bi])
-        K = min(int(self.param.deim_desired_num_components), F)
         eng.pod_basis(np.ascontiguousarray(V[:, :K]), S[:K])
         self._comps, self._comps_on_device = None, True
         self.numComp = K

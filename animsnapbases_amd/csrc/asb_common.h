@@ -107,6 +107,8 @@ struct asb_ctx {
     double* la_vtmp = nullptr;
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
+    double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
+    int64_t td_n = 0;
 
     // ---- profiling of the dominant streaming kernel ----
     bool prof = false;
@@ -147,6 +149,9 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
             ASB_FAIL(ctx, ASB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
                      __FILE__, __LINE__);                                                    \
     } while (0)
+
+// G = X^T X (n x n, both triangles) for a tall row-major X: LDS-tiled f64 MFMA kernel (asb_linalg.hip)
+int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out);
 
 #define ASB_CHECK_LAUNCH(ctx) ASB_HIP(ctx, hipGetLastError())
 

@@ -1,0 +1,245 @@
+// asb_eig.hip -- symmetric eigen-problem of a LARGE dense matrix (config 5: the F x F Gram matrix of the
+// constraint snapshots, F = 4000) on the device: Householder tridiagonalisation A = Q T Q^T and the
+// back-transformation of T's eigenvectors.  The tridiagonal problem itself (O(n^2) for the values, O(n k) for k
+// vectors) is solved by the caller between the two calls.  Replaces the LAPACK `gesdd` of
+// constraintsComponents.py:307 together with asb_pod_gram / asb_pod_basis.  gfx950 only.
+//
+// Layout: A is n x n row-major with BOTH triangles valid (128 MB at n = 4000: resident in the 256 MB MALL).
+// Step j (j = 0 .. n-3) annihilates A[j+2.., j]:  H_j = I - tau_j v_j v_j^T, v_j[j+1] = 1, and updates the
+// trailing block A22 <- A22 - v w^T - w v^T with p = tau A22 v, w = p - (tau/2)(p.v) v.  Two launches per step:
+//   k_td_small (1 block)  : p.v, w_j, then the NEXT Householder vector from row j+1 of the not yet updated
+//                           matrix (row j+1 of A22 - v w^T - w v^T is formed on the fly), d[j+1], e[j+1], tau_{j+1}
+//   k_td_update (grid)    : trailing block update fused with the next step's symmetric mat-vec
+//                           p_{j+1} = tau_{j+1} A22' v_{j+1}  -- ONE read + ONE write of the trailing block per step
+// All reductions are ordered (no atomics): every rank of a multi-GPU run gets bit-identical T and vectors.
+// v_j is kept in row j of A (columns j+1..n-1), which the trailing block no longer touches.
+#include "asb_common.h"
+
+#define TD_T 1024
+
+// step `j` (j = -1: only the first Householder vector from row 0).  vcur = v_j, vnext = v_{j+1} (absolute row index).
+__global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n, int j, const double* __restrict__ p,
+                                                  const double* __restrict__ vcur, double* __restrict__ w,
+                                                  double* __restrict__ vnext, double* __restrict__ xbuf,
+                                                  double* __restrict__ tau, double* __restrict__ d, double* __restrict__ e) {
+    __shared__ double sh[TD_T / 64 * 2];
+    __shared__ double bc[4];
+    const int tid = threadIdx.x;
+    const int r0 = j + 1;                       // first row of the current trailing block
+    double wfirst = 0.0;
+    if (j >= 0) {
+        double acc[1] = {0.0};
+        for (int r = r0 + tid; r < n; r += TD_T) acc[0] += p[r] * vcur[r];
+        block_sum<1>(acc, sh);
+        const double half = 0.5 * tau[j] * acc[0];
+        for (int r = r0 + tid; r < n; r += TD_T) {
+            const double wr = p[r] - half * vcur[r];
+            w[r] = wr;
+            if (r == r0) bc[0] = wr;
+        }
+        __syncthreads();
+        wfirst = bc[0];
+    }
+    // row r0 of the updated matrix, columns c >= r0 (vcur[r0] == 1)
+    const double* row = A + (long long)r0 * n;
+    double acc2[1] = {0.0};
+    for (int c = r0 + tid; c < n; c += TD_T) {
+        double x = row[c];
+        if (j >= 0) x -= w[c] + wfirst * vcur[c];
+        xbuf[c] = x;
+        if (c == r0) bc[1] = x;                 // the new diagonal entry
+        if (c == r0 + 1) bc[2] = x;             // alpha
+        if (c >= r0 + 2) acc2[0] += x * x;
+    }
+    block_sum<1>(acc2, sh);
+    __syncthreads();
+    const double sigma = acc2[0];
+    if (tid == 0) d[r0] = bc[1];
+    if (r0 + 1 >= n) return;                    // (never launched that far)
+    const double alpha = bc[2];
+    if (r0 + 2 >= n) {                          // last 2 x 2 block: no reflector left
+        if (tid == 0) {
+            e[r0] = alpha;
+            tau[r0] = 0.0;
+            // d[n-1] = A[n-1][n-1] - 2 v[n-1] w[n-1]
+            double last = A[(long long)(n - 1) * n + (n - 1)];
+            if (j >= 0) last -= 2.0 * vcur[n - 1] * w[n - 1];
+            d[n - 1] = last;
+        }
+        return;
+    }
+    double beta, t, scale;
+    if (sigma == 0.0) { beta = alpha; t = 0.0; scale = 0.0; }
+    else {
+        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+        t = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    if (tid == 0) { e[r0] = beta; tau[r0] = t; }
+    double* arow = A + (long long)r0 * n;
+    for (int c = r0 + 1 + tid; c < n; c += TD_T) {
+        const double v = (c == r0 + 1) ? 1.0 : xbuf[c] * scale;
+        vnext[c] = v;
+        arow[c] = v;
+    }
+}
+
+// trailing block rows/cols >= r1 = j + 2:  A -= vcur w^T + w vcur^T (when `update`), then p[i] = taun * sum_c A[i][c] vnext[c]
+template <int R>
+__global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n, int r1, int update,
+                                                  const double* __restrict__ vcur, const double* __restrict__ w,
+                                                  const double* __restrict__ vnext, const double* __restrict__ tau_next,
+                                                  double* __restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const double tn = *tau_next;
+    for (int i0 = r1 + wave * R; i0 < n; i0 += nwaves * R) {
+        double vi[R], wi[R], acc[R];
+        double* rowp[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = (i0 + q < n) ? i0 + q : n - 1;      // clamped rows repeat the last one (not stored twice: see below)
+            vi[q] = update ? vcur[i] : 0.0;
+            wi[q] = update ? w[i] : 0.0;
+            acc[q] = 0.0;
+            rowp[q] = A + (long long)i * n;
+        }
+        for (int c = r1 + lane; c < n; c += 64) {
+            const double vc = update ? vcur[c] : 0.0, wc = update ? w[c] : 0.0, vn = vnext[c];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double a = rowp[q][c];
+                if (update) {
+                    a -= vi[q] * wc + wi[q] * vc;
+                    if (i0 + q < n) rowp[q][c] = a;
+                }
+                acc[q] += a * vn;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double s = wave_sum(acc[q]);
+            if (lane == 0 && i0 + q < n) p[i0 + q] = tn * s;
+        }
+    }
+}
+
+// Z (n x k, row-major) <- Q Z with Q = H_0 H_1 ... H_{n-3}: one WAVE per column, the column in LDS,
+// reflectors applied last to first; v_j is read from row j of A (shared by all waves through L2).
+__global__ __launch_bounds__(256) void k_td_back(const double* __restrict__ A, const double* __restrict__ tau, int n,
+                                                const double* __restrict__ Z, int k, double* __restrict__ V, int wpb) {
+    extern __shared__ double zsh[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * wpb + wv;
+    if (wv >= wpb || col >= k) return;
+    double* z = zsh + (size_t)wv * n;
+    for (int r = lane; r < n; r += 64) z[r] = Z[(long long)r * k + col];
+    for (int j = n - 3; j >= 0; --j) {
+        const double t = tau[j];
+        if (t == 0.0) continue;
+        const double* v = A + (long long)j * n;
+        // lane l owns the rows r = l (mod 64) for every reflector: no z entry is ever touched by two lanes
+        const int rs = j + 1 + ((lane - (j + 1)) & 63);
+        double acc = 0.0;
+        for (int r = rs; r < n; r += 64) acc += v[r] * z[r];
+        const double s = t * wave_sum(acc);
+        for (int r = rs; r < n; r += 64) z[r] -= s * v[r];
+    }
+    for (int r = lane; r < n; r += 64) V[(long long)r * k + col] = z[r];
+}
+
+// A <- (A + A^T) / 2: the Gram tiles above and below the diagonal come from different MFMA tiles
+__global__ __launch_bounds__(256) void k_symmetrize(double* __restrict__ A, int n) {
+    const long long total = (long long)n * n;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        if (j > i) {
+            const double m = 0.5 * (A[e] + A[(long long)j * n + i]);
+            A[e] = m;
+            A[(long long)j * n + i] = m;
+        }
+    }
+}
+
+extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host, double* e_host) {
+    if (!ctx || !d_host || !e_host || n64 < 1) return ASB_ERR_ARG;
+    double* A = A_dev ? A_dev : ctx->pod_g;
+    if (!A) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_sym_tridiag: no matrix (run asb_pod_gram first or pass A_dev)");
+    if (n64 > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: n = %lld too large", (long long)n64);
+    const int n = (int)n64;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->td_work, (size_t)8 * n))) return rc;
+    double* vb0 = ctx->td_work;
+    double* vb1 = vb0 + n;
+    double* w = vb1 + n;
+    double* p = w + n;
+    double* xbuf = p + n;
+    double* tau = xbuf + n;
+    double* d = tau + n;
+    double* e = d + n;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->td_work, 0, (size_t)8 * n * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_symmetrize, dim3(2048), dim3(256), 0, ctx->stream, A, n);
+    if (n == 1) {
+        ASB_HIP(ctx, hipMemcpyAsync(d_host, A, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->td_n = n;
+        return ASB_OK;
+    }
+    if (n == 2) {
+        double h[4];
+        ASB_HIP(ctx, hipMemcpyAsync(h, A, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        d_host[0] = h[0]; d_host[1] = h[3]; e_host[0] = h[2];
+        ctx->td_n = n;
+        return ASB_OK;
+    }
+    // d[0] is never touched by a reflector
+    ASB_HIP(ctx, hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    constexpr int R = 4;
+    for (int j = -1; j <= n - 3; ++j) {
+        double* vcur = (j & 1) ? vb1 : vb0;          // j = -1 -> vb1 (unused)
+        double* vnext = ((j + 1) & 1) ? vb1 : vb0;
+        // k_td_small(j) writes d[j+1]; for j = -1 it would overwrite d[0] with the same value A[0][0]
+        hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, vcur, w, vnext, xbuf, tau, d, e);
+        if (j + 1 <= n - 3) {
+            const int r1 = j + 2, rows = n - r1;
+            int grid = (rows + 4 * R - 1) / (4 * R);
+            if (grid > 2048) grid = 2048;
+            if (grid < 1) grid = 1;
+            hipLaunchKernelGGL((k_td_update<R>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
+                               tau + (j + 1), p);
+        }
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(d_host, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(e_host, e, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->td_n = n;
+    return ASB_OK;
+}
+
+extern "C" int asb_sym_backtransform(asb_ctx* ctx, const double* A_dev, int64_t n64, const double* Z_host, int64_t k64,
+                                     double* V_host) {
+    if (!ctx || !Z_host || !V_host || n64 < 1 || k64 < 1) return ASB_ERR_ARG;
+    const double* A = A_dev ? A_dev : ctx->pod_g;
+    if (!A || !ctx->td_work || ctx->td_n != n64)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_sym_backtransform: asb_sym_tridiag has not been run on an n = %lld matrix", (long long)n64);
+    const int n = (int)n64, k = (int)k64;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->td_z, (size_t)2 * n * k))) return rc;
+    double* Z = ctx->td_z;
+    double* V = Z + (size_t)n * k;
+    ASB_HIP(ctx, hipMemcpyAsync(Z, Z_host, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double* tau = ctx->td_work + (size_t)5 * n;
+    int wpb = (int)((size_t)(160 * 1024 - 1024) / ((size_t)n * sizeof(double)));
+    if (wpb < 1) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_backtransform: n = %d does not fit one LDS column", n);
+    if (wpb > 4) wpb = 4;
+    const size_t lds = (size_t)wpb * n * sizeof(double);
+    if (lds > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_td_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_td_back, dim3((k + wpb - 1) / wpb), dim3(256), lds, ctx->stream, A, tau, n, Z, k, V, wpb);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(V_host, V, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}

@@ -51,6 +51,129 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const double* __restrict__ pa
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_syrk_tn:  G = X^T X for a tall X (R x n, row stride ld) -- the F x F Gram matrix of the POD (config 5,
+// 2 R n^2 flop: the one place on the path where the contraction is really dense, so this is the MFMA kernel).
+// Block = 4 waves, 128 x 128 output tile (only tiles on or above the diagonal), each wave a 64 x 64 sub-tile =
+// 4 x 4 v_mfma_f64_16x16x4_f64 accumulators.  The contraction runs over rows in stages of 16: both 16 x 128 operand
+// slabs go global -> registers -> LDS (double-buffered, one barrier per stage), row stride 144 doubles so that the four
+// k-rows a wave reads per instruction fall into different bank halves.  blockIdx.y = row slab (split-K into
+// `part`, summed in fixed order by k_syrk_finish, which also mirrors the lower triangle).
+// --------------------------------------------------------------------------------------
+#define SY_BM 128
+#define SY_KC 16
+#define SY_LD 144
+__global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X, long long ld, long long R, int n, long long slab,
+                                                   double* __restrict__ part, int nb) {
+    __shared__ double As[2][SY_KC][SY_LD];
+    __shared__ double Bs[2][SY_KC][SY_LD];
+    int t = blockIdx.x, ib = 0;
+    while (t >= nb - ib) { t -= nb - ib; ++ib; }
+    const int jb = ib + t;
+    const int i0 = ib * SY_BM, j0 = jb * SY_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
+    const long long r_begin = (long long)blockIdx.y * slab;
+    long long r_end = r_begin + slab;
+    if (r_end > R) r_end = R;
+    const int ca = i0 + 2 * lane, cb = j0 + 2 * lane;
+    const bool oka = ca < ld, okb = cb < ld;
+    double2 ra[4], rb[4];
+    auto fetch = [&](long long r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long r = r0 + wave + 4 * q;
+            const bool in = r < r_end;
+            ra[q] = (in && oka) ? *reinterpret_cast<const double2*>(X + r * ld + ca) : make_double2(0.0, 0.0);
+            rb[q] = (in && okb) ? *reinterpret_cast<const double2*>(X + r * ld + cb) : make_double2(0.0, 0.0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<double2*>(&As[buf][wave + 4 * q][2 * lane]) = ra[q];
+            *reinterpret_cast<double2*>(&Bs[buf][wave + 4 * q][2 * lane]) = rb[q];
+        }
+    };
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    fetch(r_begin);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (long long r0 = r_begin; r0 < r_end; r0 += SY_KC) {
+        const bool more = r0 + SY_KC < r_end;
+        if (more) fetch(r0 + SY_KC);
+#pragma unroll
+        for (int ks = 0; ks < SY_KC / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = As[cur][ks * 4 + g][wi * 64 + q * 16 + li];
+                b[q] = Bs[cur][ks * 4 + g][wj * 64 + q * 16 + li];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double* o = part + (long long)blockIdx.y * n * n;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oi = i0 + wi * 64 + x * 16 + g + 4 * q, oj = j0 + wj * 64 + y * 16 + li;
+                if (oi < n && oj < n) o[(long long)oi * n + oj] = acc[x][y][q];
+            }
+}
+
+// out[i][j] = out[j][i] = sum_s part[s][i][j] over the tiles on/above the diagonal (fixed summation order)
+__global__ __launch_bounds__(256) void k_syrk_finish(const double* __restrict__ part, int S, int n, double* __restrict__ out) {
+    const long long total = (long long)n * n;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        if (j / SY_BM < i / SY_BM) continue;
+        double s = 0.0;
+        for (int q = 0; q < S; ++q) s += part[(long long)q * total + e];
+        out[e] = s;
+        if (j / SY_BM > i / SY_BM) out[(long long)j * n + i] = s;
+    }
+}
+
+// G (n x n) = X^T X, X = R rows of stride ld (columns >= n up to ld must be readable: the zero padding of the rows)
+int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out) {
+    const int nb = (n + SY_BM - 1) / SY_BM;
+    const int tiles = nb * (nb + 1) / 2;
+    // enough blocks for >= 8 rounds of the chip's 512 resident blocks, slabs of at least 512 rows
+    int S = (8 * 512 + tiles - 1) / tiles;
+    const long long maxS = (R + 511) / 512;
+    if (S > maxS) S = (int)(maxS < 1 ? 1 : maxS);
+    if (S > 64) S = 64;
+    long long slab = ((R + S - 1) / S + SY_KC - 1) / SY_KC * SY_KC;
+    if (slab < SY_KC) slab = SY_KC;
+    S = (int)((R + slab - 1) / slab);
+    if (S < 1) S = 1;
+    const size_t need = (size_t)S * n * n;
+    if (need > ctx->la_part_cap) {
+        int rc = asb_alloc(ctx, &ctx->la_part, need);
+        if (rc) return rc;
+        ctx->la_part_cap = need;
+    }
+    hipLaunchKernelGGL(k_syrk_tn, dim3(tiles, S), dim3(256), 0, ctx->stream, X, ld, R, n, slab, ctx->la_part, nb);
+    hipLaunchKernelGGL(k_syrk_finish, dim3(2048), dim3(256), 0, ctx->stream, ctx->la_part, S, n, out);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 __global__ __launch_bounds__(256) void k_transpose_small(const double* __restrict__ in, long long rows, long long cols,
                                                          double* __restrict__ out) {
     __shared__ double tile[32][33];

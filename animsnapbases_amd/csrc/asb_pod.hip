@@ -24,7 +24,7 @@ extern "C" int asb_pod_gram(asb_ctx* ctx, double* G_dev, double* G_host) {
         if ((rc = asb_alloc(ctx, &ctx->pod_g, (size_t)F * F))) return rc;
         G = ctx->pod_g;
     }
-    if ((rc = asb_gemm_tn(ctx, ctx->X, ctx->Fp, ctx->X, ctx->Fp, 3 * ctx->n_loc, (int)F, (int)F, G))) return rc;
+    if ((rc = asb_syrk_tn(ctx, ctx->X, ctx->Fp, 3 * ctx->n_loc, (int)F, G))) return rc;
     if (G_host) {
         ASB_HIP(ctx, hipMemcpyAsync(G_host, G, (size_t)F * F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -294,6 +294,21 @@ class HipEngine(object):
         self._ck(self.lib.asb_pod_basis(self.h, ptr(V), ptr(sigma), sigma.shape[0]))
         self.K = int(sigma.shape[0])
 
+    def sym_tridiag(self, n, A_dev_ptr=None):
+        """Householder tridiagonalisation of the n x n symmetric device matrix (default: the POD Gram matrix)."""
+        d, e = np.empty(n), np.empty(max(n - 1, 0))
+        self._ck(self.lib.asb_sym_tridiag(self.h, ctypes.c_void_p(A_dev_ptr) if A_dev_ptr else None, int(n), ptr(d),
+                                          ptr(e) if n > 1 else ptr(np.empty(1))))
+        return d, e
+
+    def sym_backtransform(self, n, Z, A_dev_ptr=None):
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        assert Z.shape[0] == n
+        V = np.empty_like(Z)
+        self._ck(self.lib.asb_sym_backtransform(self.h, ctypes.c_void_p(A_dev_ptr) if A_dev_ptr else None, int(n), ptr(Z),
+                                                int(Z.shape[1]), ptr(V)))
+        return V
+
     def snapshots_affine(self, inv_scale, add_mean, rowscale_loc=None):
         if rowscale_loc is not None:
             rowscale_loc = np.ascontiguousarray(rowscale_loc, dtype=np.float64)

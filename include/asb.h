@@ -208,6 +208,15 @@ int asb_align_frames(asb_ctx* ctx, double* frames, int64_t F, int64_t N, int rig
  * vectors  comps[i] = A V[:, i] / sigma[i]  (V host F x K, sigma host K) as the device-resident basis. */
 int asb_pod_gram(asb_ctx* ctx, double* G_dev, double* G_host);
 int asb_pod_basis(asb_ctx* ctx, const double* V, const double* sigma, int64_t K);
+
+/* The F x F symmetric eigen-problem of the POD (the `svd` of constraintsComponents.py:307 in Gram form) on the
+ * device.  asb_sym_tridiag: Householder tridiagonalisation A = Q T Q^T of the n x n symmetric matrix A_dev
+ * (row-major, both triangles; NULL = the Gram matrix asb_pod_gram left in the context).  A is overwritten with
+ * the reflectors; d_host (n) / e_host (n-1) receive T's diagonal / off-diagonal.  Ordered reductions only:
+ * bit-identical on every rank.  The caller solves the tridiagonal problem (O(n^2)).
+ * asb_sym_backtransform: V = Q Z for k eigenvectors Z of T (host, n x k row-major) -> V_host (n x k). */
+int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n, double* d_host, double* e_host);
+int asb_sym_backtransform(asb_ctx* ctx, const double* A_dev, int64_t n, const double* Z_host, int64_t k, double* V_host);
 /* :421-428 / :440-443 the reference also restores the snapshot tensor:
  * X <- (X * inv_scale + mean) * rowscale[v]   (rowscale host n_loc or NULL) */
 int asb_snapshots_affine(asb_ctx* ctx, double inv_scale, int add_mean, const double* rowscale);

@@ -638,3 +638,49 @@ def test_local_support_with_device_geodesics(monkeypatch):
     print("CG iterations", snaps.compute_geodesic_distance.last_iterations, relerr(comp.comps, g["comps"]))
     assert comp.selected_vertices.tolist() == g["idx"].tolist()
     assert relerr(comp.comps, g["comps"]) < 1e-7 and relerr(comp.weigs, g["weigs"]) < TOL
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 2), (3, 2), (5, 5), (64, 7), (65, 65), (130, 20), (777, 33), (1500, 64)])
+def test_device_symmetric_eigensolver(n, k):
+    """asb_sym_tridiag + LAPACK MRRR on T + asb_sym_backtransform against numpy.linalg.eigh: T is orthogonally
+    similar to A (same spectrum), and the back-transformed vectors are A's eigenvectors."""
+    import torch
+    from scipy.linalg import eigh_tridiagonal
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, max(n // 2, 1)))
+    A = B @ B.T + 1e-3 * np.diag(rng.uniform(size=n))          # low rank + small diagonal: clustered small eigenvalues
+    A = 0.5 * (A + A.T)
+    lam_ref, V_ref = np.linalg.eigh(A)
+    e = HipEngine(0, stream=0)
+    Ad = torch.from_numpy(A.copy()).cuda()
+    d, off = e.sym_tridiag(n, Ad.data_ptr())
+    if n == 1:
+        assert d[0] == A[0, 0]
+        e.close()
+        return
+    lam = eigh_tridiagonal(d, off, eigvals_only=True)
+    assert np.allclose(lam, lam_ref, rtol=0, atol=1e-12 * abs(lam_ref).max())
+    if n > 2:
+        lamk, Z = eigh_tridiagonal(d, off, select='i', select_range=(n - k, n - 1), lapack_driver='stemr')
+        V = e.sym_backtransform(n, Z, Ad.data_ptr())
+        assert np.allclose(V.T @ V, np.eye(k), atol=1e-11)
+        assert np.abs(A @ V - V * lamk[None]).max() < 1e-11 * abs(lam_ref).max()
+    e.close()
+
+
+@pytest.mark.parametrize("ep,F", [(5, 3), (211, 130), (777, 300), (1501, 517)])
+def test_pod_gram_mfma_tiles(ep, F):
+    """G = A^T A from the LDS-tiled f64-MFMA kernel (128 x 128 tiles above the diagonal, mirrored; split over row
+    slabs) against NumPy, at sizes that leave partial tiles, partial 16-row stages and several slabs."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(ep + F)
+    frames = rng.normal(size=(F, ep, 3))
+    e = HipEngine(0)
+    e.upload(frames, 0, ep)
+    G = e.pod_gram()
+    e.close()
+    A = frames.reshape(F, -1)
+    ref = A @ A.T
+    assert np.array_equal(G, G.T)
+    assert np.abs(G - ref).max() < 1e-12 * np.abs(ref).max()
