@@ -317,6 +317,7 @@ class constraintsComponents:  # Components == bases
         # Here the inverse of V[Pt,:k,i] is carried along by the bordering (Schur-complement) update, O(k^2)
         # per step, and checked: if the solve's residual is not at rounding level the step falls back to lstsq.
         Minv = [np.zeros((0, 0)) for _ in range(3)]
+        fro2 = np.zeros((3, K))
         for k in range(K):
             coef = None
             if k > 0:
@@ -343,7 +344,7 @@ class constraintsComponents:  # Components == bases
                                 Minv[i] = None
                     x = Minv[i] @ b if (Minv[i] is not None and Minv[i].shape[0] == k) else None
                     if x is None or not np.all(np.isfinite(x)) or \
-                            np.linalg.norm(M @ x - b) > 1e-10 * (np.linalg.norm(b) + np.linalg.norm(M) * np.linalg.norm(x)):
+                            np.linalg.norm(M @ x - b) > 1e-10 * (np.linalg.norm(b) + np.sqrt(fro2[i, k - 1]) * np.linalg.norm(x)):
                         x = np.linalg.lstsq(M, b, rcond=None)[0]             # the reference's call (:829)
                         try:
                             Minv[i] = np.linalg.inv(M)
@@ -361,6 +362,10 @@ class constraintsComponents:  # Components == bases
             if comm.multi:
                 row = comm.allreduce_sum(np.zeros((K, 3)) if row is None else row).reshape(K, 3)
             rows[k] = row
+            # running ||V[Pt[:m], :m, i]||_F^2 for the residual test above: the leading (k+1) x (k+1) block gains
+            # row k (columns <= k) and column k (rows < k)
+            for i in range(3):
+                fro2[i, k] = (fro2[i, k - 1] if k else 0.0) + np.sum(rows[k, :k + 1, i] ** 2) + np.sum(rows[:k, k, i] ** 2)
             alpha = idx // p_size
             print(k, alpha)
             Pt.append(idx)
