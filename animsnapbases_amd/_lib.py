@@ -63,6 +63,7 @@ PROTOTYPES = {
     "asb_components_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
     "asb_geodesic_setup": (c_int, [ctypes.c_void_p, c_int, c_int] + [c_dp] * 14),
     "asb_geodesic_solve": (c_int, [ctypes.c_void_p, c_dp, c_int, c_dbl, c_dp, c_dp]),
+    "asb_geodesic_dense_setup": (c_int, [ctypes.c_void_p]),
     "asb_align_frames": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_int, c_dp]),
     "asb_pod_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_pod_basis": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64]),
@@ -80,6 +81,7 @@ PROTOTYPES = {
                                      ctypes.POINTER(c_dbl)]),
     "asb_splocs_results": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_test_eig3": (None, [c_dp, c_dp]),
+    "asb_test_spd_inverse": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp]),
 }
 
 

@@ -107,6 +107,7 @@ struct asb_ctx {
     double* la_vtmp = nullptr;
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
+    double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
     double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
     int64_t td_n = 0;
 
@@ -150,6 +151,10 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
                      __FILE__, __LINE__);                                                    \
     } while (0)
 
+// C = beta C + alpha A B (row-major, even dimensions; asb_dense.hip) and the in-place SPD inverse built on it
+int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
+                int N, int Kc, double alpha, double beta);
+int asb_dense_spd_inverse(asb_ctx* ctx, double* M, int np);
 // G = X^T X (n x n, both triangles) for a tall row-major X: LDS-tiled f64 MFMA kernel (asb_linalg.hip)
 int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out);
 

@@ -26,6 +26,10 @@ struct asb_geo {
     double *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *z = nullptr, *g = nullptr, *b = nullptr;
     double *part = nullptr, *sc = nullptr;         // (nblk, 64) partial sums; scalars rz[64], alpha[64], ...
     int nblk = 0;
+    // dense mode (asb_geodesic_dense_setup): explicit inverses, np = roundup(n, 16), ld np
+    bool dense = false;
+    int np = 0;
+    double *Hinv = nullptr, *Pinv = nullptr;
 };
 
 // Y = A X  (+ optional per-column partial sums of X .* Y for CG's p^T A p)
@@ -265,6 +269,80 @@ static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, 
     return ASB_OK;
 }
 
+// ------------------------------------------------------------------------------------- dense mode
+// leading n x n block <- shift (the rank-one gauge term), identity on the padding; the rest of `out` is already zero
+__global__ __launch_bounds__(256) void k_dense_init(int n, int np, double shift, double* __restrict__ out) {
+    const long long total = (long long)np * np;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / np), c = (int)(e % np);
+        if (r < n && c < n) { if (shift != 0.0) out[e] = shift; }
+        else if (r == c) out[e] = 1.0;
+    }
+}
+
+// out += CSR matrix (one wave per row; a CSR row holds each column once)
+__global__ __launch_bounds__(256) void k_csr_to_dense(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                      const double* __restrict__ vals, int n, int np, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wid; r < n; r += gridDim.x * 4) {
+        double* row = out + (long long)r * np;
+        for (int j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) row[colidx[j]] += vals[j];
+    }
+}
+
+// heat step with the explicit inverse: u_c = column src_c of (A - tL)^-1 = its row (symmetric); x is (np x 64) node-major
+__global__ __launch_bounds__(256) void k_gather_sources(const double* __restrict__ Hinv, int np, const long long* __restrict__ src,
+                                                        int nsrc, double* __restrict__ x) {
+    const long long total = (long long)np * GB;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % GB);
+        const long long i = e / GB;
+        x[e] = (c < nsrc) ? Hinv[src[c] * np + i] : 0.0;
+    }
+}
+
+// Replaces the two PCG solves by explicit inverses (blocked Gauss-Jordan, asb_dense.hip): (A - tL)^-1 and
+// (-L + (gamma / n) 1 1^T)^-1 -- the rank-one term fixes the constant null vector of the Laplacian, which the final
+// phi -= min(phi) removes again, so the distances are those of the singular system (utils/support.py:171, 205-206).
+extern "C" int asb_geodesic_dense_setup(asb_ctx* ctx) {
+    if (!ctx || !ctx->geo) return ASB_ERR_ARG;
+    asb_geo* G = ctx->geo;
+    const int n = G->n, np = (n + 15) / 16 * 16;
+    if (n > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "dense geodesics: %d vertices are too many for explicit inverses", n);
+    int rc;
+    if ((rc = asb_alloc(ctx, &G->Hinv, (size_t)np * np))) return rc;
+    if ((rc = asb_alloc(ctx, &G->Pinv, (size_t)np * np))) return rc;
+    const size_t nv = (size_t)np * GB;             // vectors get the padded length (padding rows stay zero)
+    double** vecs[] = {&G->x, &G->b};
+    for (auto v : vecs) {
+        if ((rc = asb_alloc(ctx, v, nv))) return rc;
+        ASB_HIP(ctx, hipMemsetAsync(*v, 0, nv * sizeof(double), ctx->stream));
+    }
+    // gamma = mean diagonal of -L keeps the added eigenvalue inside the spectrum
+    std::vector<double> dl((size_t)n);
+    ASB_HIP(ctx, hipMemcpyAsync(dl.data(), G->dlap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double gamma = 0.0;
+    for (double v : dl) gamma += v;
+    gamma /= n;
+    if (!(gamma > 0.0)) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "dense geodesics: the Laplacian has a non-positive mean diagonal");
+    const int grid = (np + 3) / 4 < 2048 ? (np + 3) / 4 : 2048;
+    ASB_HIP(ctx, hipMemsetAsync(G->Hinv, 0, (size_t)np * np * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(G->Pinv, 0, (size_t)np * np * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_dense_init, dim3(2048), dim3(256), 0, ctx->stream, n, np, 0.0, G->Hinv);
+    hipLaunchKernelGGL(k_dense_init, dim3(2048), dim3(256), 0, ctx->stream, n, np, gamma / n, G->Pinv);
+    hipLaunchKernelGGL(k_csr_to_dense, dim3(grid), dim3(256), 0, ctx->stream, G->heat.rowptr, G->heat.colidx, G->heat.vals, n, np,
+                       G->Hinv);
+    hipLaunchKernelGGL(k_csr_to_dense, dim3(grid), dim3(256), 0, ctx->stream, G->lap.rowptr, G->lap.colidx, G->lap.vals, n, np,
+                       G->Pinv);
+    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = asb_dense_spd_inverse(ctx, G->Hinv, np))) return rc;
+    if ((rc = asb_dense_spd_inverse(ctx, G->Pinv, np))) return rc;
+    G->dense = true;
+    G->np = np;
+    return ASB_OK;
+}
+
 // distances from each of nsrc (<= 64) source vertices: out (nsrc, n), host.  iters (optional): CG iterations of the two solves.
 extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters) {
     if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !out) return ASB_ERR_ARG;
@@ -272,16 +350,20 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
     asb_geo* G = ctx->geo;
     const int n = G->n;
     int rc;
-    if ((rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
+    if (!G->dense && (rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
     long long* src_dev = nullptr;
     if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
     src_dev = ctx->geo_src;
     ASB_HIP(ctx, hipMemcpyAsync(src_dev, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
     // heat step: (A - tL) u = delta
-    ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
     int it1 = 0, it2 = 0;
-    if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1))) return rc;
+    if (G->dense) {
+        hipLaunchKernelGGL(k_gather_sources, dim3(1024), dim3(256), 0, ctx->stream, G->Hinv, G->np, src_dev, nsrc, G->x);
+    } else {
+        ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
+        if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1))) return rc;
+    }
     // gradient, normalise, divergence
     const int gb = (G->m3 + 3) / 4 < 1024 ? (G->m3 + 3) / 4 : 1024;
     hipLaunchKernelGGL(k_spmm64, dim3(gb), dim3(256), 0, ctx->stream, G->grad.rowptr, G->grad.colidx, G->grad.vals, G->m3, G->x, G->g,
@@ -291,7 +373,9 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
                        (double*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
-    if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2))) return rc;
+    if (G->dense) {        // y = (-L + gamma/n 1 1^T)^-1 div : one (np x np) by (np x 64) product
+        if ((rc = asb_gemm_nn(ctx, G->Pinv, G->np, G->b, GB, G->x, GB, G->np, GB, G->np, 1.0, 0.0))) return rc;
+    } else if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2))) return rc;
     // phi = -y; phi -= min(phi)  ==  max(y) - y : done by negating in place first
     hipLaunchKernelGGL(k_scale_vec, dim3(G->nblk), dim3(256), 0, ctx->stream, G->x, (long long)n * GB, -1.0);
     if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;

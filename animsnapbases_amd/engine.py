@@ -248,12 +248,14 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ post-processing
     # ------------------------------------------------------------------ device geodesics
-    def geodesic_setup(self, heat, lap, grad, div):
-        """heat, lap, grad, div: scipy CSR matrices (float64)."""
+    def geodesic_setup(self, heat, lap, grad, div, dense=False):
+        """heat, lap, grad, div: scipy CSR matrices (float64).  dense: invert the two SPD systems explicitly on the
+        device (asb_geodesic_dense_setup) instead of solving them by PCG per batch."""
         keep = []
 
         def csr(m):
             m = m.tocsr()
+            m.sum_duplicates()
             m.sort_indices()
             rp, ci, v = m.indptr.astype(np.int32), m.indices.astype(np.int32), np.ascontiguousarray(m.data, dtype=np.float64)
             keep.extend([rp, ci, v])
@@ -265,6 +267,8 @@ class HipEngine(object):
         args = csr(heat) + csr(lap) + csr(grad) + csr(div) + [dh.ctypes.data, dl.ctypes.data]
         self._ck(self.lib.asb_geodesic_setup(self.h, int(n), int(m3), *args))
         self._geo_n = n
+        if dense:
+            self._ck(self.lib.asb_geodesic_dense_setup(self.h))
 
     def geodesic_solve(self, sources, tol=1e-13):
         src = np.ascontiguousarray(sources, dtype=np.int64)

@@ -55,9 +55,11 @@ class GeodesicDistanceComputation(object):
     """Callable: ``phi = geo(idx)`` -> (N,) geodesic distance from vertex ``idx``
     (shifted so that min(phi) == 0, utils/support.py:206)."""
 
-    def __init__(self, verts, tris, m=10.0, engine=None, tol=1e-13):
-        """engine: a HipEngine to run the solves on the GPU (``asb_geodesic_*``: batched Jacobi-PCG, 64 sources
-        at a time, relative residual ``tol``); None = host SuperLU like the reference."""
+    def __init__(self, verts, tris, m=10.0, engine=None, tol=1e-13, backend="pcg"):
+        """engine: a HipEngine to run the solves on the GPU (``asb_geodesic_*``, 64 sources at a time); None = host
+        SuperLU like the reference.  backend (with an engine): "dense" = the two SPD matrices are inverted once on the
+        device (blocked Gauss-Jordan on f64 MFMA, N <= 46 000) and a query is a gather plus one dense product;
+        "pcg" = batched Jacobi-PCG to relative residual ``tol`` (experimental)."""
         verts = np.asarray(verts, dtype=np.float64)
         tris = np.asarray(tris, dtype=np.int64)
         n, M = verts.shape[0], tris.shape[0]
@@ -99,8 +101,10 @@ class GeodesicDistanceComputation(object):
         self._L = L
         self._engine = None
         self.last_iterations = None
+        self._cache = {}                    # source vertex -> its distance field (solve_many)
+        self.cache_bytes = 2 << 30
         if engine is not None:          # device backend: batched Jacobi-PCG instead of the SuperLU factorisations
-            engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D)
+            engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D, dense=(backend == "dense"))
             self._engine = engine
             self._tol = tol
             return
@@ -123,26 +127,32 @@ class GeodesicDistanceComputation(object):
         return phi - phi.min(axis=0)
 
     def __call__(self, idx):
-        if self._engine is not None:
-            return self.solve_many([int(idx)])[0]
-        u0 = np.zeros(self.n)
-        u0[idx] = 1.0
-        return self._field(self._heat.solve(u0))
+        return self.solve_many([int(idx)])[0].copy()
 
     def solve_many(self, idxs):
-        """Distances from each vertex in ``idxs``: (len(idxs), n).  One multi-RHS solve per
-        distinct vertex set (repeated indices are solved once)."""
+        """Distances from each vertex in ``idxs``: (len(idxs), n).  One multi-RHS solve for the vertices not asked
+        for before: the field of a source never changes, and SPLOCS asks for the same centres again in every outer
+        iteration once they have settled (posComponents.py:158-165), so solved fields are kept (<= ``cache_bytes``)."""
         idxs = np.asarray(idxs, dtype=np.int64)
-        uniq, inv = np.unique(idxs, return_inverse=True)
-        if self._engine is not None:
-            parts, its = [], []
-            for b in range(0, uniq.size, 64):
-                phi, it = self._engine.geodesic_solve(uniq[b:b + 64], self._tol)
-                parts.append(phi)
-                its.append(it)
-            self.last_iterations = its
-            return np.ascontiguousarray(np.concatenate(parts, axis=0)[inv])
-        E = np.zeros((self.n, uniq.size))
-        E[uniq, np.arange(uniq.size)] = 1.0
-        phi = self._field(self._heat.solve(E))
-        return np.ascontiguousarray(phi.T[inv])
+        uniq = np.unique(idxs)
+        new = np.array([i for i in uniq.tolist() if i not in self._cache], dtype=np.int64)
+        if new.size:
+            if self._engine is not None:
+                parts, its = [], []
+                for b in range(0, new.size, 64):
+                    phi, it = self._engine.geodesic_solve(new[b:b + 64], self._tol)
+                    parts.append(phi)
+                    its.append(it)
+                self.last_iterations = its
+                fields = np.concatenate(parts, axis=0)
+            else:
+                E = np.zeros((self.n, new.size))
+                E[new, np.arange(new.size)] = 1.0
+                fields = np.ascontiguousarray(self._field(self._heat.solve(E)).T)
+            room = max(int(self.cache_bytes // (8 * self.n)) - len(self._cache), 0)
+            local = {}
+            for q, i in enumerate(new.tolist()):
+                (self._cache if q < room else local)[i] = fields[q]
+        else:
+            local = {}
+        return np.stack([self._cache[i] if i in self._cache else local[i] for i in idxs.tolist()])

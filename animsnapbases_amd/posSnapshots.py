@@ -18,6 +18,9 @@ from .geodesic import GeodesicDistanceComputation
 from .utils import log_time
 
 
+DENSE_GEODESIC_MAX_VERTS = 24000
+
+
 class posSnapshots:
     """Position snapshots: reads aligned ``(F, N, 3)`` frames, optionally mass-weights and
     standardises them (posSnapshots.py:26-31)."""
@@ -138,8 +141,15 @@ class posSnapshots:
         # geodesics on the NON-weighted shape (:96-99); host SciPy
         if self.tris is not None and self.verts is not None:
             shape0 = self.verts[0] if self.rest_shape == "first" else np.mean(self.verts, axis=0)
-            on_dev = os.environ.get("ASB_GEODESIC", "host") == "device" or getattr(self, "geodesic_backend", "host") == "device"
-            self.compute_geodesic_distance = GeodesicDistanceComputation(shape0, self.tris, engine=eng if on_dev else None)
+            # "dense": both SPD systems inverted once on the device, a query = gather + one dense product (default up
+            # to DENSE_GEODESIC_MAX_VERTS vertices: the N x N inverses cost 2 N^3 flop each); "host": SciPy SuperLU as
+            # the reference; "device": batched Jacobi-PCG (experimental)
+            mode = os.environ.get("ASB_GEODESIC", getattr(self, "geodesic_backend", "auto"))
+            if mode == "auto":
+                mode = "dense" if (self.nVerts <= DENSE_GEODESIC_MAX_VERTS and hasattr(eng, "geodesic_setup")) else "host"
+            self.compute_geodesic_distance = GeodesicDistanceComputation(
+                shape0, self.tris, engine=eng if mode in ("dense", "device") else None,
+                backend="dense" if mode == "dense" else "pcg")
 
         if standarize:
             self.standarize(_local_sum=local_sum)

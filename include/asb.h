@@ -193,6 +193,11 @@ int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_rp, const in
 /* distances (min-shifted, :206) from nsrc <= 64 sources: out host (nsrc, n); tol = relative residual of the
  * CG solves; iters (optional, 2 ints) = iterations of the heat and the Poisson solve */
 int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters);
+/* Dense mode (after asb_geodesic_setup): the counterpart of the reference's two SuperLU factorisations
+ * (utils/support.py:170-171) for meshes whose N x N matrices are cheap in HBM (N <= 46 000: 2 x 17 GB).  Inverts
+ * (A - tL) and the gauge-fixed -L once on the device (blocked Gauss-Jordan on f64 MFMA); asb_geodesic_solve then
+ * needs no iteration: the heat step is a column gather, the Poisson step one dense product.  tol / iters unused. */
+int asb_geodesic_dense_setup(asb_ctx* ctx);
 
 /* ------------------------------------------------ snapshot ingest --------------- */
 /* align, utils/process.py:235-250 (find_rbm_procrustes :210-234 + transform :196-208 per frame): every
@@ -258,6 +263,9 @@ int asb_splocs_results(asb_ctx* ctx, double* C_out, double* W_out);
 /* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
  * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */
 void asb_test_eig3(const double* a6, double* out4);
+/* test hook: inverse of a host symmetric positive definite matrix (n x n) through the device's blocked
+ * Gauss-Jordan / f64-MFMA GEMM path that the device geodesics use for their two SPD systems */
+int asb_test_spd_inverse(asb_ctx* ctx, const double* A_host, int64_t n, double* Ainv_host);
 
 #ifdef __cplusplus
 }

@@ -684,3 +684,21 @@ def test_pod_gram_mfma_tiles(ep, F):
     ref = A @ A.T
     assert np.array_equal(G, G.T)
     assert np.abs(G - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [1, 7, 16, 100, 128, 129, 300, 1000])
+def test_device_spd_inverse(n):
+    """Blocked Gauss-Jordan inverse (LDS block inverse + f64-MFMA GEMM sweeps) against numpy.linalg.inv."""
+    import ctypes
+    from animsnapbases_amd import HipEngine
+    from animsnapbases_amd._lib import ptr
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T + 0.05 * n * np.eye(n)
+    e = HipEngine(0)
+    out = np.empty((n, n))
+    e._ck(e.lib.asb_test_spd_inverse(e.h, ptr(np.ascontiguousarray(A)), n, ptr(out)))
+    e.close()
+    ref = np.linalg.inv(A)
+    assert np.abs(out - ref).max() < 1e-12 * np.abs(ref).max() * np.linalg.cond(A)
+    assert np.abs(out @ A - np.eye(n)).max() < 1e-11
