@@ -25,6 +25,8 @@ import sys
 import numpy as np
 from scipy.linalg import eigh_tridiagonal
 
+from . import _lib
+from ._panels import deflate_panels_multirank
 from .distributed import Comm
 from .engine import HipEngine
 from .utils import log_time, testSparsity, test_linear_dependency
@@ -210,21 +212,87 @@ class constraintsComponents:  # Components == bases
         """constraintsComponents.py:108-153."""
         p = self.param
         kind = p.constProj_basis_type
-        if kind != "pod_vectorized":
-            if kind in ("pod", "pca_blocks", "pca_blocks_with_St"):
+        if kind not in ("pod_vectorized", "pca_blocks"):
+            if kind in ("pod", "pca_blocks_with_St"):
                 raise NotImplementedError("constProj_basis_type %r is out of scope of this build (SURVEY.md section 2 #3); "
-                                          "only 'pod_vectorized' runs on the GPU" % kind)
+                                          "'pod_vectorized' and 'pca_blocks' run on the GPU" % kind)
             raise ValueError("Uknown basis type: ", kind)
-        headerSing = ['component', 'singVal']
+        if kind == "pca_blocks":
+            headerSing = ['component', 'idx', 'residual_matrix_norm'] + \
+                         ['singVal' + str(i) for i in range(self.nonlinearSnapshots.constraintsSize)]
+            run = self.compute_nonlinearity_bases_blocks
+        else:
+            headerSing = ['component', 'singVal']
+            run = self.compute_pod_for_vectorized_nonlinear_snapshots_tensor
         file_name = os.path.join(p.constProj_output_directory, p.name + "_" + p.constProj_name + self.file_name_sing)
         rank0 = self.nonlinearSnapshots._comm.rank == 0
         if self.storeSingVal and rank0:
             with open(file_name + '.csv', 'w', encoding='UTF8') as singFile:
                 writer = csv.writer(singFile)
                 writer.writerow(headerSing)
-                self.compute_pod_for_vectorized_nonlinear_snapshots_tensor(writer)
+                run(writer)
         else:
-            self.compute_pod_for_vectorized_nonlinear_snapshots_tensor(None)
+            run(None)
+
+    @log_time(constProj_output_directory)
+    def compute_nonlinearity_bases_blocks(self, writer=None):
+        """constraintsComponents.py:324-412 ('pca_blocks'): K times, the constraint whose p rows carry the most residual
+        energy is chosen and its p rows are deflated one after the other (rank-1 SVD of the row's 3 x F slab, global
+        support) -- the greedy deflation of posComponents on the constraint rows.  p = 1 IS that loop (the block
+        arg-max is the row arg-max), so it runs through the panel algorithm; p > 1 keeps the residual on the device
+        and names the row of every pick (asb_deflate_block_argmax / asb_deflate_force_next)."""
+        if self.support == 'local':
+            raise ValueError(' Local support is not yet available for nonlinearity')
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        p = int(ns.constraintsSize)
+        K = int(self.param.deim_desired_num_components)
+        Kp = K * p
+        if p == 1:
+            eng.deflate_begin(Kp, False, _lib.DEFLATE_PROJECT)
+            if comm.multi:
+                deflate_panels_multirank(eng, comm, ns.frames_rows, Kp)
+            else:
+                eng.run_global(0, Kp)
+        else:
+            for v0, n_loc in ns._shards:
+                if v0 % p or n_loc % p:
+                    raise ValueError("'pca_blocks' with p = %d needs shards of whole constraints; %d rows over %d ranks do "
+                                     "not split that way" % (p, ns.frames_rows, comm.world))
+            eng.deflate_begin(Kp, False, _lib.DEFLATE_RESIDUAL)
+            rec = recs = None
+            if comm.multi:
+                rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
+            for k in range(K):
+                b, val = eng.block_argmax(p)
+                if comm.multi:
+                    b = int(comm.global_argmax(np.array([b]), np.array([val]))[0])
+                for i in range(p):
+                    eng.force_next(b * p + i)
+                    if comm.multi:
+                        eng.local_best(k * p + i, rec.data_ptr())
+                        comm.all_gather_records(rec, recs)
+                        eng.pick(k * p + i, recs.data_ptr(), comm.world)
+                    else:
+                        eng.pick(k * p + i)
+                    eng.apply(k * p + i)
+        res = eng.results(want_comps=False, want_weigs=True)
+        normR = np.sqrt(comm.allreduce_sum(res["normR2_local"]))
+        self.weigs = res["weigs"]
+        self.largeDeforBlocks = np.asarray(res["idx"], dtype=np.int64)               # (K p,) rows, 0 <= . < e p
+        self.largeDeforPoints = self.largeDeforBlocks[::p] // p                       # (K,) constraints
+        meas = np.empty((K, 3 + p))
+        meas[:, 0] = np.arange(K)
+        meas[:, 1] = self.largeDeforPoints
+        meas[:, 2] = normR[p - 1::p]                  # ||R|| after the constraint's last row
+        meas[:, 3:] = res["sigma"].reshape(K, p)
+        self.measures_at_largeDeforVerts = meas
+        if writer is not None:
+            for row in meas:
+                writer.writerow([int(row[0]), int(row[1])] + [float(x) for x in row[2:]])
+        self._comps, self._comps_on_device = None, True
+        self.numComp = K
+        print("bases shape", (Kp, ns.frames_rows, 3), "number of components", self.numComp)
 
     @log_time(constProj_output_directory)
     def compute_pod_for_vectorized_nonlinear_snapshots_tensor(self, writer=None):

@@ -53,6 +53,9 @@ struct asb_ctx {
     int64_t K = 0;
     int mode = 0, local = 0;
     int64_t k_done = 0;
+    int64_t forced_row = -1;      // asb_deflate_force_next: global row the next pick must take
+    double* bam_val = nullptr;    // asb_deflate_block_argmax partials
+    long long* bam_idx = nullptr;
     int nblk = 0;               // partial records written by the last streaming pass
     double* R = nullptr;        // (3*n_loc, Fp) residual (mode RESIDUAL)
     double* energy = nullptr;   // (n_loc)

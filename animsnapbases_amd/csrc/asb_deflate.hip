@@ -66,7 +66,8 @@ extern "C" int asb_deflate_local_best(asb_ctx* ctx, int64_t k, double* rec_dev) 
     if (!ctx || !ctx->R) return ASB_ERR_ARG;
     if (!rec_dev) rec_dev = ctx->xrec;
     hipLaunchKernelGGL(k_local_best, dim3(1), dim3(256), 0, ctx->stream, ctx->R, ctx->pmax, ctx->pidx, ctx->psum,
-                       ctx->nblk, (long long)ctx->v0, (int)ctx->Fp, rec_dev, ctx->scal, (long long)k);
+                       ctx->nblk, (long long)ctx->v0, (int)ctx->Fp, rec_dev, ctx->scal, (long long)k, (long long)ctx->forced_row,
+                       (long long)ctx->n_loc);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
@@ -77,8 +78,77 @@ extern "C" int asb_deflate_pick(asb_ctx* ctx, int64_t k, const double* recs_dev,
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, ctx->stream, ctx->R, ctx->pmax, ctx->pidx, ctx->psum,
                        ctx->nblk, recs_dev, (int)n_rec, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
                        (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, (long long)k, (long long)ctx->K, ctx->local,
-                       (PanelState*)nullptr, (const long long*)nullptr, (long long)0);
+                       (PanelState*)nullptr, (const long long*)nullptr, (long long)0,
+                       (long long)(recs_dev ? -1 : ctx->forced_row));
     ASB_CHECK_LAUNCH(ctx);
+    ctx->forced_row = -1;          // a forced row holds for one pick
+    return ASB_OK;
+}
+
+// 'pca_blocks' (constraintsComponents.py:324-412): the next asb_deflate_local_best / asb_deflate_pick takes the slab of
+// global row `gidx` instead of the arg-max (residual mode).
+extern "C" int asb_deflate_force_next(asb_ctx* ctx, int64_t gidx) {
+    if (!ctx || !ctx->R) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_force_next needs the residual mode");
+    if (gidx < 0 || gidx >= ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_force_next: row %lld out of range", (long long)gidx);
+    if (ctx->N_glob == ctx->n_loc && (gidx < ctx->v0 || gidx >= ctx->v0 + ctx->n_loc))
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_force_next: row %lld is not on this shard", (long long)gidx);
+    ctx->forced_row = gidx;
+    return ASB_OK;
+}
+
+// block energies: sum of the current residual energies of p consecutive rows; first maximum of this shard
+// (:86-92, indxLargestDeformation).  The shard must hold whole blocks.
+__global__ __launch_bounds__(256) void k_block_argmax(const double* __restrict__ energy, long long nblocks, int p, long long b0,
+                                                      double* __restrict__ pmax, long long* __restrict__ pidx) {
+    __shared__ double sh_d[256];
+    __shared__ long long sh_i[256];
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (long long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int i = 0; i < p; ++i) s += energy[b * p + i];
+        if (am_better(s, b0 + b, be, bi)) { be = s; bi = b0 + b; }
+    }
+    sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o && am_better(sh_d[threadIdx.x + o], sh_i[threadIdx.x + o], sh_d[threadIdx.x], sh_i[threadIdx.x])) {
+            sh_d[threadIdx.x] = sh_d[threadIdx.x + o];
+            sh_i[threadIdx.x] = sh_i[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; }
+}
+
+extern "C" int asb_deflate_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out) {
+    if (!ctx || !ctx->R || !ctx->energy || !block_out || p < 1) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_block_argmax needs the residual mode");
+    if (ctx->v0 % p || ctx->n_loc % p)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_block_argmax: the shard [%lld, +%lld) does not hold whole blocks of %d rows",
+                 (long long)ctx->v0, (long long)ctx->n_loc, p);
+    const long long nb = ctx->n_loc / p;
+    const int grid = (int)((nb + 255) / 256 < 256 ? (nb + 255) / 256 : 256);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_val, (size_t)256))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_idx, (size_t)256))) return rc;
+    double hv[256];
+    long long hi[256];
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_block_argmax, dim3(grid), dim3(256), 0, ctx->stream, ctx->energy, nb, p, (long long)(ctx->v0 / p),
+                           ctx->bam_val, ctx->bam_idx);
+        ASB_CHECK_LAUNCH(ctx);
+        ASB_HIP(ctx, hipMemcpyAsync(hv, ctx->bam_val, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(hi, ctx->bam_idx, grid * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int b = 0; b < (nb > 0 ? grid : 0); ++b)
+        if (hv[b] > be || (hv[b] == be && hi[b] < bi)) { be = hv[b]; bi = hi[b]; }
+    *block_out = bi;
+    if (val_out) *val_out = be;
     return ASB_OK;
 }
 
@@ -131,7 +201,7 @@ extern "C" int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, i
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, ctx->stream, ctx->R, ctx->pmax, ctx->pidx, ctx->psum,
                        ctx->nblk, (const double*)nullptr, 0, (long long)(2 + 3 * ctx->Fp), (long long)ctx->v0,
                        (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, (long long)ctx->k_done, (long long)0, 0,
-                       (PanelState*)nullptr, (const long long*)nullptr, (long long)0);
+                       (PanelState*)nullptr, (const long long*)nullptr, (long long)0, (long long)-1);
     ASB_CHECK_LAUNCH(ctx);
     std::vector<double> h((size_t)(K + 1) * 4);
     ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -239,12 +239,18 @@ static __global__ __launch_bounds__(256) void k_local_best(const double* __restr
                                                     const double* pmax, const long long* pidx,
                                                     const double* psum, int nblk, long long v0,
                                                     int Fp, double* __restrict__ rec,
-                                                    double* __restrict__ scal, long long k) {
+                                                    double* __restrict__ scal, long long k, long long forced,
+                                                    long long n_loc) {
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
     double be, bs;
     long long bi;
     reduce_partials(pmax, pidx, psum, nblk, sh_d, sh_i, be, bi, bs);
+    if (forced >= 0) {       // the caller names the row ('pca_blocks'): its owner wins the exchange, the others abstain
+        const bool mine = forced >= v0 && forced < v0 + n_loc;
+        be = mine ? 1.0e300 : -1.0;
+        bi = mine ? forced - v0 : 0;
+    }
     if (threadIdx.x == 0) {
         rec[0] = be;
         rec[1] = __longlong_as_double(v0 + bi);
@@ -269,7 +275,8 @@ static __global__ __launch_bounds__(256) void k_pick(const double* __restrict__ 
                                               double* __restrict__ W, double* __restrict__ scal,
                                               long long k, long long K, int local_mode,
                                               PanelState* __restrict__ panel,
-                                              const long long* __restrict__ cand_idx, long long k_panel0) {
+                                              const long long* __restrict__ cand_idx, long long k_panel0,
+                                              long long forced) {
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
     __shared__ double u_sh[4];
@@ -293,6 +300,7 @@ static __global__ __launch_bounds__(256) void k_pick(const double* __restrict__ 
         reduce_partials(pmax, pidx, psum, nblk, sh_d, sh_i, be, bi, bs);
         if (tid == 0 && k > 0) scal[(k - 1) * 4 + 3] = bs;
         if (k >= K) return;
+        if (forced >= 0) bi = forced - v0;      // the caller names the row ('pca_blocks')
         slab = R + bi * 3 * (long long)Fp;
         gidx = v0 + bi;
     } else {

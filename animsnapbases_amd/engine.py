@@ -136,6 +136,15 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_get_pick(self.h, int(k), ctypes.byref(i), ctypes.byref(s)))
         return i.value, s.value
 
+    def block_argmax(self, p):
+        """(global block index, energy) of the constraint block with the largest residual energy on this shard."""
+        i, v = ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_deflate_block_argmax(self.h, int(p), ctypes.byref(i), ctypes.byref(v)))
+        return i.value, v.value
+
+    def force_next(self, gidx):
+        self._ck(self.lib.asb_deflate_force_next(self.h, int(gidx)))
+
     def apply(self, k, s_loc=None):
         if s_loc is not None:
             s_loc = np.ascontiguousarray(s_loc, dtype=np.float64)

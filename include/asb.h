@@ -107,6 +107,13 @@ int asb_deflate_local_best(asb_ctx* ctx, int64_t k, double* rec_dev);
 int asb_deflate_pick(asb_ctx* ctx, int64_t k, const double* recs_dev, int64_t n_rec);
 /* selected vertex (global index) and sigma_1 of component k (synchronises) */
 int asb_deflate_get_pick(asb_ctx* ctx, int64_t k, int64_t* idx, double* sigma);
+/* 'pca_blocks' constraint bases (snapbases/constraintsComponents.py:324-412; residual mode).
+ * asb_deflate_block_argmax: the constraint (block of p consecutive rows) with the largest residual energy on this
+ * shard -- indxLargestDeformation, :86-92 (first maximum); the shard must hold whole blocks; block_out is global.
+ * asb_deflate_force_next: the next asb_deflate_local_best / asb_deflate_pick takes global row gidx instead of the
+ * arg-max (the reference deflates the p rows of the chosen constraint one after the other, :352-356). */
+int asb_deflate_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out);
+int asb_deflate_force_next(asb_ctx* ctx, int64_t gidx);
 /* :101-111: c_k = (w_k . R)[* s] / |w_k|^2, R -= w_k (x) c_k, new energies.
  * s: host (n_loc) support factor 1 - support_map (:95), or NULL for global. */
 int asb_deflate_apply(asb_ctx* ctx, int64_t k, const double* s);

@@ -388,6 +388,35 @@ def pod_vectorized(snapTensor, desired_num_components):
     return dict(comps=np.array(C), S=S)
 
 
+def pca_blocks(snapTensor, K, p):
+    """snapbases/constraintsComponents.py:324-412 ('pca_blocks', global support): K times, the constraint whose p
+    rows carry the most residual energy is chosen (:86-92) and its p rows are deflated one after the other, each by
+    the rank-1 SVD of its 3 x F slab.  Returns dict(comps (K p, ep, 3), weigs (F, K p), measures (K, 3 + p),
+    points (K,), blocks (K p,))."""
+    R = snapTensor.copy()
+    F, ep, _ = R.shape
+    e = ep // p
+    C, W, pts, blocks, meas = [], [], [], [], []
+    for k in range(K):
+        mag = (R ** 2).sum(axis=(0, 2)).reshape(e, p).sum(axis=1)
+        idx = int(np.argmax(mag))
+        pts.append(idx)
+        sig = []
+        for i in range(p):
+            row = idx * p + i
+            _, s, Vt = sla.svd(R[:, row, :].T, full_matrices=False)
+            wk = s[0] * Vt[0]
+            ck = np.tensordot(wk, R, (0, 0)) / np.inner(wk, wk)
+            R -= np.outer(wk, ck).reshape(R.shape)
+            blocks.append(row)
+            C.append(ck)
+            W.append(wk)
+            sig.append(s[0])
+        meas.append([k, idx, np.linalg.norm(R)] + sig)
+    return dict(comps=np.array(C), weigs=np.array(W).T, measures=np.array(meas), points=np.array(pts, dtype=np.int64),
+                blocks=np.array(blocks, dtype=np.int64), R=R)
+
+
 def post_process_constraint_components(comps, snapTensor, pre_scale_factor=None, mean=None,
                                        orthogonal=False, invMassL=None):
     """snapbases/constraintsComponents.py:415-443.  Returns (comps, snapTensor) copies."""

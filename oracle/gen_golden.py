@@ -212,6 +212,50 @@ def run_reference_constraints(ref, frames, K, rest_shape, standarize, orthogonal
     return out
 
 
+def run_reference_blocks(ref, frames, K, p, standarize=True):
+    """constraintsComponents.compute_nonlinearity_bases_blocks (constProj_basis_type 'pca_blocks', :324-412)."""
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    param = types.SimpleNamespace(constProj_standarize=standarize, constProj_massWeight=False, constProj_orthogonal=False,
+                                  deim_desired_num_components=K, constProj_output_directory=".")
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param = param
+    ns.rest_shape = "first"
+    ns.dim = 3
+    ns.frs = frames.shape[0]
+    ns.constraintsSize = p
+    ns.num_constained_elements = frames.shape[1] // p
+    ns.snapTensor = frames.astype(float).copy()
+    ns.mean = None
+    ns.pre_scale_factor = 1
+    ns.massL = ns.invMassL = None
+    if standarize:
+        ns.standarize()
+    cc = object.__new__(constraintsComponents)
+    cc.param = param
+    cc.nonlinearSnapshots = ns
+    cc.numComp = 0
+    cc.comps = None
+    cc.support = "global"
+    cc.storeSingVal = False
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_nonlinearity_bases_blocks(None)
+    return dict(snapTensor=ns.snapTensor.copy(), comps=cc.comps.copy(), weigs=cc.weigs.copy(),
+                measures=cc.measures_at_largeDeforVerts.copy(), points=np.asarray(cc.largeDeforPoints, dtype=np.int64),
+                blocks=np.asarray(cc.largeDeforBlocks, dtype=np.int64), numComp=np.array(cc.numComp))
+
+
+def _blocks(work):
+    rng = np.random.default_rng(21)
+    e, F, K = 40, 20, 5
+    for p in (1, 3):
+        modes = rng.normal(size=(8, e * p, 3))
+        coef = rng.normal(size=(F, 8)) * (0.7 ** np.arange(8))[None]
+        frames = 0.2 + np.tensordot(coef, modes, (1, 0)) + 1e-4 * rng.normal(size=(F, e * p, 3))
+        res = run_reference_blocks(import_reference.cache, frames, K, p)
+        np.savez_compressed(os.path.join(OUT, "pca_blocks_p%d.npz" % p), frames=frames, K=np.array(K), p=np.array(p), **res)
+        print("wrote pca_blocks_p%d" % p, "points", res["points"].tolist())
+
+
 CASES = {
     # name: (rings, segs, F, rank, kind, seed, param overrides, with_mass)
     "pca_global_small": (8, 12, 40, 5, "iid", 1, dict(vertPos_numComponents=6), False),
@@ -287,13 +331,14 @@ def _ingest(work):
 
 
 def main():
-    """`python oracle/gen_golden.py` regenerates every fixture; `... ingest` only the ingest one.  The ingest
+    """`python oracle/gen_golden.py` regenerates every fixture; `... ingest` / `... blocks` only that one.  The ingest
     functions of the reference (utils/process.py) call `ndarray.ptp` / `np.asfarray`, which NumPy 2 removed, so that
     fixture is generated with the image's other interpreter: `/opt/conda/bin/python3.9 oracle/gen_golden.py ingest`
     (NumPy 1.26)."""
     only = sys.argv[1:] or None
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    import_reference.cache = ref
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as work:
         os.chdir(work)                             # log_time writes function_timings.txt into cwd
@@ -318,6 +363,8 @@ def main():
                                        if k != "vertPos_output_directory"},
                                     **res)
                 print("wrote", name, "idx", res["idx"].tolist())
+            if only is not None and "blocks" in only:
+                return _blocks(work)
             if only is not None and "ingest" not in only:
                 return
             if only is not None:
@@ -333,6 +380,7 @@ def main():
                 np.savez_compressed(os.path.join(OUT, nm + ".npz"), frames=frames, K=np.array(K),
                                     p=np.array(1), orthogonal=np.array(orth), **res)
                 print("wrote", nm, "Pt", res["Pt"].tolist())
+            _blocks(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

@@ -702,3 +702,76 @@ def test_device_spd_inverse(n):
     ref = np.linalg.inv(A)
     assert np.abs(out - ref).max() < 1e-12 * np.abs(ref).max() * np.linalg.cond(A)
     assert np.abs(out @ A - np.eye(n)).max() < 1e-11
+
+
+def _run_blocks(frames, K, p, tmp, comm=None, engine=None):
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    param = _cparam(K, False, tmp)
+    param.constProj_basis_type = "pca_blocks"
+    param.constProj_p_size = p
+    ns = nonlinearSnapshots(param, frames=frames, comm=comm, engine=engine)
+    ns.config()
+    ns.snapshots_prepare()
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.compute_components_store_singvalues()
+    return ns, cc
+
+
+def _check_blocks(cc, ref_comps, ref_weigs, ref_meas, ref_points, ref_blocks, tol=TOL):
+    assert cc.largeDeforPoints.tolist() == np.asarray(ref_points).tolist()
+    assert cc.largeDeforBlocks.tolist() == np.asarray(ref_blocks).tolist()
+    sgn = np.sign(np.sum(cc.weigs * ref_weigs, axis=0))
+    assert relerr(cc.weigs * sgn[None], ref_weigs) < tol
+    assert relerr(cc.comps * sgn[:, None, None], ref_comps) < tol
+    assert relerr(cc.measures_at_largeDeforVerts, ref_meas) < 1e-7
+
+
+@pytest.mark.parametrize("p", [1, 3])
+def test_pca_blocks_vs_reference_golden(p, tmp_path):
+    """constProj_basis_type 'pca_blocks' (constraintsComponents.py:324-412) against the unmodified reference; the CSV too."""
+    g = load_golden("pca_blocks_p%d" % p)
+    ns, cc = _run_blocks(g["frames"], int(g["K"]), p, tmp_path)
+    assert cc.numComp == int(g["numComp"])
+    _check_blocks(cc, g["comps"], g["weigs"], g["measures"], g["points"], g["blocks"])
+    import csv
+    rows = list(csv.reader(open(tmp_path / "c5_verts_constrprojBases_pcaExtraction_singValues.csv")))
+    assert rows[0] == ['component', 'idx', 'residual_matrix_norm'] + ['singVal%d' % i for i in range(p)]
+    assert len(rows) == 1 + int(g["K"])
+    got = np.array([[float(x) for x in r] for r in rows[1:]])
+    assert relerr(got, g["measures"]) < 1e-7
+
+
+@pytest.mark.parametrize("p,e,F,K", [(1, 6000, 48, 20), (2, 1500, 33, 9), (4, 700, 26, 5)])
+def test_pca_blocks_vs_oracle(p, e, F, K, tmp_path):
+    rng = np.random.default_rng(p * 7 + e)
+    frames = rng.uniform(-1, 1, size=(F, e * p, 3))
+    ns, cc = _run_blocks(frames, K, p, tmp_path)
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    r = orc.pca_blocks(pre["snapTensor"], K, p)
+    _check_blocks(cc, r["comps"], r["weigs"], r["measures"], r["points"], r["blocks"], tol=1e-8)
+
+
+@pytest.mark.parametrize("p", [1, 2])
+def test_multirank_pca_blocks_on_one_gpu(p, tmp_path):
+    """'pca_blocks' over 2 row shards on one GPU: p = 1 through the panel protocol, p = 2 through block arg-max
+    all-gathers and forced-row record exchanges."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(77 + p)
+    e, F, K = 2600, 40, 10
+    frames = rng.uniform(-1, 1, size=(F, e * p, 3))
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns, cc = _run_blocks(frames, K, p, tmp_path, comm=comm, engine=HipEngine(0, stream=0))
+            cc.comps                # gathered over the ranks: has to happen while every rank is still here
+        return cc
+
+    outs = run_ranks(2, rank_fn)
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    r = orc.pca_blocks(pre["snapTensor"], K, p)
+    for cc in outs:
+        _check_blocks(cc, r["comps"], r["weigs"], r["measures"], r["points"], r["blocks"], tol=1e-8)

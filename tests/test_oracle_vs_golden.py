@@ -108,3 +108,18 @@ def test_pod_deim(name):
     assert dm["Pt"].tolist() == g["Pt"].tolist()
     assert dm["alpha"].tolist() == g["alpha"].tolist()
     assert dm["alpha_ranges"].tolist() == g["alpha_ranges"].tolist()
+
+
+@pytest.mark.parametrize("p", [1, 3])
+def test_pca_blocks(p):
+    """'pca_blocks' constraint bases (constraintsComponents.py:324-412) against the unmodified reference."""
+    g = load_golden("pca_blocks_p%d" % p)
+    pre = orc.prepare_nonlinear_snapshots(g["frames"], "first", True)
+    assert relerr(pre["snapTensor"], g["snapTensor"]) < TOL
+    r = orc.pca_blocks(pre["snapTensor"], int(g["K"]), p)
+    assert r["points"].tolist() == g["points"].tolist()
+    assert r["blocks"].tolist() == g["blocks"].tolist()
+    sgn = np.sign(np.sum(r["weigs"] * g["weigs"], axis=0))          # LAPACK's SVD sign per component
+    assert relerr(r["weigs"] * sgn[None], g["weigs"]) < 1e-10
+    assert relerr(r["comps"] * sgn[:, None, None], g["comps"]) < 1e-10
+    assert relerr(r["measures"], g["measures"]) < 1e-10

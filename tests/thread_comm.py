@@ -16,7 +16,7 @@ class _Hub(object):
     def __init__(self, world):
         self.world = world
         self.slots = [None] * world
-        self.bar = threading.Barrier(world)
+        self.bar = threading.Barrier(world, timeout=120)      # a collective that not every rank enters fails instead of hanging
 
     def exchange(self, rank, obj):
         self.slots[rank] = obj
