@@ -94,6 +94,31 @@ class AsbLibraryError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.  A process must end up with ONE HIP runtime: if this library pulled in
+    the system one first, torch (the multi-GPU plumbing) would later load a second copy and find no GPU.  So when torch
+    is installed its runtime is loaded first -- without importing torch -- and libasb_hip.so binds to it by SONAME."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                              # torch already loaded its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """Loads the HIP library and binds every entry point of include/asb.h."""
     global _lib
@@ -103,6 +128,7 @@ def load():
         raise AsbLibraryError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C animsnapbases_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

@@ -53,6 +53,10 @@ struct asb_ctx {
     int64_t K = 0;
     int mode = 0, local = 0;
     int64_t k_done = 0;
+    unsigned* coop_bar = nullptr;     // k_panel_coop: [arrivals, abort flag]
+    double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
+    double* coop_w = nullptr;         // (2, grid, Fp) tentative weights
+    int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
     int64_t forced_row = -1;      // asb_deflate_force_next: global row the next pick must take
     double* bam_val = nullptr;    // asb_deflate_block_argmax partials
     long long* bam_idx = nullptr;

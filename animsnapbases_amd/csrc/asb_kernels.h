@@ -197,6 +197,62 @@ __host__ __device__ inline void eig3_top(double a00, double a01, double a02, dou
     u0 /= nn; u1 /= nn; u2 /= nn;
 }
 
+// Largest eigen-pair of a symmetric 3 x 3 matrix without the Jacobi sweeps (~6 sweeps x 3 rotations of dependent
+// sqrt / divide chains, about 5 us on one lane): trigonometric root of the characteristic polynomial, eigenvector from
+// the largest cross product of two rows of A - lambda I, two Rayleigh-quotient refinements, and a residual test
+// |A u - lambda u| <= 4 eps |A|; anything that fails it (near-degenerate top eigenvalues) goes to eig3_top.
+__host__ __device__ inline void eig3_top_fast(double a00, double a01, double a02, double a11, double a12, double a22,
+                                              double& lam, double& u0, double& u1, double& u2) {
+    const double sc = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+    if (!(sc > 0.0) || !(sc < 1.0e300)) { eig3_top(a00, a01, a02, a11, a12, a22, lam, u0, u1, u2); return; }
+    const double is = 1.0 / sc;
+    const double b00 = a00 * is, b01 = a01 * is, b02 = a02 * is, b11 = a11 * is, b12 = a12 * is, b22 = a22 * is;
+    const double q = (b00 + b11 + b22) / 3.0;
+    const double p1 = b01 * b01 + b02 * b02 + b12 * b12;
+    const double d0 = b00 - q, d1 = b11 - q, d2 = b22 - q;
+    const double p = sqrt((d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1) / 6.0);
+    bool ok = p > 0.0;
+    double l = q, x = 0.0, y = 0.0, z = 0.0;
+    if (ok) {
+        const double ip = 1.0 / p;
+        const double c00 = d0 * ip, c11 = d1 * ip, c22 = d2 * ip, c01 = b01 * ip, c02 = b02 * ip, c12 = b12 * ip;
+        double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+        r = fmin(1.0, fmax(-1.0, r));
+        l = q + 2.0 * p * cos(acos(r) / 3.0);
+        for (int it = 0; it < 3 && ok; ++it) {
+            const double m00 = b00 - l, m11 = b11 - l, m22 = b22 - l;
+            // cross products of the rows of B - l I
+            const double x0 = b01 * b12 - b02 * m11, y0 = b02 * b01 - m00 * b12, z0 = m00 * m11 - b01 * b01;      // r0 x r1
+            const double x1 = b01 * m22 - b02 * b12, y1 = b02 * b02 - m00 * m22, z1 = m00 * b12 - b01 * b02;      // r0 x r2
+            const double x2 = m11 * m22 - b12 * b12, y2 = b12 * b02 - b01 * m22, z2 = b01 * b12 - m11 * b02;      // r1 x r2
+            const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+            double nn;
+            if (n0 >= n1 && n0 >= n2) { x = x0; y = y0; z = z0; nn = n0; }
+            else if (n1 >= n2) { x = x1; y = y1; z = z1; nn = n1; }
+            else { x = x2; y = y2; z = z2; nn = n2; }
+            if (!(nn > 1.0e-20)) { ok = false; break; }        // rank(B - l I) < 2: the top eigenvalue is (nearly) double
+            const double inn = 1.0 / sqrt(nn);
+            x *= inn; y *= inn; z *= inn;
+            l = x * (b00 * x + b01 * y + b02 * z) + y * (b01 * x + b11 * y + b12 * z) + z * (b02 * x + b12 * y + b22 * z);
+        }
+    }
+    if (ok) {
+        const double r0 = b00 * x + b01 * y + b02 * z - l * x, r1 = b01 * x + b11 * y + b12 * z - l * y,
+                     r2 = b02 * x + b12 * y + b22 * z - l * z;
+        // is l really the LARGEST eigenvalue?  trace and the 2 x 2 minors give the other two: both must be <= l
+        const double tr = b00 + b11 + b22 - l;                       // l2 + l3
+        const double mm = b00 * b11 - b01 * b01 + b00 * b22 - b02 * b02 + b11 * b22 - b12 * b12 - l * tr;      // l2 l3
+        const double disc = tr * tr - 4.0 * mm;
+        const double l2 = 0.5 * (tr + sqrt(fmax(disc, 0.0)));
+        ok = fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= 1.0e-15 && l2 <= l * (1.0 - 1.0e-6);
+    }
+    if (!ok) { eig3_top(a00, a01, a02, a11, a12, a22, lam, u0, u1, u2); return; }
+    const double m0 = fabs(x), m1 = fabs(y), m2 = fabs(z);
+    const double lead = (m0 >= m1 && m0 >= m2) ? x : (m1 >= m2 ? y : z);
+    if (lead < 0.0) { x = -x; y = -y; z = -z; }
+    lam = l * sc; u0 = x; u1 = y; u2 = z;
+}
+
 // Reduce the per-block partial records of the last k_stream pass (one block).
 // Result in every thread: (be, bi) winner, bs sum of energies.
 __device__ inline void reduce_partials(const double* pmax, const long long* pidx, const double* psum,

@@ -1218,6 +1218,209 @@ extern "C" int asb_panel_assemble(asb_ctx* ctx, const double* rows_g, const long
     return ASB_OK;
 }
 
+// --------------------------------------------------------------------------------------
+// k_panel_coop: the whole inner loop of a panel (up to 16 greedy steps) in ONE launch of co-resident blocks.
+// Every candidate row triple lives in the REGISTERS of one wave for the whole panel (lane l holds frames
+// l + 64 j: 3 x NJ doubles), so a step touches no HBM:
+//   1. each block takes its best candidate (exact energy = sum of squares of the registers); that wave does the 3 x 3
+//      Gram / eigen-pair / w = u^T slab and publishes the record [energy, slot, lambda, |w|^2, w] -- like the per-rank
+//      records of the multi-GPU residual mode -- followed by its sequence number;
+//   2. every block polls ALL records (thread i <-> record i) until they carry this step's sequence number: the
+//      exchange is the barrier, one memory round trip, no read-modify-write contention;
+//   3. every block reduces the records to the same winner, checks the commit condition (energy > theta + margin),
+//      stages the winner's w in LDS and each wave deflates its own row explicitly: c = row . w / |w|^2, row -= c w.
+// Everything that crosses blocks goes through relaxed agent-scope atomic loads / stores (they bypass the per-XCD L2s,
+// which are not coherent with each other) ordered by plain s_waitcnt, so the loop needs no cache write-back or
+// invalidate.  Records and weights are double-buffered by step parity: a block can run at most one step ahead.
+// Block 0 also writes W[k], scal[k] and the committed count.  All blocks take identical decisions from identical
+// data, so they leave the loop together; a poll that does not complete within ~1 s raises the abort flag instead
+// of hanging the GPU.
+// --------------------------------------------------------------------------------------
+struct CoopRec { double e, lam, wn2; long long slot; unsigned long long seq; unsigned long long pad[3]; };
+
+__device__ __forceinline__ void coop_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double coop_load(const double* p) {
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const double* __restrict__ R0, long long m_cap, int F, int Fp,
+                                                       double* __restrict__ W, double* __restrict__ scal, long long k0, int steps,
+                                                       PanelState* __restrict__ panel, const long long* __restrict__ cand_idx,
+                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w) {
+    __shared__ double w_sh[NJ * 64];
+    __shared__ double sh_e[4];
+    __shared__ long long sh_i[4];
+    __shared__ int sh_b[4];
+    __shared__ double wv_e[4];
+    __shared__ long long wv_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = gridDim.x;
+    const long long n_cand = panel->n_cand;
+    if (n_cand > 4LL * G) {          // more candidates than resident waves: the caller falls back to the two-kernel loop
+        if (blockIdx.x == 0 && tid == 0) bar[2] = 1u;
+        return;
+    }
+    const double thr = panel->theta + panel->margin;
+    const long long s = (long long)blockIdx.x * 4 + wv;          // this wave's candidate slot
+    const bool have = s < n_cand && cand_idx[s] >= 0;
+    double x[3][NJ];
+    {
+        const double* row = R0 + s * 3 * (long long)Fp;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = lane + 64 * j;
+                x[d][j] = (have && f < Fp) ? row[(long long)d * Fp + f] : 0.0;
+            }
+    }
+    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(bar + 4);      // [16][6] timestamps of block 0 (debug)
+    for (int t = 0; t < steps; ++t) {
+        const unsigned long long seq = (unsigned long long)t + 1;
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 0] = wall_clock64();
+        // ---- 1. block-local best and its record
+        double e = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) e += x[d][j] * x[d][j];
+        e = wave_sum(e);
+        if (lane == 0) { wv_e[wv] = have ? e : -1.0; wv_i[wv] = have ? s : 0x7fffffffffffffffLL; }
+        __syncthreads();
+        int ow = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (am_better(wv_e[q], wv_i[q], wv_e[ow], wv_i[ow])) ow = q;
+        CoopRec* myrec = rec + (size_t)(t & 1) * G + blockIdx.x;
+        double* myw = rec_w + ((size_t)(t & 1) * G + blockIdx.x) * Fp;
+        if (wv == ow) {
+            double g[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const double a = x[0][j], b = x[1][j], c = x[2][j];
+                g[0] += a * a; g[1] += a * b; g[2] += a * c; g[3] += b * b; g[4] += b * c; g[5] += c * c;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
+            double lam, u0, u1, u2;
+            eig3_top_fast(g[0], g[1], g[2], g[3], g[4], g[5], lam, u0, u1, u2);     // every lane: identical inputs and result
+            double wn = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = lane + 64 * j;
+                const double wvv = (f < F) ? (u0 * x[0][j] + u1 * x[1][j] + u2 * x[2][j]) : 0.0;
+                if (f < Fp) coop_store(myw + f, wvv);
+                wn += wvv * wvv;
+            }
+            wn = wave_sum(wn);
+            if (lane == 0) {
+                coop_store(&myrec->e, wv_e[ow]);
+                coop_store(&myrec->lam, lam);
+                coop_store(&myrec->wn2, wn);
+                __hip_atomic_store(&myrec->slot, wv_i[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);              // every store of this wave has been acknowledged ...
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&myrec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+        }
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 1] = wall_clock64();
+        // ---- 2. + 3. poll every record until it is this step's, reduce to the same winner in every block
+        const CoopRec* recs = rec + (size_t)(t & 1) * G;
+        double be = -1.0;
+        long long bi = 0x7fffffffffffffffLL;
+        int bb = 0;
+        int dead = 0;
+        for (int b = tid; b < G; b += 256) {
+            CoopRec* r = const_cast<CoopRec*>(recs) + b;
+            long long spins = 0;
+            while (__hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1LL << 20) || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { dead = 1; break; }
+            }
+            if (dead) break;
+            const double eb = coop_load(&r->e);
+            const long long ib = __hip_atomic_load(&r->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (am_better(eb, ib, be, bi)) { be = eb; bi = ib; bb = b; }
+        }
+        if (__syncthreads_or(dead)) {
+            if (tid == 0) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 2] = wall_clock64();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double oe = __shfl_xor(be, o, 64);
+            const long long oi = __shfl_xor(bi, o, 64);
+            const int ob = __shfl_xor(bb, o, 64);
+            if (am_better(oe, oi, be, bi)) { be = oe; bi = oi; bb = ob; }
+        }
+        if (lane == 0) { sh_e[wv] = be; sh_i[wv] = bi; sh_b[wv] = bb; }
+        __syncthreads();
+        be = sh_e[0]; bi = sh_i[0]; bb = sh_b[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (am_better(sh_e[q], sh_i[q], be, bi)) { be = sh_e[q]; bi = sh_i[q]; bb = sh_b[q]; }
+        if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max: the panel ends here
+            if (blockIdx.x == 0 && tid == 0) panel->done = 1;
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 3] = wall_clock64();
+        const double wn2 = coop_load(&recs[bb].wn2);
+        const double* ww = rec_w + ((size_t)(t & 1) * G + bb) * Fp;
+        for (int f = tid; f < NJ * 64; f += 256) w_sh[f] = (f < Fp) ? coop_load(ww + f) : 0.0;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            const long long k = k0 + t;
+            for (int f = tid; f < Fp; f += 256) W[k * (long long)Fp + f] = w_sh[f];
+            if (tid == 0) {
+                scal[k * 4 + 0] = sqrt(fmax(coop_load(&recs[bb].lam), 0.0));
+                scal[k * 4 + 1] = wn2;
+                scal[k * 4 + 2] = __longlong_as_double(cand_idx[bi]);
+                panel->committed = t + 1;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 4] = wall_clock64();
+        if (t + 1 < steps) {          // explicit deflation of this wave's row
+            double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const double wj = w_sh[lane + 64 * j];
+                acc[0] += x[0][j] * wj; acc[1] += x[1][j] * wj; acc[2] += x[2][j] * wj;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[d] = wave_sum(acc[d]) / wn2;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const double wj = w_sh[lane + 64 * j];
+                x[0][j] -= acc[0] * wj; x[1][j] -= acc[1] * wj; x[2][j] -= acc[2] * wj;
+            }
+        }
+        __syncthreads();              // w_sh and the wave records are rewritten in the next step
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 5] = wall_clock64();
+    }
+}
+
+template <int NJ>
+static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bool* launched) {
+    int per_cu = 0;
+    ASB_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_panel_coop<NJ>, 256, 0));
+    if (per_cu < 1) { *launched = false; return ASB_OK; }
+    if ((long long)per_cu * ctx->n_cu < grid) grid = per_cu * ctx->n_cu;      // the kernel refuses panels with more candidates
+    // A plain launch: the grid is no larger than what the occupancy query says is resident at once on this device, and
+    // nothing these blocks wait for depends on other work, so they all become resident (a cooperative launch would
+    // assert the same thing but is not usable on every stream, e.g. torch's null stream).  The barrier's poll limit
+    // turns any surprise into an error instead of a hang.
+    ASB_HIP(ctx, hipMemsetAsync(ctx->coop_bar, 0, 4 * sizeof(unsigned), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(ctx->coop_rec, 0, (size_t)2 * grid * sizeof(CoopRec), ctx->stream));
+    hipLaunchKernelGGL(k_panel_coop<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (long long)ctx->m_cap, (int)ctx->F,
+                       (int)ctx->Fp, ctx->W, ctx->scal, k0, steps, ctx->pstate, ctx->cand_idx, ctx->coop_bar,
+                       (CoopRec*)ctx->coop_rec, ctx->coop_w);
+    ASB_CHECK_LAUNCH(ctx);
+    *launched = true;
+    return ASB_OK;
+}
+
 // up to `steps` greedy steps on the context's candidate buffer (asb_panel_select with NULL
 // buffers, or asb_panel_assemble); returns the number of components committed.
 extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int64_t* committed) {
@@ -1237,7 +1440,19 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         launch_stream(ctx, c, false, grid, a);
         ctx->cnblk = grid;
     }
-    for (int t = 0; t < steps; ++t) {
+    bool coop = false;
+    if (ctx->panel_coop && ctx->Fp <= 2048) {      // the whole inner loop in one cooperative launch, rows in registers
+        const int cgrid = (int)((ctx->m_cap + 3) / 4);
+        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 6))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid * 8))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid * ctx->Fp))) return rc;
+        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid, k0, steps, &coop);
+        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid, k0, steps, &coop);
+        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop);
+        else rc = launch_panel_coop<32>(ctx, cgrid, k0, steps, &coop);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < (coop ? 0 : steps); ++t) {
         const long long k = k0 + t;
         hipLaunchKernelGGL(k_pick_panel, dim3(1), dim3(ASB_PP_T), 0, ctx->stream, ctx->candR, ctx->cand_c, (long long)ctx->m_cap,
                            ctx->cpmax, ctx->cpidx, ctx->cnblk, (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal, k,
@@ -1253,6 +1468,27 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *committed = h.committed;
     ctx->n_panels++;
+    if (coop) {
+        unsigned flags[4];
+        ASB_HIP(ctx, hipMemcpy(flags, ctx->coop_bar, sizeof(flags), hipMemcpyDeviceToHost));
+        if (flags[1]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "panel kernel: the grid barrier timed out (blocks not co-resident?)");
+        if (flags[2]) {               // more candidates than resident waves: this panel runs through the two-kernel loop
+            const int save = ctx->panel_coop;
+            ctx->panel_coop = 0;
+            ctx->n_panels--;
+            rc = asb_panel_run(ctx, k0, steps, global_all, assembled, committed);
+            ctx->panel_coop = save;
+            return rc;
+        }
+    }
+    if (coop && getenv("ASB_DEBUG_PANELS")) {
+        unsigned long long tl[16 * 6];
+        (void)hipMemcpy(tl, ctx->coop_bar + 4, sizeof(tl), hipMemcpyDeviceToHost);
+        for (int t = 0; t < (int)h.committed && t < 16; ++t)
+            fprintf(stderr, "[asb]   step %2d: record %.2f us | poll %.2f | reduce %.2f | w_sh+publish %.2f | deflate %.2f\n", t,
+                    (tl[t * 6 + 1] - tl[t * 6 + 0]) * 0.01, (tl[t * 6 + 2] - tl[t * 6 + 1]) * 0.01, (tl[t * 6 + 3] - tl[t * 6 + 2]) * 0.01,
+                    (tl[t * 6 + 4] - tl[t * 6 + 3]) * 0.01, (tl[t * 6 + 5] - tl[t * 6 + 4]) * 0.01);
+    }
     if (getenv("ASB_DEBUG_PANELS")) {
         double sc[8];
         (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
