@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long
 
 // level 1: find the bin where the count from the top reaches m_target -> next range.
 // level 2: final tau (lower edge of the crossing bin; upper edge if that overflows m_cap).
-__global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, double* __restrict__ sc, int level,
+__global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __restrict__ sc, int level,
                                              long long m_target, long long m_cap) {
     __shared__ int lh[ASB_NBINS];
     __shared__ int seg[256];
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, doubl
     int ssum = 0;
     for (int q = 0; q < PER; ++q) {
         const int v = hist[threadIdx.x * PER + q];
+        hist[threadIdx.x * PER + q] = 0;          // consumed: the next k_hist accumulates into zeros again
         lh[threadIdx.x * PER + q] = v;
         ssum += v;
     }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void k_tau(const int* __restrict__ hist, doubl
     if (threadIdx.x != 0) return;
     const double lo = sc[SC_LO], hi = sc[SC_HI];
     const double width = (hi - lo) / (double)ASB_NBINS;
-    long long acc = (long long)sc[SC_ABOVE];
+    long long acc = (level == 1) ? 0 : (long long)sc[SC_ABOVE];      // vertices above the binade found at level 1
     int sg = 255;
     for (; sg >= 0; --sg) {                 // coarse: segments of PER bins from the top
         if (acc + seg[sg] >= m_target) break;
@@ -277,8 +278,14 @@ __global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ 
 }
 
 // arms the panel: every vertex outside the candidate buffer has energy <= theta
-__global__ void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
-                            long long n_slots, double margin_rel) {
+__global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
+                            long long n_slots, double margin_rel, unsigned* __restrict__ coop_flags,
+                            unsigned long long* __restrict__ coop_rec, int n_rec) {
+    // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4)
+    if (coop_flags && threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
+    if (coop_rec)
+        for (int r = threadIdx.x; r < n_rec; r += blockDim.x) coop_rec[(size_t)r * 8 + 4] = 0ull;
+    if (threadIdx.x != 0) return;
     if (n_slots >= 0) panel->n_cand = n_slots;
     panel->theta = global_all ? -1.0e300 : (panel->pad ? 1.0e300 : sc[SC_TAU]);
     panel->margin = margin_rel * sc[SC_E0MAX];
@@ -618,7 +625,9 @@ __global__ __launch_bounds__(1024) void k_project_lds(
 // 256 KB panel stays L2-resident.  No LDS, no partial tiles, one launch per pass; whole rows are streamed
 // (the access pattern measured at 5.7 TB/s by tools/probe_stream_patterns.hip).
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_wq(const double* __restrict__ Wt, int Fp, double* __restrict__ Wq) {
+__global__ __launch_bounds__(256) void k_build_wq(const double* __restrict__ Wt, int Fp, double* __restrict__ Wq,
+                                                  unsigned* __restrict__ tile_counter) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) tile_counter[threadIdx.x] = 0u;      // the projection kernel's work queue
     const long long total = (long long)Fp * 16;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(e & 3), i = (int)((e >> 2) & 15), g = (int)((e >> 6) & 3);
@@ -825,8 +834,7 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->Wq, (size_t)ctx->Fp * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
-    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq);
-    ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq, ctx->tile_counter);
     const int variant = ctx->l2_variant;
     const int NT = variant == 0 ? 2 : (variant == 1 ? 3 : 4);
     const long long ntiles = (rows + 16 * NT - 1) / (16 * NT);
@@ -912,6 +920,7 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if ((rc = asb_alloc(ctx, &ctx->cpsum, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->colpart, (size_t)ctx->nblk_cap * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
     if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->gram, (size_t)K * ASB_PANEL_COLS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ctmp, (size_t)ASB_CBLOCKS * ctx->m_cap))) return rc;
@@ -1139,11 +1148,9 @@ static int hist_grid(const asb_ctx* ctx) {
 extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
     int* h = hist_dev ? hist_dev : ctx->hist;
-    if (level == 1) {      // the count above the crossing bin starts from 0
-        const double zero = 0.0;
-        ASB_HIP(ctx, hipMemcpyAsync(ctx->scalar_dev + SC_ABOVE, &zero, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
-    ASB_HIP(ctx, hipMemsetAsync(h, 0, ASB_NBINS * sizeof(int), ctx->stream));
+    // the context's own histogram is zero here: cleared when the mode starts and by every asb_panel_tau that consumed
+    // it; a caller's buffer (all-reduced in between) is cleared explicitly
+    if (hist_dev) ASB_HIP(ctx, hipMemsetAsync(h, 0, ASB_NBINS * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_hist, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc,
                        ctx->scalar_dev, h, level == 1 ? 1 : 0);
     ASB_CHECK_LAUNCH(ctx);
@@ -1152,7 +1159,7 @@ extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
 
 extern "C" int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
-    hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, hist_dev ? hist_dev : ctx->hist, ctx->scalar_dev, level,
+    hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, hist_dev ? const_cast<int*>(hist_dev) : ctx->hist, ctx->scalar_dev, level,
                        (long long)ctx->m_target, (long long)ctx->m_cap);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -1411,8 +1418,6 @@ static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bo
     // nothing these blocks wait for depends on other work, so they all become resident (a cooperative launch would
     // assert the same thing but is not usable on every stream, e.g. torch's null stream).  The barrier's poll limit
     // turns any surprise into an error instead of a hang.
-    ASB_HIP(ctx, hipMemsetAsync(ctx->coop_bar, 0, 4 * sizeof(unsigned), ctx->stream));
-    ASB_HIP(ctx, hipMemsetAsync(ctx->coop_rec, 0, (size_t)2 * grid * sizeof(CoopRec), ctx->stream));
     hipLaunchKernelGGL(k_panel_coop<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (long long)ctx->m_cap, (int)ctx->F,
                        (int)ctx->Fp, ctx->W, ctx->scal, k0, steps, ctx->pstate, ctx->cand_idx, ctx->coop_bar,
                        (CoopRec*)ctx->coop_rec, ctx->coop_w);
@@ -1431,8 +1436,16 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ASB_PANEL_COLS * ctx->m_cap * 3))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->slab_scratch, (size_t)3 * ctx->Fp))) return rc;
-    hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(1), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
-                       (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL);
+    const int cgrid_all = (int)((ctx->m_cap + 3) / 4);
+    const bool want_coop = ctx->panel_coop && ctx->Fp <= 2048;
+    if (want_coop) {
+        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 6))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid_all * 8))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid_all * ctx->Fp))) return rc;
+    }
+    hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
+                       (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
+                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     if (assembled) {      // energies / partial records of the assembled buffer (rows came from other ranks)
         StreamArgs a{ctx->candR, nullptr, nullptr, nullptr, nullptr, ctx->cand_e, ctx->cpmax, ctx->cpidx, ctx->cpsum,
@@ -1441,11 +1454,8 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         ctx->cnblk = grid;
     }
     bool coop = false;
-    if (ctx->panel_coop && ctx->Fp <= 2048) {      // the whole inner loop in one cooperative launch, rows in registers
-        const int cgrid = (int)((ctx->m_cap + 3) / 4);
-        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 6))) return rc;
-        if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid * 8))) return rc;
-        if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid * ctx->Fp))) return rc;
+    if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
+        const int cgrid = cgrid_all;
         if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid, k0, steps, &coop);
         else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid, k0, steps, &coop);
         else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop);

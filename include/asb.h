@@ -136,7 +136,7 @@ int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
 int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max_local, double set_e0max);
 /* local energy histogram (ASB_NBINS = 2048 ints) into hist_dev (NULL: internal) */
 int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev);
-/* threshold step from the (summed) histogram */
+/* threshold step from the (summed) histogram; the histogram is consumed (cleared to zero) */
 int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev);
 /* this shard's candidates (energy > tau; every vertex when global_all; only forced_gidx when
  * >= 0), in vertex order, and their exact residual rows (3*Fp doubles each) into the caller's
