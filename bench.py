@@ -163,7 +163,7 @@ def main():
         traffic = None
         pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))["kernels"]
             kname = {2: "k_project_lds", 3: "k_project_l2<4, 2>"}.get(pk)
             if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1):
                 traffic = pm[kname]["hbm_bytes"]
