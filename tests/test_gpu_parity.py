@@ -775,3 +775,24 @@ def test_multirank_pca_blocks_on_one_gpu(p, tmp_path):
     r = orc.pca_blocks(pre["snapTensor"], K, p)
     for cc in outs:
         _check_blocks(cc, r["comps"], r["weigs"], r["measures"], r["points"], r["blocks"], tol=1e-8)
+
+
+@pytest.mark.parametrize("N,F", [(1300, 1100), (1300, 96), (900, 1500)])
+def test_panel_kernel_candidate_capacity(N, F):
+    """The co-resident panel kernel holds one candidate per wave.  With every vertex a candidate (N below the buffer
+    capacity) and F > 1024 only 1024 waves are resident: N = 1300 must go through the two-kernel fallback of that
+    panel, N = 900 and small F through the register kernel -- all three must give the oracle's sequence."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(N + F)
+    K = 12
+    X = rng.normal(size=(F, N, 3))
+    e = HipEngine(0)
+    e.upload(X, 0, N)
+    e.deflate_begin(K, False, 1)
+    e.run_global(0, K)
+    r = e.results()
+    e.close()
+    ref = orc.extract_k_components(X, K)
+    assert r["idx"].tolist() == ref["idx"].tolist()
+    comps, weigs = align_signs(r["comps"], r["weigs"], ref["comps"])
+    assert relerr(comps, ref["comps"]) < 1e-9 and relerr(weigs, ref["weigs"]) < 1e-9
