@@ -17,6 +17,7 @@ c_int = ctypes.c_int
 c_dbl = ctypes.c_double
 
 ASB_OK = 0
+ERR_LIMIT = -4          # ASB_ERR_LIMIT
 DEFLATE_RESIDUAL, DEFLATE_PROJECT = 0, 1
 
 # name -> (restype, argtypes): must list every symbol of include/asb.h
@@ -46,6 +47,10 @@ PROTOTYPES = {
     "asb_panel_scale": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_dbl]),
     "asb_panel_hist": (c_int, [ctypes.c_void_p, c_int, c_dp]),
     "asb_panel_tau": (c_int, [ctypes.c_void_p, c_int, c_dp]),
+    "asb_panel_top_energies": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
+    "asb_panel_global_tau": (c_int, [ctypes.c_void_p, c_dp, c_int, c_i64, c_dp]),
+    "asb_panel_set_tau": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_panel_target": (c_i64, [ctypes.c_void_p]),
     "asb_panel_select": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_int, c_dp, c_dp, ctypes.POINTER(c_i64),
                                  ctypes.POINTER(c_int)]),
     "asb_panel_capacity": (c_i64, [ctypes.c_void_p]),

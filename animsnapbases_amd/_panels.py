@@ -4,35 +4,54 @@ import numpy as np
 
 
 def deflate_panels_multirank(eng, comm, n_rows, K):
-    """Projection-mode deflation over several ranks.  Per PANEL (up to 16
-    components): two histogram all-reduces fix the global threshold, each rank rebuilds the
-    exact residual rows of its own candidates, ONE padded all-gather replicates the ~1000
-    candidate rows on every rank, every rank runs the identical greedy steps on them (no
-    per-component collective), then projects its own shard.  Ranks stay in lock-step because
-    every decision is taken on all-reduced / all-gathered data."""
+    """Projection-mode deflation over several ranks.  Per PANEL (up to 16 components):
+      1. every rank thresholds its OWN energies (two local histogram steps, no collective) and exports its ~768 largest
+         energies + its local threshold; ONE small all-gather (12 KB per rank) gives every rank the same global
+         threshold tau -- the (m_target+1)-th largest energy overall, never below a rank's local bound -- and the
+         per-rank candidate counts;
+      2. each rank rebuilds the exact residual rows of its own candidates (energy > tau); a padded all-gather of
+         rows and of vertex ids replicates the ~768 candidate rows on every rank;
+      3. every rank runs the identical greedy steps on them (no per-component collective), then projects its shard.
+    Three collectives and two host synchronisations per panel.  Ranks stay in lock-step because every decision is
+    a function of all-gathered data."""
     dev = comm.exchange_device(eng.device_exchange)
     torch = comm._torch
     cap, rl = eng.panel_capacity(), eng.panel_row_len()
+    m_target = eng.panel_target()
     _, e0 = eng.panel_scale()
     eng.panel_scale(set_e0max=float(comm.allreduce_max(e0)[0]))
-    hist = torch.zeros(eng.NBINS, dtype=torch.int32, device=dev)
     rows_loc = torch.zeros(cap * rl, dtype=torch.float64, device=dev)
     idx_loc = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    top_loc = torch.empty(cap + 1, dtype=torch.float64, device=dev)
+    top_all = torch.empty(comm.world * (cap + 1), dtype=torch.float64, device=dev)
     global_all = n_rows <= cap
     k, stalled, forced_next = 0, 0, -1
     while k < K:
         forced = forced_next if stalled >= 2 else -1
-        if forced < 0 and not global_all:
-            for level in (1, 2):
-                eng.panel_hist(level, hist.data_ptr())
-                comm.allreduce_tensor(hist)
-                eng.panel_tau(level, hist.data_ptr())
         take_all = forced >= 0 or global_all
-        n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), forced, take_all)
-        info = comm.all_gather_ints([n_c, int(ov)])
-        counts, total = info[:, 0].copy(), int(info[:, 0].sum())
+        if not take_all:
+            for level in (1, 2):                         # local threshold: ~m_target of this rank's vertices above it
+                eng.panel_hist(level, None)
+                eng.panel_tau(level, None)
+            eng.panel_top_energies(top_loc.data_ptr(), cap)
+            comm.all_gather_into(top_all, top_loc)
+            counts = eng.panel_global_tau(top_all.data_ptr(), comm.world, cap)      # tau installed; the panel's first host sync
+            if counts is None:                            # table too large for the selection kernel: same rule with torch
+                tab = top_all.view(comm.world, cap + 1)
+                exported = tab[:, :cap].reshape(-1)
+                kth = torch.topk(exported, m_target + 1).values[-1].clamp(min=0.0)
+                tau = torch.maximum(kth, tab[:, cap].max()).reshape(1).contiguous()
+                eng.panel_set_tau(tau.data_ptr())
+                counts = (tab[:, :cap] > tau).sum(dim=1).cpu().numpy().astype(np.int64)
+            eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), -1, False, want_counts=False)
+            overflow = False
+        else:
+            n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), forced, True)
+            info = comm.all_gather_ints([n_c, int(ov)])
+            counts, overflow = info[:, 0].copy(), bool(info[:, 1].any())
+        total = int(counts.sum())
         done = 0
-        if not info[:, 1].any() and 0 < total <= cap:
+        if not overflow and 0 < total <= cap:
             maxc = int(counts.max())
             rows_g = torch.empty(comm.world * maxc * rl, dtype=torch.float64, device=dev)
             idx_g = torch.empty(comm.world * maxc, dtype=torch.int64, device=dev)
@@ -56,4 +75,3 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
         stalled = 0
         eng.panel_project(k, done)
         k += done
-

@@ -1165,6 +1165,49 @@ extern "C" int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev) {
     return ASB_OK;
 }
 
+// Multi-rank thresholding in ONE exchange.  After the two local histogram steps (asb_panel_hist / asb_panel_tau with
+// NULL buffers: no all-reduce) this writes the shard's energies above its LOCAL threshold into out_dev[0 .. cap)
+// (unordered, the rest -1) and the local threshold -- a bound on everything not exported -- into out_dev[cap].
+// The ranks all-gather these (cap + 1 doubles each); the global threshold is then
+//   tau = max( (m_target + 1)-th largest exported energy,  max over ranks of the local thresholds ),
+// which every rank installs with asb_panel_set_tau before asb_panel_select.
+__global__ __launch_bounds__(256) void k_export_above(const double* __restrict__ energy, long long n, const double* __restrict__ sc,
+                                                      long long cap, double* __restrict__ out, unsigned* __restrict__ counter) {
+    const double tau = sc[SC_TAU];
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+        const double e = energy[v];
+        if (e > tau) {
+            const unsigned slot = atomicAdd(counter, 1u);
+            if (slot < cap) out[slot] = e;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[cap] = tau;
+}
+__global__ __launch_bounds__(256) void k_fill(double* __restrict__ out, long long n, double v, unsigned* __restrict__ counter) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = v;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0u;
+}
+
+extern "C" int asb_panel_top_energies(asb_ctx* ctx, double* out_dev, int64_t cap) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !out_dev || cap < 1) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    unsigned* counter = ctx->tile_counter + 15;
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, ctx->stream, out_dev, (long long)cap + 1, -1.0, counter);
+    hipLaunchKernelGGL(k_export_above, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc,
+                       ctx->scalar_dev, (long long)cap, out_dev, counter);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// installs the candidate threshold (a device scalar): asb_panel_select then takes energy > tau, asb_panel_run uses
+// tau as the bound on every non-candidate
+extern "C" int asb_panel_set_tau(asb_ctx* ctx, const double* tau_dev) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !tau_dev) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->scalar_dev + SC_TAU, tau_dev, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+
 // ordered compaction of this shard's candidates (E > tau; all vertices when global_all; only
 // forced_gidx when >= 0) and their exact residual rows.  rows_out / idx_out: caller's device
 // buffers of capacity m_cap (multi-rank staging) or NULL for the context's own candidate buffer.
@@ -1203,25 +1246,120 @@ extern "C" int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, in
 
 // multi-rank: builds the (replicated) global candidate buffer from the all-gathered, padded
 // per-rank pieces: rows_g (world, maxcount, 3, Fp), idx_g (world, maxcount), counts (world).
+struct RankCounts { long long c[16]; };
+// one block per candidate slot: slot -> (rank, position in that rank's padded piece) -> copy the row and its vertex id
+__global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ rows_g, const long long* __restrict__ idx_g, RankCounts cnt,
+                                                  int world, long long maxcount, long long row_len, double* __restrict__ candR,
+                                                  long long* __restrict__ cand_idx, long long total) {
+    for (long long s = blockIdx.x; s < total; s += gridDim.x) {
+        long long off = s;
+        int r = 0;
+        while (r < world - 1 && off >= cnt.c[r]) { off -= cnt.c[r]; ++r; }
+        const double2* src = reinterpret_cast<const double2*>(rows_g + ((long long)r * maxcount + off) * row_len);
+        double2* dst = reinterpret_cast<double2*>(candR + s * row_len);
+        for (long long j = threadIdx.x; j < row_len / 2; j += 256) dst[j] = src[j];
+        if (threadIdx.x == 0) cand_idx[s] = idx_g[(long long)r * maxcount + off];
+    }
+}
+
 extern "C" int asb_panel_assemble(asb_ctx* ctx, const double* rows_g, const long long* idx_g, const int64_t* counts,
                                   int world, int64_t maxcount) {
     if (!ctx || !ctx->candR || !rows_g || !idx_g || !counts) return ASB_ERR_ARG;
-    const size_t row_b = (size_t)3 * ctx->Fp * sizeof(double);
+    if (world < 1 || world > 16) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_panel_assemble: at most 16 ranks (got %d)", world);
+    RankCounts rc_;
     int64_t off = 0;
+    for (int r = 0; r < 16; ++r) rc_.c[r] = 0;
     for (int r = 0; r < world; ++r) {
         const int64_t c = counts[r];
         if (c < 0 || c > maxcount) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_assemble: bad count");
         if (off + c > ctx->m_cap) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_panel_assemble: %lld candidates exceed the capacity %lld",
                                            (long long)(off + c), (long long)ctx->m_cap);
-        if (c > 0) {
-            ASB_HIP(ctx, hipMemcpyAsync((char*)ctx->candR + (size_t)off * row_b, (const char*)rows_g + (size_t)r * maxcount * row_b,
-                                        (size_t)c * row_b, hipMemcpyDeviceToDevice, ctx->stream));
-            ASB_HIP(ctx, hipMemcpyAsync(ctx->cand_idx + off, idx_g + (size_t)r * maxcount, (size_t)c * sizeof(long long),
-                                        hipMemcpyDeviceToDevice, ctx->stream));
-        }
+        rc_.c[r] = c;
         off += c;
     }
+    if (off > 0) {
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)(off < 2048 ? off : 2048)), dim3(256), 0, ctx->stream, rows_g, idx_g, rc_, world,
+                           (long long)maxcount, (long long)(3 * ctx->Fp), ctx->candR, ctx->cand_idx, (long long)off);
+        ASB_CHECK_LAUNCH(ctx);
+    }
     ctx->n_slots_host = off;
+    return ASB_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Global threshold of the multi-rank panel from the all-gathered exports (asb_panel_top_energies): exact radix select
+// of the (m_target + 1)-th largest energy in LDS (8 passes over the 64-bit patterns, which order like the non-negative
+// doubles they encode), tau = max(that, the ranks' local thresholds) -> SC_TAU, and the per-rank candidate counts.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_global_tau(const double* __restrict__ tab, int world, long long cap, long long want,
+                                                     double* __restrict__ sc, long long* __restrict__ counts) {
+    extern __shared__ unsigned long long keys[];          // world * cap
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long prefix_sh;
+    __shared__ long long remaining_sh;
+    __shared__ double tau_sh;
+    const int tid = threadIdx.x;
+    const long long n = (long long)world * cap;
+    for (long long i = tid; i < n; i += 1024) {
+        const double e = tab[(i / cap) * (cap + 1) + (i % cap)];
+        keys[i] = (e > 0.0) ? (unsigned long long)__double_as_longlong(e) : 0ull;
+    }
+    if (tid == 0) { prefix_sh = 0ull; remaining_sh = want; }
+    __syncthreads();
+    for (int byte = 7; byte >= 0; --byte) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = prefix_sh;
+        for (long long i = tid; i < n; i += 1024) {
+            const unsigned long long kx = keys[i];
+            if (byte == 7 || (kx >> (8 * (byte + 1))) == prefix) atomicAdd(&hist[(kx >> (8 * byte)) & 255ull], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long rem = remaining_sh;
+            int b = 255;
+            for (; b > 0; --b) {
+                if ((long long)hist[b] >= rem) break;
+                rem -= hist[b];
+            }
+            remaining_sh = rem;
+            prefix_sh = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double tau = (n >= want) ? __longlong_as_double((long long)prefix_sh) : 0.0;
+        for (int r = 0; r < world; ++r) tau = fmax(tau, tab[(long long)r * (cap + 1) + cap]);
+        tau_sh = tau;
+        sc[SC_TAU] = tau;
+    }
+    __syncthreads();
+    const double tau = tau_sh;
+    const int wv = tid >> 6, lane = tid & 63;
+    for (int r = wv; r < world; r += 16) {
+        long long c = 0;
+        for (long long i = lane; i < cap; i += 64) c += tab[(long long)r * (cap + 1) + i] > tau ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) counts[r] = c;
+    }
+}
+
+// tab_dev: (world, cap + 1) all-gathered exports.  Installs tau on the device and returns the per-rank candidate counts.
+extern "C" int asb_panel_global_tau(asb_ctx* ctx, const double* tab_dev, int world, int64_t cap, int64_t* counts_out) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !tab_dev || !counts_out || world < 1 || cap < 1) return ASB_ERR_ARG;
+    const size_t lds = (size_t)world * cap * sizeof(unsigned long long);
+    if (world > 16 || lds > 150 * 1024) return ASB_ERR_LIMIT;        // the caller falls back to its own selection
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_idx, (size_t)256))) return rc;
+    if (lds > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_global_tau, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_global_tau, dim3(1), dim3(1024), lds, ctx->stream, tab_dev, world, (long long)cap,
+                       (long long)ctx->m_target + 1, ctx->scalar_dev, ctx->bam_idx);
+    ASB_CHECK_LAUNCH(ctx);
+    long long h[16];
+    ASB_HIP(ctx, hipMemcpyAsync(h, ctx->bam_idx, (size_t)world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < world; ++r) counts_out[r] = h[r];
     return ASB_OK;
 }
 
@@ -1447,12 +1585,6 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
                        want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
-    if (assembled) {      // energies / partial records of the assembled buffer (rows came from other ranks)
-        StreamArgs a{ctx->candR, nullptr, nullptr, nullptr, nullptr, ctx->cand_e, ctx->cpmax, ctx->cpidx, ctx->cpsum,
-                     (long long)ctx->m_cap, ctx->pstate};
-        launch_stream(ctx, c, false, grid, a);
-        ctx->cnblk = grid;
-    }
     bool coop = false;
     if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
         const int cgrid = cgrid_all;
@@ -1461,6 +1593,12 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop);
         else rc = launch_panel_coop<32>(ctx, cgrid, k0, steps, &coop);
         if (rc) return rc;
+    }
+    if (assembled && !coop) {      // two-kernel loop: energies / partial records of the assembled buffer (rows came from other ranks)
+        StreamArgs a{ctx->candR, nullptr, nullptr, nullptr, nullptr, ctx->cand_e, ctx->cpmax, ctx->cpidx, ctx->cpsum,
+                     (long long)ctx->m_cap, ctx->pstate};
+        launch_stream(ctx, c, false, grid, a);
+        ctx->cnblk = grid;
     }
     for (int t = 0; t < (coop ? 0 : steps); ++t) {
         const long long k = k0 + t;
@@ -1568,6 +1706,7 @@ extern "C" int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max
 }
 
 extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_cap : 0; }
+extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? ctx->m_target : 0; }
 
 // single-rank driver: all K components with no host round trip inside a panel
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {

@@ -172,11 +172,30 @@ class HipEngine(object):
         self._ck(self.lib.asb_panel_scale(self.h, ctypes.byref(a), ctypes.byref(b), float(set_e0max)))
         return a.value, b.value
 
-    def panel_hist(self, level, hist_ptr):
-        self._ck(self.lib.asb_panel_hist(self.h, int(level), ctypes.c_void_p(hist_ptr)))
+    def panel_hist(self, level, hist_ptr=None):
+        self._ck(self.lib.asb_panel_hist(self.h, int(level), ctypes.c_void_p(hist_ptr) if hist_ptr else None))
 
-    def panel_tau(self, level, hist_ptr):
-        self._ck(self.lib.asb_panel_tau(self.h, int(level), ctypes.c_void_p(hist_ptr)))
+    def panel_tau(self, level, hist_ptr=None):
+        self._ck(self.lib.asb_panel_tau(self.h, int(level), ctypes.c_void_p(hist_ptr) if hist_ptr else None))
+
+    def panel_top_energies(self, out_ptr, cap):
+        self._ck(self.lib.asb_panel_top_energies(self.h, ctypes.c_void_p(out_ptr), int(cap)))
+
+    def panel_global_tau(self, tab_ptr, world, cap):
+        """Per-rank candidate counts after installing the global threshold; None when the table is too large for the
+        device selection (the caller then selects with torch and calls panel_set_tau)."""
+        counts = np.empty(world, dtype=np.int64)
+        rc = self.lib.asb_panel_global_tau(self.h, ctypes.c_void_p(tab_ptr), int(world), int(cap), ptr(counts))
+        if rc == _lib.ERR_LIMIT:
+            return None
+        self._ck(rc)
+        return counts
+
+    def panel_set_tau(self, tau_ptr):
+        self._ck(self.lib.asb_panel_set_tau(self.h, ctypes.c_void_p(tau_ptr)))
+
+    def panel_target(self):
+        return int(self.lib.asb_panel_target(self.h))
 
     def panel_capacity(self):
         return int(self.lib.asb_panel_capacity(self.h))
@@ -184,7 +203,11 @@ class HipEngine(object):
     def panel_row_len(self):
         return 3 * ((self.F + 15) // 16 * 16)
 
-    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False):
+    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False, want_counts=True):
+        if not want_counts:          # no host synchronisation: the caller knows the counts from the gathered energies
+            self._ck(self.lib.asb_panel_select(self.h, int(k), int(forced_gidx), int(bool(global_all)),
+                                               ctypes.c_void_p(rows_ptr), ctypes.c_void_p(idx_ptr), None, None))
+            return None, None
         n, ov = ctypes.c_int64(), ctypes.c_int()
         self._ck(self.lib.asb_panel_select(self.h, int(k), int(forced_gidx), int(bool(global_all)),
                                            ctypes.c_void_p(rows_ptr), ctypes.c_void_p(idx_ptr), ctypes.byref(n),

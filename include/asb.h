@@ -138,6 +138,17 @@ int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max_local, dou
 int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev);
 /* threshold step from the (summed) histogram; the histogram is consumed (cleared to zero) */
 int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev);
+/* One-exchange thresholding for several ranks: after the LOCAL histogram steps (hist_dev = NULL, no all-reduce),
+ * asb_panel_top_energies writes this shard's energies above its local threshold into out_dev[0 .. cap) (unordered,
+ * padded with -1) and that local threshold into out_dev[cap].  The ranks all-gather the cap + 1 doubles; the global
+ * threshold tau = max((m_target + 1)-th largest exported energy, max of the local thresholds) is installed with
+ * asb_panel_set_tau (device scalar) on every rank.  asb_panel_target: m_target. */
+int asb_panel_top_energies(asb_ctx* ctx, double* out_dev, int64_t cap);
+/* the same selection on the device: tab_dev = the all-gathered (world, cap + 1) exports; installs tau and returns the
+ * per-rank candidate counts (host, world).  ASB_ERR_LIMIT when world * cap does not fit the selection kernel's LDS. */
+int asb_panel_global_tau(asb_ctx* ctx, const double* tab_dev, int world, int64_t cap, int64_t* counts_out);
+int asb_panel_set_tau(asb_ctx* ctx, const double* tau_dev);
+int64_t asb_panel_target(const asb_ctx* ctx);
 /* this shard's candidates (energy > tau; every vertex when global_all; only forced_gidx when
  * >= 0), in vertex order, and their exact residual rows (3*Fp doubles each) into the caller's
  * device buffers of capacity asb_panel_capacity() (NULL: the context's own buffer).

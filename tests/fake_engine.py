@@ -172,8 +172,15 @@ class FakeEngine(object):
     def panel_row_len(self):
         return 3 * self.F
 
-    def panel_hist(self, level, hist_ptr):
-        h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
+    def _hist_buf(self, hist_ptr):
+        if not hist_ptr:                 # NULL: the context's own (local) histogram
+            if not hasattr(self, "_own_hist"):
+                self._own_hist = np.zeros(self.NBINS, dtype=np.int32)
+            return self._own_hist
+        return np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
+
+    def panel_hist(self, level, hist_ptr=None):
+        h = self._hist_buf(hist_ptr)
         if level == 1:                                        # biased-exponent histogram
             self.above = 0
             e = self.E[self.E >= 0]
@@ -184,8 +191,28 @@ class FakeEngine(object):
             b = np.minimum(((e - self.lo) * scale).astype(np.int64), self.NBINS - 1)
         h[:] = np.bincount(b, minlength=self.NBINS).astype(np.int32)[:self.NBINS]
 
-    def panel_tau(self, level, hist_ptr):
-        h = np.ctypeslib.as_array((ctypes.c_int32 * self.NBINS).from_address(hist_ptr))
+    def panel_target(self):
+        return self.M_TARGET
+
+    def panel_top_energies(self, out_ptr, cap):
+        out = _view(out_ptr, cap + 1)
+        out[:] = -1.0
+        e = self.E[self.E > self.tau][:cap]
+        out[:e.size] = e[::-1]                      # any order: the device export is unordered too
+        out[cap] = self.tau
+
+    def panel_global_tau(self, tab_ptr, world, cap):
+        tab = _view(tab_ptr, world * (cap + 1)).reshape(world, cap + 1)
+        exported = np.sort(tab[:, :cap].reshape(-1))[::-1]
+        kth = max(exported[self.M_TARGET], 0.0) if exported.size > self.M_TARGET else 0.0
+        self.tau = float(max(kth, tab[:, cap].max()))
+        return (tab[:, :cap] > self.tau).sum(axis=1).astype(np.int64)
+
+    def panel_set_tau(self, tau_ptr):
+        self.tau = float(_view(tau_ptr, 1)[0])
+
+    def panel_tau(self, level, hist_ptr=None):
+        h = self._hist_buf(hist_ptr)
         acc, b = self.above, self.NBINS - 1
         while b >= 0 and acc + h[b] < self.M_TARGET:
             acc += int(h[b])
@@ -213,7 +240,7 @@ class FakeEngine(object):
             R -= self.W[j][:, None, None] * self.C[j][vloc][None]
         return R
 
-    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False):
+    def panel_select(self, k, rows_ptr, idx_ptr, forced_gidx=-1, global_all=False, want_counts=True):
         if forced_gidx >= 0:
             vloc = np.array([forced_gidx - self.v0]) if self.v0 <= forced_gidx < self.v0 + self.n_loc else np.zeros(0, np.int64)
         elif global_all:
