@@ -66,6 +66,8 @@ PROTOTYPES = {
     "asb_orth_gram": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_orth_apply": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_orth_refine": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_orth_gram_get": (c_int, [ctypes.c_void_p, c_dp]),
+    "asb_components_transform": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_download": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_components_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64]),
     "asb_geodesic_setup": (c_int, [ctypes.c_void_p, c_int, c_int] + [c_dp] * 14),

@@ -29,7 +29,7 @@ from . import _lib
 from ._panels import deflate_panels_multirank
 from .distributed import Comm
 from .engine import HipEngine
-from .utils import log_time, testSparsity, test_linear_dependency
+from .utils import log_time, qr_factor, summed_grams, testSparsity, test_linear_dependency
 
 constProj_output_directory = ""
 
@@ -355,11 +355,14 @@ class constraintsComponents:  # Components == bases
             ns._snapTensor = None
         if p.constProj_orthogonal:
             for _ in range(2):                                                 # CholeskyQR2
-                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.multi else None
-                eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
-                if Gbuf is not None:
-                    comm.allreduce_tensor(Gbuf)
-                eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+                if self.numComp <= 128:                                        # one-block Cholesky on the device
+                    Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.multi else None
+                    eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+                    if Gbuf is not None:
+                        comm.allreduce_tensor(Gbuf)
+                    eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+                else:                                    # larger K: K x K Cholesky on the host, products on the device
+                    eng.components_transform(qr_factor(summed_grams(eng, comm, self.numComp)))
         if p.constProj_massWeight:
             assert ns.frames_rows == ns.invMassL.shape[0]
             eng.components_post(False, 1.0, ns.invMassL[v0:v0 + n_loc])

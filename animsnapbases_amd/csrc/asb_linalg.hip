@@ -386,7 +386,6 @@ __global__ __launch_bounds__(256) void k_scale_eigvecs(const double* __restrict_
 extern "C" int asb_orth_gram(asb_ctx* ctx, double* G_dev) {
     if (!ctx || !ctx->comps) return ASB_ERR_ARG;
     const int64_t K = ctx->K, n = ctx->n_loc;
-    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "q_orthogonal on the device supports K <= 128 (K = %lld)", (long long)K);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->oct, (size_t)3 * n * K))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->og, (size_t)3 * K * K))) return rc;
@@ -404,6 +403,8 @@ extern "C" int asb_orth_gram(asb_ctx* ctx, double* G_dev) {
 extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out) {
     if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
     const int64_t K = ctx->K, n = ctx->n_loc;
+    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_orth_apply: the one-block eigen-solver takes K <= 128 (K = %lld); "
+                          "use asb_orth_gram_get + asb_components_transform", (long long)K);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->olam, (size_t)3 * K))) return rc;
@@ -457,6 +458,33 @@ extern "C" int asb_orth_refine(asb_ctx* ctx, const double* G_dev) {
         if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, Gl, K, K, (int)n, (int)K, ctx->comps2 + l, 3, 3 * n))) return rc;
     }
     ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+
+// the three K x K Gram matrices asb_orth_gram left in the context (single rank) -> host
+extern "C" int asb_orth_gram_get(asb_ctx* ctx, double* G_host) {
+    if (!ctx || !ctx->og || !G_host) return ASB_ERR_ARG;
+    ASB_HIP(ctx, hipMemcpyAsync(G_host, ctx->og, (size_t)3 * ctx->K * ctx->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// comps[:, :, l] <- T_l^T-combination of the components: new_j = sum_i comps_i T[l][i][j]  (T host, (3, K, K) row-major).
+// The K x K factor of an orthogonalisation whose small dense step ran on the host (K > 128: orth = V S^-1 of the Gram
+// matrix's eigen-decomposition, qr = L^-T of its Cholesky factor); needs asb_orth_gram to have been called.
+extern "C" int asb_components_transform(asb_ctx* ctx, const double* T_host) {
+    if (!ctx || !ctx->comps || !ctx->oct || !T_host) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, n = ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->ovec, T_host, (size_t)3 * K * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    for (int l = 0; l < 3; ++l)
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, ctx->ovec + (size_t)l * K * K, K, K, (int)n, (int)K, ctx->comps2 + l, 3,
+                                3 * n)))
+            return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }
 

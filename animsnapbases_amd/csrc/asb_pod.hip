@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void k_chol_tinv(const double* __restrict__ G,
 extern "C" int asb_qr_apply(asb_ctx* ctx, const double* G_dev) {
     if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
     const int64_t K = ctx->K, n = ctx->n_loc;
+    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_qr_apply: the one-block Cholesky takes K <= 128 (K = %lld); "
+                          "use asb_orth_gram_get + asb_components_transform", (long long)K);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;

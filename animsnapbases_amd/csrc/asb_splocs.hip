@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void k_cholinv(const double* __restrict__ G, d
     }
 }
 
+// out (np x np) = [G + rho I, 0; 0, I]
+__global__ __launch_bounds__(256) void k_pad_spd(const double* __restrict__ G, double rho, int K, int np, double* __restrict__ out) {
+    const long long total = (long long)np * np;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / np), j = (int)(e % np);
+        out[e] = (i < K && j < K) ? G[(long long)i * K + j] + (i == j ? rho : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+}
+
 // rhs = c + rho (Z - U)     (:176)
 __global__ __launch_bounds__(256) void k_admm_rhs(const double* __restrict__ c, const double* __restrict__ Z,
                                                   const double* __restrict__ U, double rho, long long n,
@@ -213,7 +222,6 @@ static int dot_to_host(asb_ctx* ctx, asb_splocs* s, const double* a, const doubl
 
 extern "C" int asb_splocs_begin(asb_ctx* ctx) {
     if (!ctx || !ctx->comps || !ctx->W) return ASB_ERR_ARG;
-    if (ctx->K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "SPLOCS on the device supports K <= 128 (K = %lld)", (long long)ctx->K);
     if (!ctx->splocs) ctx->splocs = new asb_splocs();
     asb_splocs* s = ctx->splocs;
     const int64_t K = ctx->K, n3 = 3 * ctx->n_loc, F = ctx->F;
@@ -295,12 +303,23 @@ extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, i
         if (rc) return rc;
     }
     ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
-    if ((size_t)K * K * sizeof(double) > 48 * 1024)
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_cholinv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(K * K * sizeof(double))));
-    hipLaunchKernelGGL(k_cholinv, dim3(1), dim3(256), (size_t)K * K * sizeof(double), ctx->stream, s->G, rho, (int)K,
-                       s->Ginv, s->status);
-    ASB_CHECK_LAUNCH(ctx);
+    if (K <= 128) {
+        if ((size_t)K * K * sizeof(double) > 48 * 1024)
+            ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_cholinv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(K * K * sizeof(double))));
+        hipLaunchKernelGGL(k_cholinv, dim3(1), dim3(256), (size_t)K * K * sizeof(double), ctx->stream, s->G, rho, (int)K,
+                           s->Ginv, s->status);
+        ASB_CHECK_LAUNCH(ctx);
+    } else {            // larger K: blocked Gauss-Jordan on f64 MFMA (asb_dense.hip) on the matrix padded to a multiple of 16
+        const int np = (int)((K + 15) / 16 * 16);
+        int rc2;
+        if ((rc2 = asb_alloc(ctx, &ctx->dn_test, (size_t)np * np))) return rc2;
+        hipLaunchKernelGGL(k_pad_spd, dim3(256), dim3(256), 0, ctx->stream, s->G, rho, (int)K, np, ctx->dn_test);
+        ASB_CHECK_LAUNCH(ctx);
+        if ((rc2 = asb_dense_spd_inverse(ctx, ctx->dn_test, np))) return rc2;
+        ASB_HIP(ctx, hipMemcpy2DAsync(s->Ginv, (size_t)K * sizeof(double), ctx->dn_test, (size_t)np * sizeof(double),
+                                      (size_t)K * sizeof(double), (size_t)K, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     ASB_HIP(ctx, hipMemcpyAsync(s->Z, s->C, (size_t)K * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // Z = C.copy()
     const long long n = (long long)K * n3;
     const int eg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

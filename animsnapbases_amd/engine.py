@@ -388,6 +388,16 @@ class HipEngine(object):
         self._ck(self.lib.asb_orth_apply(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None, ptr(sing)))
         return sing
 
+    def orth_gram_get(self):
+        G = np.empty((3, self.K, self.K))
+        self._ck(self.lib.asb_orth_gram_get(self.h, ptr(G)))
+        return G
+
+    def components_transform(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        assert T.shape == (3, self.K, self.K)
+        self._ck(self.lib.asb_components_transform(self.h, ptr(T)))
+
     def orth_refine(self, G_dev_ptr=None):
         self._ck(self.lib.asb_orth_refine(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
 

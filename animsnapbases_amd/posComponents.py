@@ -17,6 +17,7 @@ from scipy.linalg import norm, svd, orth
 from . import _lib
 from .distributed import Comm
 from .posSnapshots import posSnapshots
+from . import utils as _u
 from ._panels import deflate_panels_multirank
 from .utils import log_time, store_components, testSparsity, test_linear_dependency
 
@@ -265,18 +266,24 @@ class posComponents:  # Components == bases
             self._comps_on_device = True
         loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None)
         if self.param.q_orthogonal:
-            Gbuf = None
-            if comm.multi:
-                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange)
-            eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
-            if Gbuf is not None:
-                comm.allreduce_tensor(Gbuf)
-            self.ortho_sing_vals = eng.orth_apply(Gbuf.data_ptr() if Gbuf is not None else None)
+            K = self.numComp
+            if K <= 128:                # Gram -> one-block Jacobi eigen-solver -> U = A V S^-1, all on the device
+                Gbuf = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
+                gp = Gbuf.data_ptr() if Gbuf is not None else None
+                eng.orth_gram(gp)
+                if Gbuf is not None:
+                    comm.allreduce_tensor(Gbuf)
+                self.ortho_sing_vals = eng.orth_apply(gp)
+            else:                       # larger K: the K x K eigen-problem on the host, the N x K products on the device
+                T, self.ortho_sing_vals = _u.orth_factor(_u.summed_grams(eng, comm, K), snaps.nVerts)
+                eng.components_transform(T)
             # the Gram route leaves U^T U = I + O(eps cond^2): one Newton-Schulz step with the Gram of U removes it
-            eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+            Gbuf = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
+            gp = Gbuf.data_ptr() if Gbuf is not None else None
+            eng.orth_gram(gp)
             if Gbuf is not None:
                 comm.allreduce_tensor(Gbuf)
-            eng.orth_refine(Gbuf.data_ptr() if Gbuf is not None else None)
+            eng.orth_refine(gp)
             loc = None
         if self.param.q_massWeight:
             assert snaps.nVerts == snaps.invMassL.shape[0]

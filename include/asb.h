@@ -194,6 +194,12 @@ int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
 int asb_orth_gram(asb_ctx* ctx, double* G_dev);
 int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out);
 int asb_orth_refine(asb_ctx* ctx, const double* G_dev);
+/* K > 128 (the one-block eigen-solver / Cholesky of asb_orth_apply / asb_qr_apply stop there): the K x K step of
+ * the orthogonalisation runs on the host.  asb_orth_gram_get: the three Gram matrices of asb_orth_gram (NULL buffer)
+ * to the host; asb_components_transform: comps[:, :, l] <- sum_i comps_i T[l][i][j] with T host (3, K, K) --
+ * T_l = V S^-1 (orth, :284-287) or L^-T (qr, constraintsComponents.py:431-435). */
+int asb_orth_gram_get(asb_ctx* ctx, double* G_host);
+int asb_components_transform(asb_ctx* ctx, const double* T_host);
 /* the device-resident basis (K, n_loc, 3) to the host */
 int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */

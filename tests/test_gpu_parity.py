@@ -796,3 +796,60 @@ def test_panel_kernel_candidate_capacity(N, F):
     assert r["idx"].tolist() == ref["idx"].tolist()
     comps, weigs = align_signs(r["comps"], r["weigs"], ref["comps"])
     assert relerr(comps, ref["comps"]) < 1e-9 and relerr(weigs, ref["weigs"]) < 1e-9
+
+
+def test_orthogonal_large_K_vs_scipy_orth():
+    """q_orthogonal with K = 160 > 128 (bunny's configuration has 200): the K x K eigen-problem runs on the host, the
+    N x K products on the device; result = scipy's SVD-based orth of the same (post-processed) basis, U^T U = I."""
+    from scipy.linalg import orth
+    from animsnapbases_amd import posComponents, posSnapshots
+    rng = np.random.default_rng(160)
+    F, N, K = 200, 900, 160
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = _param(vertPos_numComponents=K, q_orthogonal=True)
+    snaps, comp = _run(verts, None, param)
+    pre_orth = comp.comps / snaps.pre_scale_factor + snaps.mean[None]           # what post-processing orthogonalises
+    comp.post_process_components()
+    for l in range(3):
+        ref = orth(pre_orth[:, :, l].T).T
+        got = comp.comps[:, :, l]
+        sg = np.sign(np.sum(got * ref, axis=1))
+        assert relerr(got * sg[:, None], ref) < 1e-7
+        assert np.allclose(got @ got.T, np.eye(K), atol=1e-10)
+
+
+def test_constraints_qr_large_K(tmp_path):
+    """constProj_orthogonal with K = 200 (the reference's example configurations use 200 - 1000): CholeskyQR2 with the
+    K x K Cholesky on the host == scipy's economic QR up to column signs."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(200)
+    ep, F, K = 1500, 260, 200
+    frames = 0.1 + rng.normal(size=(F, ep, 3))
+    ns, cc = _run_constraints(frames, K, True, tmp_path)
+    raw = cc.comps.copy() / ns.pre_scale_factor + ns.mean[None]
+    cc.post_process_components()
+    for l in range(3):
+        ref = sla.qr(raw[:, :, l].T, mode="economic")[0].T
+        got = cc.comps[:, :, l]
+        sg = np.sign(np.sum(got * ref, axis=1))
+        assert relerr(got * sg[:, None], ref) < 1e-8
+        assert np.allclose(got @ got.T, np.eye(K), atol=1e-11)
+
+
+def test_splocs_large_K_vs_oracle():
+    """SPLOCS with K = 136 > 128: (W^T W + rho I)^-1 through the blocked Gauss-Jordan inverse instead of the one-block
+    Cholesky."""
+    rest_v, tris = orc.synth_mesh(16, 24, seed=3)          # 386 vertices
+    verts = orc.synth_snapshots(rest_v, 150, rank=140, seed=3, kind="bumps", decay=0.985)     # 136 modes above the noise
+    K = 136
+    param = _param(vertPos_numComponents=K, q_support="local", vertPos_bases_type="SPLOCS", vertPos_smooth_max_dist=0.4,
+                   splocs_max_itrs=2, splocs_admm_num_itrs=3, splocs_lambda=2.0, splocs_rho=10.0)
+    snaps, comp = _run(verts, tris, param)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris)
+    d = orc.extract_k_components(pre["snapTensor"], K, "local", geo, 0.1, 0.4)
+    assert comp.selected_vertices.tolist() == d["idx"].tolist()
+    s = orc.splocs_glob_optimization(pre["snapTensor"], d["comps"], d["weigs"], d["R"], geo, 0.1, 0.4, 2, 3, 2.0, 10.0)
+    assert comp.splocs_centres.tolist() == s["idx"].tolist()
+    assert np.allclose(comp.splocs_trace, s["trace"], rtol=1e-8)
+    assert relerr(comp.splocs_comps, s["C"]) < 1e-8
