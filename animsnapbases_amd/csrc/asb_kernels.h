@@ -173,6 +173,14 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_stream(
 
 __host__ __device__ inline void eig3_top(double a00, double a01, double a02, double a11, double a12, double a22,
                          double& lam, double& u0, double& u1, double& u2) {
+    // work on A / max|a_ij|: the convergence test squares the entries, which must neither overflow nor flush to zero
+    // for snapshots scaled like 1e+-120
+    const double sc = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+    const bool scaled = sc > 0.0 && sc < 1.0e300;
+    if (scaled) {
+        const double is = 1.0 / sc;
+        a00 *= is; a01 *= is; a02 *= is; a11 *= is; a12 *= is; a22 *= is;
+    }
     // eigenvector matrix V, column j = (v0j, v1j, v2j)
     double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
     for (int sweep = 0; sweep < 30; ++sweep) {
@@ -195,6 +203,7 @@ __host__ __device__ inline void eig3_top(double a00, double a01, double a02, dou
     if (lead < 0.0) { u0 = -u0; u1 = -u1; u2 = -u2; }
     const double nn = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
     u0 /= nn; u1 /= nn; u2 /= nn;
+    if (scaled) lam *= sc;
 }
 
 // Largest eigen-pair of a symmetric 3 x 3 matrix without the Jacobi sweeps (~6 sweeps x 3 rotations of dependent

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void k_best_energy(const double* pmax, const l
 // against X (not the residual), Y = X.W_panel picks up  sum_j c_j[v] (w_j . w_t).  Left in, it
 // costs eps*kappa^2 (the classical-Gram-Schmidt effect); removing it restores eps*kappa:
 //     c_t[v] = ( X_v . w_t - sum_{j<k0} c_j[v] |w_j|^2-free Gram term ) / |w_t|^2
-// k_panel_gram: G[j][t] = w_j . w_{k0+t}  (j < k0).   k_correct: applies it, then updates the
+// k_panel_gram: G[j][t] = w_j . w_{k0+t}  (j < k0 + ncols).   k_correct: applies it -- earlier panels first, then the
+// panel's own columns in order -- and updates the
 // energies E[v] -= sum_t |w_t|^2 |c_t[v]|^2 and the per-block partial records.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W, const double* __restrict__ Wt,
@@ -381,6 +382,19 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                 }
             }
         }
+        // the same correction among the panel's own columns, in order (column t needs the corrected columns j < t):
+        // their mutual orthogonality is only eps relative to the rows at panel start, which is not small against a
+        // later, much weaker component of the same panel
+        __syncthreads();
+        for (int q = tid; q < 16 * 16; q += 256) gs[q] = G[(long long)k0 * 16 + q] / inv[q & 15];
+        __syncthreads();
+#pragma unroll
+        for (int t = 1; t < 16; ++t)
+#pragma unroll
+            for (int j = 0; j < t; ++j) {
+                const double gq = (t < ncols) ? gs[j * 16 + t] : 0.0;
+                c[t][0] -= c[j][0] * gq; c[t][1] -= c[j][1] * gq; c[t][2] -= c[j][2] * gq;
+            }
         if (valid) {
             double loss = 0.0;
 #pragma unroll
@@ -785,7 +799,8 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     ASB_CHECK_LAUNCH(ctx);
     launch_project(ctx, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc);      // HIP-event bracketed per kernel launch
     ASB_CHECK_LAUNCH(ctx);
-    if (k0 > 0) hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)k0), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
+    // rows j < k0: earlier panels' weights against this panel's; rows k0 .. k0+ncols-1: the panel's own Gram matrix
+    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(k0 + ncols)), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
     hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
@@ -1003,7 +1018,8 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_cand_dots(
         if (t == 0 && valid) {
             double* c = cand_c + ((long long)t_panel * m_cap + s) * 3;
             c[0] = acc[0] / wn2; c[1] = acc[1] / wn2; c[2] = acc[2] / wn2;
-            double e = energy[s] - (acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]) / wn2;
+            // c . acc, not acc^2 / |w|^2: the squares of dot products of 1e-120-scaled snapshots flush to zero
+            double e = energy[s] - (c[0] * acc[0] + c[1] * acc[1] + c[2] * acc[2]);
             if (e < 0.0) e = 0.0;
             energy[s] = e;
             if (am_better(e, s, bmax, bidx)) { bmax = e; bidx = s; }

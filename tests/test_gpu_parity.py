@@ -853,3 +853,53 @@ def test_splocs_large_K_vs_oracle():
     assert comp.splocs_centres.tolist() == s["idx"].tolist()
     assert np.allclose(comp.splocs_trace, s["trace"], rtol=1e-8)
     assert relerr(comp.splocs_comps, s["C"]) < 1e-8
+
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1023, 1025, 1600, 2500, 4100]))
+    F = int(rng.choice([1, 2, 7, 16, 33, 64, 100, 257, 520, 1030]))
+    kind = ["uniform", "lowrank", "dupes", "zeros", "tiny", "huge"][seed % 6]
+    if kind == "lowrank":
+        r = max(1, min(F, 12))
+        X = (rng.normal(size=(F, r)) * (0.8 ** np.arange(r))) @ rng.normal(size=(r, N * 3))
+        X = X.reshape(F, N, 3) + 1e-6 * rng.normal(size=(F, N, 3))
+    else:
+        X = rng.uniform(-1, 1, size=(F, N, 3))
+    if kind == "dupes" and N > 4:               # exact ties: the first index must win, as np.argmax does
+        X[:, N // 2] = X[:, 1]
+        X[:, N - 1] = X[:, 1]
+    if kind == "zeros" and N > 3:
+        X[:, ::3] = 0.0
+    if kind == "tiny":
+        X *= 1e-120
+    if kind == "huge":
+        X *= 1e120
+    K = int(max(1, min(rng.integers(1, 40), (min(F, 3 * N) + 1) // 2)))
+    return X, K, kind
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed", list(range(36)))
+def test_fuzz_global_deflation(seed, mode):
+    """Seeded sweep over awkward shapes (N, F around wave / tile / buffer boundaries) and data (exact duplicates, zero
+    vertices, 1e-120 / 1e+120 scaling, low rank): index sequence == oracle, values to 1e-8."""
+    from animsnapbases_amd import HipEngine
+    X, K, kind = _fuzz_case(seed)
+    ref = orc.extract_k_components(X, K)
+    if not np.all(np.isfinite(ref["comps"])):
+        pytest.skip("the reference itself produces non-finite values here")
+    sig = ref["measures"][:, 1]
+    e = HipEngine(0)
+    e.upload(X, 0, X.shape[1])
+    e.deflate_begin(K, False, mode)
+    e.run_global(0, K)
+    r = e.results()
+    e.close()
+    # compare up to the first component whose singular value has dropped to rounding noise relative to the first
+    good = int(np.argmax(sig < 1e-9 * sig[0])) if np.any(sig < 1e-9 * sig[0]) else K
+    assert good >= 1
+    assert r["idx"][:good].tolist() == ref["idx"][:good].tolist(), (kind, X.shape, K)
+    comps, weigs = align_signs(r["comps"][:good], r["weigs"][:, :good], ref["comps"][:good])
+    assert relerr(comps, ref["comps"][:good]) < 1e-8, (kind, X.shape, K)
+    assert relerr(weigs, ref["weigs"][:, :good]) < 1e-8, (kind, X.shape, K)
