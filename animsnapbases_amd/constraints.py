@@ -101,6 +101,9 @@ class nonlinearSnapshots:
             massL = self.massL
         v0, n_loc = comm.my_shard(X.shape[1])
         self._shards = comm.shards(X.shape[1])
+        if min(n for _, n in self._shards) == 0:
+            raise ValueError("%d constraint rows cannot be sharded over %d ranks: every rank needs at least one row"
+                             % (X.shape[1], comm.world))
         eng.upload(X, v0, n_loc, massL)
         if self.param.constProj_standarize:
             self.standarize()

@@ -131,6 +131,9 @@ class posSnapshots:
         else:
             v0, n_loc = comm.my_shard(self.nVerts)
             self._shards = comm.shards(self.nVerts)
+            if min(n for _, n in self._shards) == 0:        # every rank sees the same partition and raises together
+                raise ValueError("%d vertices cannot be sharded over %d ranks: every rank needs at least one vertex"
+                                 % (self.nVerts, comm.world))
             eng.upload(self.verts, v0, n_loc, massL)      # (:73, :82) copy + M^{1/2} X, vertex-major
 
         # rest shape (:85-89); the mean row is subtracted only when standardising (:168)

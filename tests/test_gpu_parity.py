@@ -903,3 +903,82 @@ def test_fuzz_global_deflation(seed, mode):
     comps, weigs = align_signs(r["comps"][:good], r["weigs"][:, :good], ref["comps"][:good])
     assert relerr(comps, ref["comps"][:good]) < 1e-8, (kind, X.shape, K)
     assert relerr(weigs, ref["weigs"][:, :good]) < 1e-8, (kind, X.shape, K)
+
+
+@pytest.mark.parametrize("mode", ["project", "residual"])
+@pytest.mark.parametrize("world,N,F,K", [(2, 2, 9, 2), (3, 4, 20, 3), (3, 64, 33, 10), (2, 1000, 100, 20), (3, 1700, 64, 24),
+                                         (2, 3001, 257, 30), (3, 2, 12, 2)])
+def test_fuzz_multirank_shards(world, N, F, K, mode):
+    """Shard shapes at the edges: one vertex per rank, candidate counts around the buffer capacity -- every rank must end
+    with the oracle's result; fewer vertices than ranks (an EMPTY shard) is refused with a clear error."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(world * 1000 + N)
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = _param(vertPos_numComponents=K)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.deflate_mode = mode
+            comp.compute_components_store_singvalues()
+        return comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy()
+
+    if N < world:                     # an empty shard is refused on every rank, with the reason
+        with pytest.raises(ValueError, match="cannot be sharded"):
+            run_ranks(world, rank_fn)
+        return
+    outs = run_ranks(world, rank_fn)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    ref = orc.extract_k_components(pre["snapTensor"], K)
+    for idx, comps, weigs in outs:
+        assert idx.tolist() == ref["idx"].tolist()
+        comps, weigs = align_signs(comps, weigs, ref["comps"])
+        assert relerr(comps, ref["comps"]) < 1e-8 and relerr(weigs, ref["weigs"]) < 1e-8
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fuzz_local_support(seed):
+    """Local support on random small meshes / frame counts: +-project_weight, device geodesic support maps, residual
+    updates -- index sequence and values against the oracle (its geodesics: host SuperLU)."""
+    rng = np.random.default_rng(1000 + seed)
+    rings, segs = int(rng.integers(3, 14)), int(rng.integers(4, 22))
+    F = int(rng.choice([6, 17, 40, 65, 130]))
+    rest_v, tris = orc.synth_mesh(rings, segs, seed=seed)
+    N = rest_v.shape[0]
+    K = int(min(rng.integers(2, 9), F // 2, N // 2))
+    verts = orc.synth_snapshots(rest_v, F, rank=max(K + 2, 6), seed=seed, kind="bumps", decay=0.9)
+    dmax = float(rng.uniform(0.25, 0.6))
+    param = _param(vertPos_numComponents=K, q_support="local", vertPos_smooth_max_dist=dmax)
+    snaps, comp = _run(verts, tris, param)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    geo = orc.Geodesics(verts[0], tris)
+    ref = orc.extract_k_components(pre["snapTensor"], K, "local", geo, 0.1, dmax)
+    assert comp.selected_vertices.tolist() == ref["idx"].tolist(), (rings, segs, F, K)
+    assert relerr(comp.comps, ref["comps"]) < 1e-7, (rings, segs, F, K)
+    assert relerr(comp.weigs, ref["weigs"]) < 1e-7
+    assert relerr(comp.measures_at_largeDeforVerts, ref["measures"]) < 1e-7
+
+
+@pytest.mark.parametrize("ep,F,K,orth", [(2, 5, 2, False), (3, 7, 3, True), (40, 40, 9, True), (129, 33, 12, False),
+                                         (700, 130, 64, True), (257, 300, 40, False), (50, 2, 2, True)])
+def test_fuzz_pod_deim_shapes(ep, F, K, orth, tmp_path):
+    """POD + post-processing + DEIM on awkward shapes (fewer rows than frames, K = F, one row): singular values, spans
+    and DEIM points against the oracle."""
+    rng = np.random.default_rng(ep * 7 + F)
+    r = max(1, min(F, 3 * ep, 2 * K + 3))
+    frames = 0.2 + np.tensordot(rng.normal(size=(F, r)) * (0.85 ** np.arange(r))[None], rng.normal(size=(r, ep, 3)), (1, 0)) \
+        + 1e-5 * rng.normal(size=(F, ep, 3))
+    K = min(K, F, 3 * ep)
+    ns, cc = _run_constraints(frames, K, orth, tmp_path)
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    pod = orc.pod_vectorized(pre["snapTensor"], K)
+    keep = pod["S"][:K] > 1e-7 * pod["S"][0]                      # the Gram route resolves sigma down to ~1e-8 sigma_max
+    assert relerr(cc.singular_values[:K][keep], pod["S"][:K][keep]) < 1e-8
+    got, want = cc.comps.reshape(K, -1)[keep], pod["comps"].reshape(K, -1)[keep]
+    sg = np.sign(np.sum(got * want, axis=1))
+    assert relerr(got * sg[:, None], want) < 1e-6
