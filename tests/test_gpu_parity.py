@@ -982,3 +982,90 @@ def test_fuzz_pod_deim_shapes(ep, F, K, orth, tmp_path):
     got, want = cc.comps.reshape(K, -1)[keep], pod["comps"].reshape(K, -1)[keep]
     sg = np.sign(np.sum(got * want, axis=1))
     assert relerr(got * sg[:, None], want) < 1e-6
+
+
+def test_full_size_config4_properties():
+    """BASELINE.json config 4 at FULL size (100 000 vertices x 2000 frames, K = 128; 4.8 GB generated on the device):
+    size-independent properties of the result, checked with torch on the GPU --
+      * the two independent device algorithms (residual tensor kept / projection panels) select the same 128 vertices
+        and give the same basis and weights;
+      * the first vertex is the arg-max of the initial energies; all selected vertices are distinct;
+      * weights mutually orthogonal; c_k = w_k^T X / |w_k|^2 (the identity the reference satisfies to 9e-16);
+      * X - sum_k w_k (x) c_k has the recorded Frobenius norm, and the recorded norms never increase."""
+    import torch
+    from animsnapbases_amd import posComponents, posSnapshots
+    F, N, K = 2000, 100000, 128
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2024)
+    outs = {}
+    for mode in ("project", "residual"):
+        gen.manual_seed(2024)
+        Xd = torch.rand((F, N, 3), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_device(Xd.data_ptr(), F, N, "first", True, keepalive=Xd)
+            comp = posComponents(_param(vertPos_numComponents=K), snaps)
+            comp.deflate_mode = mode
+            comp.compute_components_store_singvalues()
+        outs[mode] = (comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(),
+                      comp.measures_at_largeDeforVerts.copy(), snaps.pre_scale_factor, snaps.mean.copy())
+        del comp, snaps, Xd
+        torch.cuda.empty_cache()
+    idx, comps, weigs, meas, psf, mean = outs["project"]
+    idx_r, comps_r, weigs_r, meas_r, _, _ = outs["residual"]
+    assert idx.tolist() == idx_r.tolist() and len(set(idx.tolist())) == K
+    comps_a, weigs_a = align_signs(comps, weigs, comps_r)
+    assert relerr(comps_a, comps_r) < 1e-9 and relerr(weigs_a, weigs_r) < 1e-9
+    assert relerr(meas[:, 1:], meas_r[:, 1:]) < 1e-9
+    assert (np.diff(meas[:, 2]) <= 0).all()
+    G = weigs.T @ weigs
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).min()
+    # the standardised tensor again, on the device: (X - X[0]) * psf
+    gen.manual_seed(2024)
+    Xd = torch.rand((F, N, 3), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+    Xs = ((Xd - Xd[0:1]) * psf).reshape(F, 3 * N)
+    del Xd
+    assert int(torch.argmax((Xs.reshape(F, N, 3) ** 2).sum(dim=(0, 2))).item()) == int(idx[0])
+    Wd = torch.from_numpy(weigs).cuda()                                # (F, K)
+    Cd = torch.from_numpy(comps.reshape(K, 3 * N)).cuda()              # (K, 3N)
+    proj = (Wd.T @ Xs) / (Wd * Wd).sum(dim=0)[:, None]
+    assert float(torch.linalg.norm(proj - Cd) / torch.linalg.norm(Cd)) < 1e-10
+    R = Xs - Wd @ Cd
+    assert abs(float(torch.linalg.norm(R)) - meas[-1, 2]) < 1e-7 * meas[-1, 2]
+
+
+def test_full_size_config5_properties(tmp_path):
+    """BASELINE.json config 5 at FULL size (50 000 x 3 rows, 4000 frames, K = 256): U orthonormal, its span captures
+    exactly the energy the recorded singular values say (|A - U U^T A|_F^2 = sum_{i > K} sigma_i^2), A^T U = V S, and
+    DEIM returns K distinct points."""
+    import contextlib
+    import io
+    import torch
+    ep, F, K = 50000, 4000, 256
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    r = 300
+    coef = torch.randn((F, r), dtype=torch.float64, device="cuda", generator=gen) * (0.97 ** torch.arange(r, device="cuda", dtype=torch.float64))
+    modes = torch.randn((r, ep * 3), dtype=torch.float64, device="cuda", generator=gen)
+    frames = (0.1 + coef @ modes + 1e-4 * torch.randn((F, ep * 3), dtype=torch.float64, device="cuda", generator=gen))
+    frames = frames.reshape(F, ep, 3).cpu().numpy()
+    del coef, modes
+    torch.cuda.empty_cache()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns, cc = _run_constraints(frames, K, False, tmp_path)
+        S = cc.singular_values.copy()
+        U = torch.from_numpy(cc.comps.reshape(K, -1)).cuda()                      # rows = left singular vectors
+        cc.deim()
+    assert len(set(cc.geom_Pt.tolist())) == K
+    A = torch.from_numpy(((frames - frames[0:1]) * ns.pre_scale_factor).reshape(F, -1)).cuda()      # (F, 3 ep) = A^T
+    del frames
+    G = U @ U.T
+    assert float((G - torch.eye(K, dtype=torch.float64, device="cuda")).abs().max()) < 1e-9
+    P = A @ U.T                                                                    # (F, K) = A^T U = V S
+    col = torch.linalg.norm(P, dim=0).cpu().numpy()
+    assert relerr(col, S[:K]) < 1e-9
+    total = float((A * A).sum())
+    assert abs(total - float((S ** 2).sum())) < 1e-9 * total
+    resid = float(torch.linalg.norm(A - P @ U) ** 2)
+    tail = float((S[K:] ** 2).sum())
+    assert abs(resid - tail) < 1e-6 * total and resid < 0.01 * total
