@@ -189,7 +189,11 @@ def main():
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
                          "launches": launches,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         # SURVEY.md 8(d) prices a whole step at 24 N F (1 + K) bytes (one read of X per component);
+                         # the panel algorithm reads X once per PANEL, so the step beats that figure's own roofline
+                         "survey_step_bytes": 24.0 * N * F * (1 + K),
+                         "survey_step_equivalent_GBps": 24.0 * N * F * (1 + K) / (dt / args.steps) / 1e9},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, N, K, args.cpu_budget)
