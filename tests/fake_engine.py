@@ -201,7 +201,11 @@ class FakeEngine(object):
         out[:e.size] = e[::-1]                      # any order: the device export is unordered too
         out[cap] = self.tau
 
+    GLOBAL_TAU_ON_DEVICE = True          # False: behave like ASB_ERR_LIMIT (the driver then selects with torch)
+
     def panel_global_tau(self, tab_ptr, world, cap):
+        if not self.GLOBAL_TAU_ON_DEVICE:
+            return None
         tab = _view(tab_ptr, world * (cap + 1)).reshape(world, cap + 1)
         exported = np.sort(tab[:, :cap].reshape(-1))[::-1]
         kth = max(exported[self.M_TARGET], 0.0) if exported.size > self.M_TARGET else 0.0

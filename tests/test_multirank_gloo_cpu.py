@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, support, tmpdir, mode=None):
+def _worker(rank, world, port, support, tmpdir, mode=None, device_select=True):
     import contextlib
     import io
 
@@ -46,6 +46,7 @@ def _worker(rank, world, port, support, tmpdir, mode=None):
                                       q_orthogonal=False, vertPos_output_directory=tmpdir, name="mr%d" % rank)
         comm = Comm()
         assert comm.world == world and comm.rank == rank
+        FakeEngine.GLOBAL_TAU_ON_DEVICE = device_select
         with contextlib.redirect_stdout(io.StringIO()):
             snaps = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False,
                                              engine=FakeEngine(), comm=comm)
@@ -88,9 +89,11 @@ def test_two_rank_gloo_matches_oracle(support, tmp_path):
     mp.spawn(_worker, args=(2, port, support, str(tmp_path), "residual"), nprocs=2, join=True)
 
 
-def test_two_rank_gloo_projection_mode(tmp_path):
-    """The panel (projection-mode) multi-rank protocol: histogram all-reduces, padded candidate
-    all-gather, replicated greedy steps, local projection -- through the CPU test double."""
+@pytest.mark.parametrize("device_select", [True, False])
+def test_two_rank_gloo_projection_mode(tmp_path, device_select):
+    """The panel (projection-mode) multi-rank protocol: local thresholds, one all-gather of exported energies, global
+    threshold (the engine's selection, or the torch fallback the driver uses when the table exceeds the selection
+    kernel's LDS), padded candidate all-gather, replicated greedy steps, local projection -- through the CPU test double."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, "global", str(tmp_path), "project"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, "global", str(tmp_path), "project", device_select), nprocs=2, join=True)
