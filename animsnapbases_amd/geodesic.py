@@ -1,21 +1,18 @@
-"""Heat-method geodesic distances on the HOST (SciPy SuperLU) -- the support maps of
-``support='local'`` and SPLOCS.
+"""Heat-method geodesic distances -- the support maps of ``support='local'`` and SPLOCS.
 
-Follows the formulas of the reference's ``GeodesicDistanceComputation``
-(utils/support.py:139-208; cotan Laplacian :81-136; m = 10, t = m*h^2), but is organised
-differently: the per-triangle gradient and the per-vertex divergence are assembled ONCE as
-sparse matrices G (3M x N) and D (N x 3M), so one query is two SuperLU solves and two
-sparse mat-vecs, and ``solve_many`` answers K queries with multi-right-hand-side solves
-(what one SPLOCS outer iteration needs, posComponents.py:158-165).
+Follows the formulas of the reference's ``GeodesicDistanceComputation`` (utils/support.py:139-208; cotan
+Laplacian :81-136; m = 10, t = m*h^2), organised differently: the per-triangle gradient and the per-vertex
+divergence are assembled ONCE as sparse matrices G (3M x N) and D (N x 3M); ``solve_many`` answers a batch of
+sources at a time and remembers every field it has solved (SPLOCS asks for the same centres again once they settle).
 
-SURVEY.md 8(f)-3 asks for a device solver.  ``engine=`` switches the two solves to batched
-Jacobi-preconditioned CG on the GPU (csrc/asb_geodesic.hip, 64 sources per batch).  It is
-EXPERIMENTAL and opt-in (``ASB_GEODESIC=device``): it matches SuperLU to 1e-11 on well-shaped
-meshes of ~1e3 vertices, but the Jacobi preconditioner needs thousands of iterations on large or
-badly shaped meshes (measured: 14 290-vertex lat-long sphere, > 1 s per solve against 4 ms for
-SuperLU) and raises rather than returning unconverged distances.  A multigrid / incomplete-Cholesky
-preconditioner is what the row still needs; host SuperLU stays the default and is the Amdahl term
-of the local / SPLOCS modes.
+Backends (chosen by posSnapshots, ``ASB_GEODESIC``):
+* ``engine=..., backend="dense"`` (default): the two SPD systems the reference factorises with SuperLU (:170-171)
+  are INVERTED once on the device (csrc/asb_dense.hip: blocked Gauss-Jordan on f64 MFMA); a query is a column gather
+  for the heat step, two SpMMs for gradient / divergence and one dense product for the Poisson step.
+* ``engine=None``: host SciPy SuperLU like the reference (symmetric minimum-degree ordering) -- opt-in only.
+* ``engine=..., backend="pcg"``: sparse batched Jacobi-PCG on the device (csrc/asb_geodesic.hip); experimental: 1e-11
+  against SuperLU on well-shaped ~1e3-vertex meshes, thousands of iterations on badly shaped 14k-vertex ones, where it
+  raises rather than return unconverged distances.
 """
 import numpy as np
 from scipy import sparse
