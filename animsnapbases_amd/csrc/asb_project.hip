@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
         // their mutual orthogonality is only eps relative to the rows at panel start, which is not small against a
         // later, much weaker component of the same panel
         __syncthreads();
-        for (int q = tid; q < 16 * 16; q += 256) gs[q] = G[(long long)k0 * 16 + q] / inv[q & 15];
+        for (int q = tid; q < 16 * 16; q += 256)       // rows beyond ncols do not exist in G (it has K rows in all)
+            gs[q] = ((q >> 4) < ncols) ? G[(long long)k0 * 16 + q] / inv[q & 15] : 0.0;
         __syncthreads();
 #pragma unroll
         for (int t = 1; t < 16; ++t)

@@ -1,0 +1,66 @@
+"""Long seeded sweep (not part of the test suite): random shapes / data kinds, both device algorithms against the
+oracle.  python tools/fuzz_sweep.py [first_seed] [count]"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from animsnapbases_amd import HipEngine
+from oracle import asb_oracle as orc
+from conftest import align_signs, relerr
+
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 6000))
+    F = int(rng.integers(1, 700))
+    kind = rng.choice(["uniform", "lowrank", "dupes", "zeros", "scaled", "smooth"])
+    if kind == "lowrank":
+        r = int(rng.integers(1, 20))
+        X = (rng.normal(size=(F, r)) * (rng.uniform(0.5, 0.95) ** np.arange(r))) @ rng.normal(size=(r, N * 3))
+        X = X.reshape(F, N, 3) + 10.0 ** rng.integers(-9, -3) * rng.normal(size=(F, N, 3))
+    elif kind == "smooth":
+        t = np.linspace(0, 1, F)[:, None, None]
+        X = np.sin(2 * np.pi * (t * rng.uniform(0.5, 4, size=(1, N, 3)) + rng.uniform(size=(1, N, 3)))) * rng.uniform(0.1, 1, size=(1, N, 1))
+    else:
+        X = rng.uniform(-1, 1, size=(F, N, 3))
+    if kind == "dupes" and N > 4:
+        for _ in range(int(rng.integers(1, 6))):
+            a, b = rng.integers(0, N, size=2)
+            X[:, a] = X[:, b]
+    if kind == "zeros" and N > 3:
+        X[:, rng.integers(0, N, size=N // 3)] = 0.0
+    if kind == "scaled":
+        X *= 10.0 ** rng.integers(-140, 140)
+    K = int(max(1, min(rng.integers(1, 70), (min(F, 3 * N) + 1) // 2)))
+    ref = orc.extract_k_components(X, K)
+    if not np.all(np.isfinite(ref["comps"])):
+        continue
+    sig = ref["measures"][:, 1]
+    good = int(np.argmax(sig < 1e-9 * sig[0])) if np.any(sig < 1e-9 * sig[0]) else K
+    for mode in (0, 1):
+        if "-v" in sys.argv:
+            print("start seed", seed, kind, X.shape, "K", K, "mode", mode, flush=True)
+        e = HipEngine(0)
+        e.upload(X, 0, N)
+        e.deflate_begin(K, False, mode)
+        try:
+            e.run_global(0, K)
+            r = e.results()
+        except Exception as ex:
+            print("seed", seed, kind, X.shape, K, "mode", mode, "RAISED", repr(ex)[:200], flush=True)
+            bad += 1
+            e.close()
+            continue
+        e.close()
+        ok_idx = r["idx"][:good].tolist() == ref["idx"][:good].tolist()
+        err = np.inf
+        if ok_idx and good:
+            comps, weigs = align_signs(r["comps"][:good], r["weigs"][:, :good], ref["comps"][:good])
+            err = max(relerr(comps, ref["comps"][:good]), relerr(weigs, ref["weigs"][:, :good]))
+        if not ok_idx or not err < 1e-7:
+            bad += 1
+            print("seed", seed, kind, X.shape, K, "good", good, "mode", mode, "idx_ok", ok_idx, "err %.2e" % err, flush=True)
+    if (seed - first) % 20 == 19:
+        print("... %d cases, %d bad, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+print("done:", count, "cases,", bad, "bad")
