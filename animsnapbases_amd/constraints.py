@@ -335,6 +335,13 @@ class constraintsComponents:  # Components == bases
             lam, V = lam[::-1], V[:, ::-1]
         S = np.sqrt(np.maximum(lam, 0.0))
         self.singular_values = S
+        # The Gram route resolves singular values down to ~sqrt(eps) sigma_max (vector k carries an error eps (sigma_0 /
+        # sigma_k)^2).  Below that a left vector A v / sigma is noise divided by noise: refuse instead of returning it.
+        if not S[K - 1] > 3e-8 * S[0]:
+            raise ArithmeticError("POD: singular value %d of the %d requested is %.3e of the largest -- below what the "
+                                  "Gram-matrix route resolves (1e-8); ask for fewer components (the snapshot matrix has "
+                                  "numerical rank %d)" % (K, K, S[K - 1] / S[0] if S[0] > 0 else 0.0,
+                                                          int(np.sum(S > 3e-8 * S[0]))))
         if writer is not None:
             for ai, bi in zip(range(1, S.shape[0] + 1), S):
                 writer.writerow([ai, bi])

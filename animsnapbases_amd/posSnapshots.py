@@ -72,9 +72,16 @@ class posSnapshots:
     @classmethod
     def from_device(cls, dev_ptr, F, N, rest_shape="first", standarize=True, engine=None, comm=None, keepalive=None):
         """Adopts an ``(F, N, 3)`` float64 tensor that already sits in this rank's HBM (e.g. a
-        torch tensor's ``data_ptr()``): this rank's shard of a larger problem, or all of it."""
+        torch tensor's ``data_ptr()``): this rank's shard of a larger problem, or all of it.  The tensor is
+        standardised IN PLACE.  Without an ``engine`` the work is queued on torch's current stream when torch is loaded
+        (so it is ordered after whatever produced the tensor); with an engine on another stream the caller must have
+        synchronised the producer."""
         self = cls.__new__(cls)
         self._keepalive = keepalive
+        if engine is None and "torch" in sys.modules:
+            import torch
+            if torch.cuda.is_available():
+                engine = HipEngine(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
         cls.__init__(self, None, None, rest_shape, "", None, standarize, False, engine=engine, comm=comm,
                      device_data=(int(dev_ptr), int(F), int(N)))
         return self
