@@ -76,6 +76,8 @@ PROTOTYPES = {
     "asb_align_frames": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_int, c_dp]),
     "asb_pod_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_pod_basis": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64]),
+    "asb_pod_project": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "asb_components_truncate": (c_int, [ctypes.c_void_p, c_i64]),
     "asb_sym_tridiag": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp, c_dp]),
     "asb_sym_backtransform": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "asb_snapshots_affine": (c_int, [ctypes.c_void_p, c_dbl, c_int, c_dp]),

@@ -488,6 +488,13 @@ extern "C" int asb_components_transform(asb_ctx* ctx, const double* T_host) {
     return ASB_OK;
 }
 
+// keeps the first K components of the device-resident basis (rows are contiguous: nothing moves)
+extern "C" int asb_components_truncate(asb_ctx* ctx, int64_t K) {
+    if (!ctx || !ctx->comps || K < 1 || K > ctx->K) return ASB_ERR_ARG;
+    ctx->K = K;
+    return ASB_OK;
+}
+
 // replaces the device-resident basis by a host array (K, n_loc, 3) (a caller-assigned `comps`)
 extern "C" int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K) {
     if (!ctx || !ctx->X || !comps_host || K < 1) return ASB_ERR_ARG;

@@ -51,6 +51,28 @@ extern "C" int asb_pod_basis(asb_ctx* ctx, const double* V, const double* sigma,
     return ASB_OK;
 }
 
+// B = Q^T A for the device-resident basis Q (K rows of length 3 n_loc) and the snapshots: B[k][f] = sum_r Q[k][r] X[r][f]
+// (K x F, this shard's partial sum) into B_dev (caller's device buffer, all-reduced over ranks) and/or B_host.
+// The Rayleigh-Ritz step of the POD: the small SVD of B recovers, from A itself, the accuracy the Gram matrix lost.
+extern "C" int asb_pod_project(asb_ctx* ctx, double* B_dev, double* B_host) {
+    if (!ctx || !ctx->X || !ctx->comps) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, F = ctx->F, n3 = 3 * ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->oct, (size_t)n3 * K))) return rc;
+    if ((rc = asb_transpose(ctx, ctx->comps, K, n3, ctx->oct))) return rc;
+    double* B = B_dev;
+    if (!B) {
+        if ((rc = asb_alloc(ctx, &ctx->pod_v, (size_t)F * K))) return rc;
+        B = ctx->pod_v;
+    }
+    if ((rc = asb_gemm_tn(ctx, ctx->oct, K, ctx->X, ctx->Fp, n3, (int)K, (int)F, B))) return rc;
+    if (B_host) {
+        ASB_HIP(ctx, hipMemcpyAsync(B_host, B, (size_t)K * F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ASB_OK;
+}
+
 // X <- (X * inv_scale + mean) * rowscale     (:421-428, :440-443: the reference also restores
 // nonlinearSnapshots.snapTensor); rowscale host (n_loc) or NULL
 __global__ __launch_bounds__(256) void k_affine_rows(double* __restrict__ X, long long nrows, int F, int Fp, double inv_scale,

@@ -330,6 +330,11 @@ class HipEngine(object):
         self._ck(self.lib.asb_pod_basis(self.h, ptr(V), ptr(sigma), sigma.shape[0]))
         self.K = int(sigma.shape[0])
 
+    def pod_project(self, B_dev_ptr=None, to_host=True):
+        B = np.empty((self.K, self.F)) if to_host else None
+        self._ck(self.lib.asb_pod_project(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, ptr(B)))
+        return B
+
     def sym_tridiag(self, n, A_dev_ptr=None):
         """Householder tridiagonalisation of the n x n symmetric device matrix (default: the POD Gram matrix)."""
         d, e = np.empty(n), np.empty(max(n - 1, 0))
@@ -373,6 +378,10 @@ class HipEngine(object):
         out = np.empty((self.K, self.n_loc, 3))
         self._ck(self.lib.asb_components_download(self.h, ptr(out)))
         return out
+
+    def components_truncate(self, K):
+        self._ck(self.lib.asb_components_truncate(self.h, int(K)))
+        self.K = int(K)
 
     def components_upload(self, comps_loc):
         comps_loc = np.ascontiguousarray(comps_loc, dtype=np.float64)

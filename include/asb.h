@@ -237,6 +237,13 @@ int asb_align_frames(asb_ctx* ctx, double* frames, int64_t F, int64_t N, int rig
  * vectors  comps[i] = A V[:, i] / sigma[i]  (V host F x K, sigma host K) as the device-resident basis. */
 int asb_pod_gram(asb_ctx* ctx, double* G_dev, double* G_host);
 int asb_pod_basis(asb_ctx* ctx, const double* V, const double* sigma, int64_t K);
+/* Rayleigh-Ritz refinement of the POD basis: B = Q^T A (K x F, this shard's partial sum) for the device-resident
+ * (orthonormalised) basis Q, into B_dev (to be all-reduced) and/or B_host.  The SVD of the small B, taken from A
+ * itself, restores the eps * sigma_0 / sigma_k accuracy of the reference's `svd` (:307) that the Gram route
+ * (eps * (sigma_0 / sigma_k)^2) loses on weak components; the rotation is applied with asb_components_transform. */
+int asb_pod_project(asb_ctx* ctx, double* B_dev, double* B_host);
+/* keeps the first K components of the device-resident basis (drops the oversampling vectors of the refinement) */
+int asb_components_truncate(asb_ctx* ctx, int64_t K);
 
 /* The F x F symmetric eigen-problem of the POD (the `svd` of constraintsComponents.py:307 in Gram form) on the
  * device.  asb_sym_tridiag: Householder tridiagonalisation A = Q T Q^T of the n x n symmetric matrix A_dev

@@ -118,7 +118,7 @@ for seed in range(first, first + count):
                     report(seed, ("blocks val", frames.shape, K, p, relerr(cc.comps * sgn[:, None, None], rr["comps"])))
             else:
                 pod = orc.pod_vectorized(pre["snapTensor"], K)
-                keep = pod["S"][:K] > 1e-4 * pod["S"][0]          # Gram route: vector error eps (s0 / sk)^2
+                keep = pod["S"][:K] > 3e-7 * pod["S"][0]          # refined route: vector error ~ eps s0 / sk
                 got, want = cc.comps.reshape(K, -1)[keep], pod["comps"].reshape(K, -1)[keep]
                 sg = np.sign(np.sum(got * want, axis=1))
                 if not relerr(cc.singular_values[:K][keep], pod["S"][:K][keep]) < 1e-8 or not relerr(got * sg[:, None], want) < 1e-5:
