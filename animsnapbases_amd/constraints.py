@@ -280,7 +280,7 @@ class constraintsComponents:  # Components == bases
                         eng.pick(k * p + i)
                     eng.apply(k * p + i)
         res = eng.results(want_comps=False, want_weigs=True)
-        normR = np.sqrt(comm.allreduce_sum(res["normR2_local"]))
+        normR = np.sqrt(np.maximum(comm.allreduce_sum(res["normR2_local"]), 0.0))     # |X|^2 - sum can round below 0 once |R| < 1e-8 |X|
         self.weigs = res["weigs"]
         self.largeDeforBlocks = np.asarray(res["idx"], dtype=np.int64)               # (K p,) rows, 0 <= . < e p
         self.largeDeforPoints = self.largeDeforBlocks[::p] // p                       # (K,) constraints

@@ -144,7 +144,7 @@ class posComponents:  # Components == bases
                 eng.apply(k, s_loc)
 
         res = eng.results(want_comps=False, want_weigs=True)
-        normR = np.sqrt(comm.allreduce_sum(res["normR2_local"]))
+        normR = np.sqrt(np.maximum(comm.allreduce_sum(res["normR2_local"]), 0.0))     # |X|^2 - sum can round below 0 once |R| < 1e-8 |X|
         self.weigs = res["weigs"]
         self.selected_vertices = res["idx"]
         self._comps, self._comps_on_device = None, True
