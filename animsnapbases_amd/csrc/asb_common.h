@@ -57,6 +57,16 @@ struct asb_ctx {
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
     double* coop_w = nullptr;         // (2, grid, Fp) tentative weights
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
+    // super-panels (asb_project.hip): how the next asb_panel_run behaves / what it did
+    int run_writeback = 0, run_theta_band = 0, run_coop_used = 0;
+    int super_panels = 0;             // ASB_SUPER_PANELS=1
+    long long band_target = 12288, band_cap = 16384;
+    long long* band_idx = nullptr;
+    long long *btmp = nullptr, *bcnt = nullptr;
+    double *band_E = nullptr, *bpmax = nullptr, *bpsum = nullptr;
+    long long* bpidx = nullptr;
+    PanelState* bstate = nullptr;
+    double *Wt3 = nullptr, *wn2t3 = nullptr, *Wq3 = nullptr;
     int64_t forced_row = -1;      // asb_deflate_force_next: global row the next pick must take
     double* bam_val = nullptr;    // asb_deflate_block_argmax partials
     long long* bam_idx = nullptr;

@@ -28,7 +28,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define ASB_PANEL_COLS 16
 
 // layout of ctx->scalar_dev (doubles)
-enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7 };
+enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
+       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13 };        // 8..10: k_best_energy; 11..13: super-panels (band)
 
 // --------------------------------------------------------------------------------------
 // k_gather: item s -> vertex v = idx_map[s] - v0 (or s); rebuilds its residual row
@@ -231,16 +232,17 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
 #define ASB_CBLOCKS 128
 __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E, long long n, long long v0,
                                                    const double* __restrict__ sc, int take_all, long long m_cap,
-                                                   long long* __restrict__ tmp, long long* __restrict__ cnt) {
+                                                   long long* __restrict__ tmp, long long* __restrict__ cnt, int hi_slot = -1) {
     __shared__ long long pre[256];
     const int tid = threadIdx.x;
     const double tau = take_all ? -1.0e300 : sc[SC_TAU];
+    const double tau_hi = hi_slot >= 0 ? sc[hi_slot] : 1.7976931348623157e308;       // band: tau < E <= tau_hi
     const long long seg = (n + gridDim.x - 1) / gridDim.x;
     const long long s0 = blockIdx.x * seg, s1 = (s0 + seg < n) ? s0 + seg : n;
     const long long sub = (seg + 255) / 256;
     const long long a = s0 + tid * sub, b = (a + sub < s1) ? a + sub : s1;
     long long c = 0;
-    for (long long i = a; i < b; ++i) c += (E[i] > tau);
+    for (long long i = a; i < b; ++i) c += (E[i] > tau && !(E[i] > tau_hi));
     pre[tid] = c;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     long long pos = pre[tid] - c;
     long long* out = tmp + (long long)blockIdx.x * m_cap;
     for (long long i = a; i < b; ++i)
-        if (E[i] > tau) {
+        if (E[i] > tau && !(E[i] > tau_hi)) {
             if (pos < m_cap) out[pos] = v0 + i;
             ++pos;
         }
@@ -280,17 +282,43 @@ __global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ 
 // arms the panel: every vertex outside the candidate buffer has energy <= theta
 __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
                             long long n_slots, double margin_rel, unsigned* __restrict__ coop_flags,
-                            unsigned long long* __restrict__ coop_rec, int n_rec) {
+                            unsigned long long* __restrict__ coop_rec, int n_rec, int theta_from_band = 0) {
     // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4)
     if (coop_flags && threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
     if (coop_rec)
         for (int r = threadIdx.x; r < n_rec; r += blockDim.x) coop_rec[(size_t)r * 8 + 4] = 0ull;
     if (threadIdx.x != 0) return;
     if (n_slots >= 0) panel->n_cand = n_slots;
-    panel->theta = global_all ? -1.0e300 : (panel->pad ? 1.0e300 : sc[SC_TAU]);
+    // later sub-panels of a super-panel: every vertex outside candidates and band is below tau2 (stale but valid), the
+    // band's energies are exact (k_correct on the band after every sub-panel)
+    panel->theta = global_all ? -1.0e300
+                              : (panel->pad ? 1.0e300 : (theta_from_band ? fmax(sc[SC_TAU2], sc[SC_BANDMAX]) : sc[SC_TAU]));
     panel->margin = margin_rel * sc[SC_E0MAX];
     panel->done = 0;
     panel->committed = 0;
+}
+
+__global__ void k_sc_copy(double* __restrict__ sc, int dst, int src) { sc[dst] = sc[src]; }
+// band_E[i] = E[band_idx[i] - v0]
+__global__ __launch_bounds__(256) void k_band_energy(const double* __restrict__ E, const long long* __restrict__ band_idx,
+                                                     const PanelState* __restrict__ bstate, long long v0, double* __restrict__ band_E) {
+    const long long n = bstate->n_cand;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) band_E[i] = E[band_idx[i] - v0];
+}
+// sc[SC_BANDMAX] = max over the band's per-block maxima (k_correct on the band)
+__global__ __launch_bounds__(256) void k_band_max(const double* __restrict__ pmax, int nblk, double* __restrict__ sc,
+                                                  const PanelState* __restrict__ bstate) {
+    __shared__ double sh[256];
+    double m = -1.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) m = fmax(m, pmax[b]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    // a band that overflowed its buffer does not cover (tau2, tau]: no bound from it
+    if (threadIdx.x == 0) sc[SC_BANDMAX] = bstate->pad ? 1.0e300 : sh[0];
 }
 
 // forced single candidate (degenerate ties): global vertex id gidx if this shard owns it
@@ -341,11 +369,16 @@ __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W
     if (threadIdx.x < 16) G[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x];
 }
 
+// vmap != nullptr: only the vertices vmap[0 .. bstate->n_cand) (global ids; the band of a super-panel) are treated, E is
+// their compact energy array and colpart is not written (the full pass accounts for every vertex later).
 __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, long long comp_stride, long long n_vert,
                                                  int k0, int ncols, const double* __restrict__ G,
                                                  const double* __restrict__ wn2, double* __restrict__ E,
                                                  double* __restrict__ pmax, long long* __restrict__ pidx,
-                                                 double* __restrict__ psum, double* __restrict__ colpart) {
+                                                 double* __restrict__ psum, double* __restrict__ colpart,
+                                                 const long long* __restrict__ vmap = nullptr,
+                                                 const PanelState* __restrict__ bstate = nullptr, long long v0 = 0) {
+    if (vmap != nullptr) n_vert = bstate->n_cand;
     __shared__ double gs[64 * 16];
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
@@ -358,8 +391,9 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
 #pragma unroll
     for (int t = 0; t < 16; ++t) inv[t] = wn2[t];
     for (long long base = (long long)blockIdx.x * 256; base < n_vert; base += (long long)gridDim.x * 256) {
-        const long long v = base + tid;
-        const bool valid = v < n_vert;
+        const long long vi = base + tid;                      // index into E
+        const bool valid = vi < n_vert;
+        const long long v = (vmap != nullptr) ? (valid ? vmap[vi] - v0 : 0) : vi;       // local vertex
         double c[16][3];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -407,16 +441,16 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                     loss += q;
                     csum[t] += q;
                 }
-            double e = E[v] - loss;
+            double e = E[vi] - loss;
             if (e < 0.0) e = 0.0;
-            E[v] = e;
+            E[vi] = e;
             bsum += e;
             if (am_better(e, v, bmax, bidx)) { bmax = e; bidx = v; }
         }
     }
     __syncthreads();
     block_sum<16>(csum, sh_d);
-    if (tid < 16) colpart[(long long)blockIdx.x * 16 + tid] = csum[tid];
+    if (tid < 16 && vmap == nullptr) colpart[(long long)blockIdx.x * 16 + tid] = csum[tid];
     __syncthreads();
     sh_d[tid] = bmax; sh_d[256 + tid] = bsum; sh_i[tid] = bidx;
     __syncthreads();
@@ -740,6 +774,96 @@ __global__ __launch_bounds__(512) void k_project_l2(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_project_wide: the same product for NCT column tiles in ONE read of X (super-panels: up to 3 sub-panels of <= 16
+// committed components each).  Wq / wn2 hold the tiles back to back (tile ct at Wq + ct * Fp * 16, wn2 + 16 ct); tile
+// ct writes its columns i < nc[ct] to component rows kb[ct] + i.  MAP: the rows are those of the vertices vmap[.]
+// (the band of a super-panel) instead of all of the shard's.
+// --------------------------------------------------------------------------------------
+struct WideArgs { long long kb[3]; int nc[3]; };
+template <int NT, int G, int NCT, bool MAP>
+__global__ __launch_bounds__(512) void k_project_wide(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter,
+    const long long* __restrict__ vmap, const PanelState* __restrict__ bstate, long long v0) {
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+    constexpr int TR = 16 * NT;
+    if (MAP) rows = 3 * bstate->n_cand;
+    const long long ntiles = (rows + TR - 1) / TR;
+    const int nchunk = Fp / 16;
+    const double4* wq[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) wq[ct] = reinterpret_cast<const double4*>(Wq + (long long)ct * Fp * 16) + (g * 16 + i);
+    for (;;) {
+        unsigned int t = 0;
+        if (l == 0) t = atomicAdd(counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((long long)t >= ntiles) break;
+        const double4* xp[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            long long r = (long long)t * TR + 16 * m + i;
+            if (r >= rows) r = rows - 1;
+            if (MAP) r = 3 * (vmap[r / 3] - v0) + r % 3;
+            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+        }
+        d4 acc[NT][NCT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        double4 a[NT][G], an[NT][G];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int m = 0; m < NT; ++m) a[m][q] = (q < nchunk) ? xp[m][4 * q] : make_double4(0, 0, 0, 0);
+        for (int c = 0; c < nchunk; c += G) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+                    an[m][q] = (c + G + q < nchunk) ? xp[m][4 * (c + G + q)] : make_double4(0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                if (c + q < nchunk) {
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const double4 b = wq[ct][64 * (c + q)];
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].x, b.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].y, b.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].z, b.z, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].w, b.w, acc[m][ct], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+            if (i < wa.nc[ct]) {
+                const double inv = wn2[16 * ct + i];
+                double* col = comps + (wa.kb[ct] + i) * comp_stride;
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        long long r = (long long)t * TR + 16 * m + g + 4 * q;
+                        if (r < rows) {
+                            if (MAP) r = 3 * (vmap[r / 3] - v0) + r % 3;
+                            col[r] = acc[m][ct][q] / inv;
+                        }
+                    }
+            }
+    }
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
                                                 double* __restrict__ scal) {
@@ -811,6 +935,97 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal);
     ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// ---- super-panels ------------------------------------------------------------------------------------------------
+static int super_alloc(asb_ctx* ctx) {
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)3 * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)3 * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)48))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->band_idx, (size_t)ctx->band_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->band_E, (size_t)ctx->band_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->btmp, (size_t)ASB_CBLOCKS * ctx->band_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bcnt, (size_t)ASB_CBLOCKS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bstate, (size_t)1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bpmax, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bpidx, (size_t)ctx->nblk_cap))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bpsum, (size_t)ctx->nblk_cap))) return rc;
+    return ASB_OK;
+}
+
+// builds tile ct's panel operands (B in both layouts, |w|^2) for components [kb, kb + nc)
+static void wide_build_tile(asb_ctx* ctx, int ct, long long kb, int nc) {
+    double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
+    hipLaunchKernelGGL(k_build_wt, dim3(64), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, kb, nc, (int)ctx->Fp, Wt, ctx->wn2t3 + 16 * ct);
+    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, Wt, (int)ctx->Fp, ctx->Wq3 + (size_t)ct * ctx->Fp * 16,
+                       ctx->tile_counter);
+}
+
+// correction + energy update of tile ct (its columns against everything before them), like the tail of project_pass
+static int wide_correct_tile(asb_ctx* ctx, int ct, long long kb, int nc, bool band) {
+    const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
+    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram);
+    if (band) {
+        long long cw = (ctx->band_cap + 255) / 256;
+        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+        hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)0, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->band_E, ctx->bpmax, ctx->bpidx, ctx->bpsum,
+                           ctx->colpart, ctx->band_idx, ctx->bstate, (long long)ctx->v0);
+        hipLaunchKernelGGL(k_band_max, dim3(1), dim3(256), 0, ctx->stream, ctx->bpmax, cgrid, ctx->scalar_dev, ctx->bstate);
+    } else {
+        long long cw = (ctx->n_loc + 255) / 256;
+        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+        hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart);
+        ctx->nblk = cgrid;
+        hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, nc, kb, ctx->scal);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// the band's exact energies after the sub-panel [kb, kb + nc): projection of the band's rows of X (16 columns), correction
+static int band_pass(asb_ctx* ctx, long long kb, int nc) {
+    wide_build_tile(ctx, 0, kb, nc);
+    WideArgs wa{{kb, 0, 0}, {nc, 0, 0}};
+    // 16-row tiles: the band is only ~36k rows, larger tiles would leave most waves idle
+    hipLaunchKernelGGL((k_project_wide<1, 8, 1, true>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, (long long)0, (int)ctx->Fp,
+                       ctx->Wq3, ctx->wn2t3, wa, ctx->comps, (long long)(3 * ctx->n_loc), ctx->tile_counter, ctx->band_idx, ctx->bstate,
+                       (long long)ctx->v0);
+    ASB_CHECK_LAUNCH(ctx);
+    return wide_correct_tile(ctx, 0, kb, nc, true);
+}
+
+// ONE pass over X for up to three sub-panels
+static int project_pass_wide(asb_ctx* ctx, int ntile, const long long* kb, const int* nc) {
+    WideArgs wa{{0, 0, 0}, {0, 0, 0}};
+    for (int ct = 0; ct < ntile; ++ct) {
+        wide_build_tile(ctx, ct, kb[ct], nc[ct]);
+        wa.kb[ct] = kb[ct];
+        wa.nc[ct] = nc[ct];
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    const long long rows = 3 * ctx->n_loc;
+    size_t slot;
+    int rc;
+    if ((rc = prof_begin(ctx, slot))) return rc;
+    if (ntile == 1)
+        hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    else if (ntile == 2)
+        hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    else
+        hipLaunchKernelGGL((k_project_wide<4, 1, 3, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    if ((rc = prof_end(ctx, slot))) return rc;
+    ASB_CHECK_LAUNCH(ctx);
+    for (int ct = 0; ct < ntile; ++ct)
+        if ((rc = wide_correct_tile(ctx, ct, kb[ct], nc[ct], false))) return rc;
     return ASB_OK;
 }
 
@@ -1406,10 +1621,10 @@ __device__ __forceinline__ double coop_load(const double* p) {
 }
 
 template <int NJ>
-__global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const double* __restrict__ R0, long long m_cap, int F, int Fp,
+__global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const double* R0, long long m_cap, int F, int Fp,
                                                        double* __restrict__ W, double* __restrict__ scal, long long k0, int steps,
                                                        PanelState* __restrict__ panel, const long long* __restrict__ cand_idx,
-                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w) {
+                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w, double* rows_out) {
     __shared__ double w_sh[NJ * 64];
     __shared__ double sh_e[4];
     __shared__ long long sh_i[4];
@@ -1525,7 +1740,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             if (am_better(sh_e[q], sh_i[q], be, bi)) { be = sh_e[q]; bi = sh_i[q]; bb = sh_b[q]; }
         if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max: the panel ends here
             if (blockIdx.x == 0 && tid == 0) panel->done = 1;
-            return;
+            break;
         }
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 3] = wall_clock64();
         const double wn2 = coop_load(&recs[bb].wn2);
@@ -1543,7 +1758,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             }
         }
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 4] = wall_clock64();
-        if (t + 1 < steps) {          // explicit deflation of this wave's row
+        if (t + 1 < steps || rows_out != nullptr) {          // explicit deflation of this wave's row
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1561,10 +1776,21 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         __syncthreads();              // w_sh and the wave records are rewritten in the next step
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 5] = wall_clock64();
     }
+    // super-panels run several of these launches on the same candidates: the deflated rows become the next start rows
+    if (rows_out != nullptr && have) {
+        double* row = rows_out + s * 3 * (long long)Fp;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int f = lane + 64 * j;
+                if (f < Fp) row[(long long)d * Fp + f] = x[d][j];
+            }
+    }
 }
 
 template <int NJ>
-static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bool* launched) {
+static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bool* launched, bool writeback) {
     int per_cu = 0;
     ASB_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_panel_coop<NJ>, 256, 0));
     if (per_cu < 1) { *launched = false; return ASB_OK; }
@@ -1575,7 +1801,7 @@ static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bo
     // turns any surprise into an error instead of a hang.
     hipLaunchKernelGGL(k_panel_coop<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (long long)ctx->m_cap, (int)ctx->F,
                        (int)ctx->Fp, ctx->W, ctx->scal, k0, steps, ctx->pstate, ctx->cand_idx, ctx->coop_bar,
-                       (CoopRec*)ctx->coop_rec, ctx->coop_w);
+                       (CoopRec*)ctx->coop_rec, ctx->coop_w, writeback ? ctx->candR : (double*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
     *launched = true;
     return ASB_OK;
@@ -1600,15 +1826,16 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     }
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
-                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all);
+                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all,
+                       ctx->run_theta_band);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     bool coop = false;
     if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
         const int cgrid = cgrid_all;
-        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid, k0, steps, &coop);
-        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid, k0, steps, &coop);
-        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop);
-        else rc = launch_panel_coop<32>(ctx, cgrid, k0, steps, &coop);
+        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
+        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
+        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
+        else rc = launch_panel_coop<32>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
         if (rc) return rc;
     }
     if (assembled && !coop) {      // two-kernel loop: energies / partial records of the assembled buffer (rows came from other ranks)
@@ -1628,6 +1855,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         }
     }
     ASB_CHECK_LAUNCH(ctx);
+    ctx->run_coop_used = coop ? 1 : 0;
     PanelState h;
     ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1643,6 +1871,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
             ctx->n_panels--;
             rc = asb_panel_run(ctx, k0, steps, global_all, assembled, committed);
             ctx->panel_coop = save;
+            ctx->run_coop_used = 0;
             return rc;
         }
     }
@@ -1726,12 +1955,89 @@ extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_
 extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? ctx->m_target : 0; }
 
 // single-rank driver: all K components with no host round trip inside a panel
+// Super-panel (ASB_SUPER_PANELS=1): up to three sub-panels of <= 16 greedy steps on the SAME candidate rows (the panel
+// kernel writes them back) before X is read once for all their columns.  What lets a later sub-panel prove its picks:
+// a BAND of the next ~12k vertices below the candidates gets exact energies after every sub-panel (projection of its
+// rows only + the usual correction: ~0.1 ms), so the bound on everything that is not a candidate drops from the stale
+// tau to max(tau2, largest band energy), where tau2 (stale, valid) bounds the vertices below the band.
+static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
+    int rc;
+    *done_out = 0;
+    if ((rc = super_alloc(ctx))) return rc;
+    // candidates: energy > tau
+    for (int level = 1; level <= 2; ++level) {
+        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+        if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+    }
+    if ((rc = asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU_HI, (int)SC_TAU);
+    // band: tau2 < energy <= tau
+    for (int level = 1; level <= 2; ++level) {
+        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+        hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level, (long long)ctx->band_target,
+                           (long long)ctx->band_cap);
+    }
+    hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc, (long long)ctx->v0,
+                       ctx->scalar_dev, 0, (long long)ctx->band_cap, ctx->btmp, ctx->bcnt, (int)SC_TAU_HI);
+    hipLaunchKernelGGL(k_compact_b, dim3(ASB_CBLOCKS), dim3(64), 0, ctx->stream, ctx->btmp, ctx->bcnt, ASB_CBLOCKS,
+                       (long long)ctx->band_cap, ctx->band_idx, ctx->bstate);
+    hipLaunchKernelGGL(k_band_energy, dim3(64), dim3(256), 0, ctx->stream, ctx->energy, ctx->band_idx, ctx->bstate, (long long)ctx->v0,
+                       ctx->band_E);
+    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU2, (int)SC_TAU);
+    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU, (int)SC_TAU_HI);
+    ASB_CHECK_LAUNCH(ctx);
+    long long kb[3];
+    int nc[3], ntile = 0;
+    long long total = 0;
+    for (int sp = 0; sp < 3 && k + total < k1; ++sp) {
+        const int steps = (int)((k1 - k - total) < ASB_PANEL_COLS ? (k1 - k - total) : ASB_PANEL_COLS);
+        int64_t done = 0;
+        ctx->run_writeback = 1;
+        ctx->run_theta_band = sp > 0 ? 1 : 0;
+        rc = asb_panel_run(ctx, k + total, steps, 0, 0, &done);
+        ctx->run_writeback = 0;
+        ctx->run_theta_band = 0;
+        if (rc) return rc;
+        if (done == 0) break;
+        kb[ntile] = k + total;
+        nc[ntile] = (int)done;
+        ++ntile;
+        total += done;
+        if (!ctx->run_coop_used) break;            // the two-kernel fallback does not carry the rows over
+        static const int min_go = getenv("ASB_SUPER_MIN") ? atoi(getenv("ASB_SUPER_MIN")) : 4;
+        if (done < min_go) break;                  // the bound is what stopped it early (all energies are moving): read X
+        if (sp < 2 && k + total < k1 && (rc = band_pass(ctx, kb[ntile - 1], (int)done))) return rc;
+    }
+    if (total > 0) {
+        if ((rc = project_pass_wide(ctx, ntile, kb, nc))) return rc;
+        ctx->k_done = k + total;
+    }
+    *done_out = total;
+    return ASB_OK;
+}
+
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
     long long k = k0;
     int stalled = 0;
     const int global_all = ctx->n_loc <= ctx->m_cap;
+    // worth it (and the band meaningful) from a few ten thousand vertices on; the band is ~1/10 of the shard, at most 8192
+    const bool use_super = ctx->super_panels && !global_all && ctx->project_kernel == 3 && ctx->panel_coop && ctx->Fp <= 2048 &&
+                           ctx->n_loc >= 20000;
+    if (use_super && !getenv("ASB_BAND_TARGET")) {
+        long long bt = ctx->n_loc / 10;
+        ctx->band_target = bt < 2048 ? 2048 : (bt > 8192 ? 8192 : bt);
+        ctx->band_cap = ctx->band_target * 4 / 3;
+    }
     while (k < k1) {
+        if (use_super && stalled == 0) {
+            int64_t done = 0;
+            if ((rc = super_panel(ctx, k, k1, &done))) return rc;
+            if (done > 0) { k += done; continue; }
+            stalled = 1;                                 // nothing provable: the single-panel path below refreshes / forces
+            if ((rc = asb_panel_refresh(ctx, k, nullptr, nullptr))) return rc;
+            continue;
+        }
         int64_t forced = -1;
         if (stalled >= 2) {        // massive exact ties: the first arg-max of the (exact) energies alone
             double be;

@@ -7,13 +7,15 @@ from animsnapbases_amd import HipEngine
 from oracle import asb_oracle as orc
 from conftest import align_signs, relerr
 
-first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
+nums = [a for a in sys.argv[1:] if not a.startswith("-")]
+first, count = int(nums[0]) if len(nums) > 0 else 1000, int(nums[1]) if len(nums) > 1 else 100
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    N = int(rng.integers(1, 6000))
-    F = int(rng.integers(1, 700))
+    big = "--big" in sys.argv                 # shards large enough for super-panels (ASB_SUPER_PANELS=1)
+    N = int(rng.integers(20000, 70000)) if big else int(rng.integers(1, 6000))
+    F = int(rng.integers(8, 150)) if big else int(rng.integers(1, 700))
     kind = rng.choice(["uniform", "lowrank", "dupes", "zeros", "scaled", "smooth"])
     if kind == "lowrank":
         r = int(rng.integers(1, 20))
@@ -38,7 +40,7 @@ for seed in range(first, first + count):
         continue
     sig = ref["measures"][:, 1]
     good = int(np.argmax(sig < 1e-9 * sig[0])) if np.any(sig < 1e-9 * sig[0]) else K
-    for mode in (0, 1):
+    for mode in ((1,) if big else (0, 1)):
         if "-v" in sys.argv:
             print("start seed", seed, kind, X.shape, "K", K, "mode", mode, flush=True)
         e = HipEngine(0)
