@@ -184,7 +184,9 @@ def main():
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": ({2: "k_project_lds", 3: "k_project_l2<4,2>"}.get(pk, "k_project_mfma") +
+                         "kernel": (("k_project_wide<NT,G,1..3> (super-panels: up to 48 columns per read of X)"
+                                     if os.environ.get("ASB_SUPER_PANELS", "0") == "1" and mode == "project" else
+                                     {2: "k_project_lds", 3: "k_project_l2<4,2>"}.get(pk, "k_project_mfma")) +
                                     " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
