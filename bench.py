@@ -165,7 +165,8 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))["kernels"]
             kname = {2: "k_project_lds", 3: "k_project_l2<4, 2>"}.get(pk)
-            if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1):
+            if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1) and \
+                    os.environ.get("ASB_SUPER_PANELS", "0") != "1":
                 traffic = pm[kname]["hbm_bytes"]
         except Exception:
             traffic = None
