@@ -252,7 +252,9 @@ class constraintsComponents:  # Components == bases
         K = int(self.param.deim_desired_num_components)
         Kp = K * p
         if p == 1:
-            eng.deflate_begin(Kp, False, _lib.DEFLATE_PROJECT)
+            from .posComponents import _auto_global_mode
+            small = _auto_global_mode(ns.frs, ns._shards[comm.rank][1], comm.multi) == "residual"
+            eng.deflate_begin(Kp, False, _lib.DEFLATE_RESIDUAL if small else _lib.DEFLATE_PROJECT)
             if comm.multi:
                 deflate_panels_multirank(eng, comm, ns.frames_rows, Kp)
             else:

@@ -22,6 +22,22 @@ from ._panels import deflate_panels_multirank
 from .utils import log_time, store_components, testSparsity, test_linear_dependency
 
 
+SMALL_TENSOR_BYTES = 128 << 20
+
+
+def n_loc_of(snaps):
+    return snaps._shards[snaps._comm.rank][1]
+
+
+def _auto_global_mode(F, n_loc, multi):
+    """Which device algorithm for support='global'.  The panel (projection) algorithm wins as soon as a read of X costs
+    more than its per-panel overheads; a shard that fits the 256 MB Infinity Cache together with its residual copy
+    (bunny: 68 MB) is faster through the plain residual loop, which has no host round trip at all (measured at
+    14 290 x 200, K = 32: 1.3 ms against 2.8 ms).  Several ranks always use the panel protocol."""
+    Fp = (int(F) + 15) // 16 * 16
+    return "residual" if (not multi and 24 * int(n_loc) * Fp <= SMALL_TENSOR_BYTES) else "project"
+
+
 class posComponents:  # Components == bases
     def __init__(self, param, pos_snapshots=None):
         self.basesType = param.vertPos_bases_type
@@ -114,7 +130,7 @@ class posComponents:  # Components == bases
         # 16 components); otherwise the residual tensor is kept and updated per component.
         mode = self.deflate_mode
         if mode is None:
-            mode = "residual" if local else "project"
+            mode = "residual" if local else _auto_global_mode(self.pos_snapshots.frs, n_loc_of(snaps), comm.multi)
         if mode == "project" and local:
             raise ValueError("deflate_mode='project' needs global support")
         eng.deflate_begin(K, local, _lib.DEFLATE_PROJECT if mode == "project" else _lib.DEFLATE_RESIDUAL)
