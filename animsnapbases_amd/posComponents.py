@@ -22,7 +22,7 @@ from ._panels import deflate_panels_multirank
 from .utils import log_time, store_components, testSparsity, test_linear_dependency
 
 
-SMALL_TENSOR_BYTES = 128 << 20
+SMALL_TENSOR_BYTES = 256 << 20
 
 
 def n_loc_of(snaps):
