@@ -172,6 +172,7 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
 int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
                 int N, int Kc, double alpha, double beta);
 int asb_dense_spd_inverse(asb_ctx* ctx, double* M, int np);
+int asb_deflate_apply_dev(asb_ctx* ctx, int64_t k, const double* s_dev);      // asb_deflate.hip
 // G = X^T X (n x n, both triangles) for a tall row-major X: LDS-tiled f64 MFMA kernel (asb_linalg.hip)
 int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out);
 

@@ -178,6 +178,16 @@ extern "C" int asb_deflate_apply(asb_ctx* ctx, int64_t k, const double* s) {
     return ASB_OK;
 }
 
+// the same with the support map already on the device (asb_deflate_apply_geodesic)
+int asb_deflate_apply_dev(asb_ctx* ctx, int64_t k, const double* s_dev) {
+    if (!ctx || !ctx->R) return ASB_ERR_ARG;
+    if (k < 0 || k >= ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply: k = %lld out of range", (long long)k);
+    int rc = stream_pass(ctx, true, ctx->W + k * ctx->Fp, ctx->scal + k * 4, s_dev, ctx->comps + (size_t)k * 3 * ctx->n_loc);
+    if (rc) return rc;
+    ctx->k_done = k + 1;
+    return ASB_OK;
+}
+
 extern "C" int asb_deflate_run_global(asb_ctx* ctx, int64_t k0, int64_t k1) {
     if (!ctx || !ctx->W) return ASB_ERR_ARG;
     if (ctx->local) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_run_global: context is in local-support mode");

@@ -30,6 +30,7 @@ struct asb_geo {
     bool dense = false;
     int np = 0;
     double *Hinv = nullptr, *Pinv = nullptr;
+    double* sv_part = nullptr;      // k_symv_tiles partial sums
 };
 
 // Y = A X  (+ optional per-column partial sums of X .* Y for CG's p^T A p)
@@ -343,18 +344,12 @@ extern "C" int asb_geodesic_dense_setup(asb_ctx* ctx) {
     return ASB_OK;
 }
 
-// distances from each of nsrc (<= 64) source vertices: out (nsrc, n), host.  iters (optional): CG iterations of the two solves.
-extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters) {
-    if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !out) return ASB_ERR_ARG;
-    if (!(tol >= 1e-14)) tol = 1e-14;      // below the rounding floor CG only wanders (and can blow up)
+// distances of nsrc (<= 64) sources whose vertex ids are on the device; result (nsrc, n), min-shifted, in ctx->geo_out
+static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, double tol, int* it1_out, int* it2_out) {
     asb_geo* G = ctx->geo;
     const int n = G->n;
     int rc;
     if (!G->dense && (rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
-    long long* src_dev = nullptr;
-    if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
-    src_dev = ctx->geo_src;
-    ASB_HIP(ctx, hipMemcpyAsync(src_dev, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
     // heat step: (A - tL) u = delta
     int it1 = 0, it2 = 0;
     if (G->dense) {
@@ -381,10 +376,171 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
     if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;
     hipLaunchKernelGGL(k_shift_min_out, dim3(nsrc), dim3(256), 0, ctx->stream, G->x, n, nsrc, ctx->geo_out);
     ASB_CHECK_LAUNCH(ctx);
-    ASB_HIP(ctx, hipMemcpyAsync(out, ctx->geo_out, (size_t)nsrc * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (it1_out) *it1_out = it1;
+    if (it2_out) *it2_out = it2;
+    return ASB_OK;
+}
+
+// ---- single source, dense backend: the per-component query of support='local'.  Column vectors instead of the 64-wide
+// batch: u = row src of (A - tL)^-1 (symmetric), X = -grad u / |grad u| per face, b = div X, y = Pinv b through the upper
+// triangle of the symmetric Pinv only (each 128 x 128 tile is read once and used for y_I += T b_J and y_J += T^T b_I),
+// phi = max(y) - y.  All sums have a fixed order.
+#define SV_T 128
+__global__ __launch_bounds__(256) void k_face_field1(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                     const double* __restrict__ vals, int ntri, const double* __restrict__ Hinv,
+                                                     int np, const long long* __restrict__ src, double* __restrict__ g) {
+    const double* u = Hinv + src[0] * (long long)np;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntri; t += gridDim.x * 256) {
+        double q[3];
+        for (int d = 0; d < 3; ++d) {
+            const int r = 3 * t + d;
+            double y = 0.0;
+            for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) y += vals[j] * u[colidx[j]];
+            q[d] = y;
+        }
+        const double len = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        g[3 * t] = -q[0] / len; g[3 * t + 1] = -q[1] / len; g[3 * t + 2] = -q[2] / len;
+    }
+}
+__global__ __launch_bounds__(256) void k_spmv1(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                               const double* __restrict__ vals, int rows, int rows_pad,
+                                               const double* __restrict__ x, double* __restrict__ y) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows_pad; r += gridDim.x * 256) {
+        double a = 0.0;
+        if (r < rows)
+            for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) a += vals[j] * x[colidx[j]];
+        y[r] = a;                                  // rows..rows_pad: explicit zeros (the buffer is shared with the batch path)
+    }
+}
+// one block per tile (ib <= jb) of the symmetric matrix: prow[jb][i] = (T b_J)_i, pcol[ib][j] = (T^T b_I)_j (off-diagonal only)
+__global__ __launch_bounds__(256) void k_symv_tiles(const double* __restrict__ P, int np, int nb, const double* __restrict__ b,
+                                                    double* __restrict__ prow, double* __restrict__ pcol) {
+    __shared__ double sh[4][SV_T];
+    int t = blockIdx.x, ib = 0;
+    while (t >= nb - ib) { t -= nb - ib; ++ib; }
+    const int jb = ib + t;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i0 = ib * SV_T, j0 = jb * SV_T, c = j0 + 2 * lane;
+    const bool okc = c < np;                       // np is even: the pair is in or out together
+    const double bj0 = okc ? b[c] : 0.0, bj1 = okc ? b[c + 1] : 0.0;
+    double ca0 = 0.0, ca1 = 0.0;
+    for (int rr = 0; rr < SV_T / 4; rr += 4) {
+        double2 a[4];
+        double bi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = i0 + (rr + q) * 4 + wid;
+            const bool ok = okc && r < np;
+            a[q] = ok ? *reinterpret_cast<const double2*>(P + (long long)r * np + c) : make_double2(0.0, 0.0);
+            bi[q] = r < np ? b[r] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = i0 + (rr + q) * 4 + wid;
+            double s = a[q].x * bj0 + a[q].y * bj1;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && r < np) prow[(long long)jb * np + r] = s;
+            ca0 += a[q].x * bi[q];
+            ca1 += a[q].y * bi[q];
+        }
+    }
+    if (ib == jb) return;
+    sh[wid][2 * lane] = ca0; sh[wid][2 * lane + 1] = ca1;
+    __syncthreads();
+    if (threadIdx.x < SV_T && j0 + (int)threadIdx.x < np) {
+        const int x = threadIdx.x;
+        pcol[(long long)ib * np + j0 + x] = (sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_symv_finish(const double* __restrict__ prow, const double* __restrict__ pcol, int np, int nb,
+                                                     double* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    const int mb = i / SV_T;
+    double s = 0.0;
+    for (int q = 0; q < mb; ++q) s += pcol[(long long)q * np + i];
+    for (int q = mb; q < nb; ++q) s += prow[(long long)q * np + i];
+    y[i] = s;
+}
+// out[i] = max(y) - y[i]
+__global__ __launch_bounds__(1024) void k_max_minus(const double* __restrict__ y, int n, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double m = -1.0e300;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, y[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    m = sh[0];
+    for (int i = threadIdx.x; i < n; i += 1024) out[i] = m - y[i];
+}
+
+static int geodesic_solve1_dense(asb_ctx* ctx, const long long* src_dev) {
+    asb_geo* G = ctx->geo;
+    const int n = G->n, np = G->np, nb = (np + SV_T - 1) / SV_T, ntri = G->m3 / 3;
+    int rc;
+    if ((rc = asb_alloc(ctx, &G->sv_part, (size_t)2 * nb * np))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;
+    // G->g (3M x 64), G->b and G->x (np x 64) are the batch buffers: their heads serve as the single columns
+    hipLaunchKernelGGL(k_face_field1, dim3((ntri + 255) / 256), dim3(256), 0, ctx->stream, G->grad.rowptr, G->grad.colidx, G->grad.vals,
+                       ntri, G->Hinv, np, src_dev, G->g);
+    hipLaunchKernelGGL(k_spmv1, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, G->div.rowptr, G->div.colidx, G->div.vals, n, np,
+                       G->g, G->b);
+    double* prow = G->sv_part;
+    double* pcol = G->sv_part + (size_t)nb * np;
+    hipLaunchKernelGGL(k_symv_tiles, dim3(nb * (nb + 1) / 2), dim3(256), 0, ctx->stream, G->Pinv, np, nb, G->b, prow, pcol);
+    hipLaunchKernelGGL(k_symv_finish, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, prow, pcol, np, nb, G->x);
+    hipLaunchKernelGGL(k_max_minus, dim3(1), dim3(1024), 0, ctx->stream, G->x, n, ctx->geo_out);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// distances from each of nsrc (<= 64) source vertices: out (nsrc, n), host.  iters (optional): CG iterations of the two solves.
+extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters) {
+    if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !out) return ASB_ERR_ARG;
+    if (!(tol >= 1e-14)) tol = 1e-14;      // below the rounding floor CG only wanders (and can blow up)
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->geo_src, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    int it1 = 0, it2 = 0;
+    if ((rc = geodesic_solve_dev(ctx, ctx->geo_src, nsrc, tol, &it1, &it2))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(out, ctx->geo_out, (size_t)nsrc * ctx->geo->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (iters) { iters[0] = it1; iters[1] = it2; }
     return ASB_OK;
+}
+
+// ---- support='local' without a host round trip per component (posComponents.py:87-105 with the dense geodesics):
+// the vertex asb_deflate_pick chose is read from the device, its distance field solved, s = 1 - support_map (:61-64)
+// formed for this shard's vertices and the deflation pass applied -- everything queued on the context's stream.
+__global__ void k_src_from_pick(const double* __restrict__ scal, long long k, long long* __restrict__ src) {
+    src[0] = __double_as_longlong(scal[k * 4 + 2]);
+}
+__global__ __launch_bounds__(256) void k_support_weights(const double* __restrict__ phi, long long v0, long long n_loc, double dmin,
+                                                         double dmax, double* __restrict__ s) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_loc; i += (long long)gridDim.x * 256) {
+        const double p = fmin(fmax(phi[v0 + i], dmin), dmax);
+        s[i] = 1.0 - (p - dmin) / (dmax - dmin);
+    }
+}
+
+extern "C" int asb_deflate_apply_geodesic(asb_ctx* ctx, int64_t k, double dmin, double dmax) {
+    if (!ctx || !ctx->geo || !ctx->scal) return ASB_ERR_ARG;
+    if (!ctx->geo->dense) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply_geodesic needs the dense geodesic backend");
+    if (ctx->geo->n != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply_geodesic: the mesh has %d vertices, the snapshots %lld",
+                                            ctx->geo->n, (long long)ctx->N_glob);
+    if (k < 0 || k >= ctx->K) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
+    hipLaunchKernelGGL(k_src_from_pick, dim3(1), dim3(1), 0, ctx->stream, ctx->scal, (long long)k, ctx->geo_src);
+    if ((rc = geodesic_solve1_dense(ctx, ctx->geo_src))) return rc;
+    const int grid = (int)((ctx->n_loc + 255) / 256 < 1024 ? (ctx->n_loc + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_support_weights, dim3(grid), dim3(256), 0, ctx->stream, ctx->geo_out, (long long)ctx->v0, (long long)ctx->n_loc,
+                       dmin, dmax, ctx->s_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    return asb_deflate_apply_dev(ctx, k, ctx->s_dev);
 }
 
 void asb_geo_free(asb_ctx* ctx) {

@@ -299,8 +299,12 @@ class HipEngine(object):
         args = csr(heat) + csr(lap) + csr(grad) + csr(div) + [dh.ctypes.data, dl.ctypes.data]
         self._ck(self.lib.asb_geodesic_setup(self.h, int(n), int(m3), *args))
         self._geo_n = n
+        self.geodesic_dense = bool(dense)
         if dense:
             self._ck(self.lib.asb_geodesic_dense_setup(self.h))
+
+    def apply_geodesic(self, k, dmin, dmax):
+        self._ck(self.lib.asb_deflate_apply_geodesic(self.h, int(k), float(dmin), float(dmax)))
 
     def geodesic_solve(self, sources, tol=1e-13):
         src = np.ascontiguousarray(sources, dtype=np.int64)

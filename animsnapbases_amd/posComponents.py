@@ -144,6 +144,9 @@ class posComponents:  # Components == bases
             rec = recs = None
             if comm.multi:
                 rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
+            geo = snaps.compute_geodesic_distance
+            on_device_maps = local and getattr(geo, "_engine", None) is eng and getattr(eng, "geodesic_dense", False) \
+                and type(self).compute_support_map is posComponents.compute_support_map
             for k in range(K):
                 if comm.multi:
                     eng.local_best(k, rec.data_ptr())
@@ -152,6 +155,9 @@ class posComponents:  # Components == bases
                 else:
                     eng.pick(k)
                 s_loc = None
+                if local and on_device_maps:          # pick -> distance field -> support weights -> pass: no host round trip
+                    eng.apply_geodesic(k, self.smooth_min_dist, self.smooth_max_dist)
+                    continue
                 if local:
                     idx, _ = eng.get_pick(k)
                     s = 1 - self.compute_support_map(idx, snaps.compute_geodesic_distance,

@@ -222,6 +222,10 @@ int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double to
  * (A - tL) and the gauge-fixed -L once on the device (blocked Gauss-Jordan on f64 MFMA); asb_geodesic_solve then
  * needs no iteration: the heat step is a column gather, the Poisson step one dense product.  tol / iters unused. */
 int asb_geodesic_dense_setup(asb_ctx* ctx);
+/* support='local' step without a host round trip (posComponents.py:87-105, dense geodesics): reads the vertex
+ * asb_deflate_pick chose for component k on the device, solves its distance field, forms
+ * s = 1 - (clip(phi, dmin, dmax) - dmin) / (dmax - dmin) (:61-64) for this shard and applies the deflation. */
+int asb_deflate_apply_geodesic(asb_ctx* ctx, int64_t k, double dmin, double dmax);
 
 /* ------------------------------------------------ snapshot ingest --------------- */
 /* align, utils/process.py:235-250 (find_rbm_procrustes :210-234 + transform :196-208 per frame): every
