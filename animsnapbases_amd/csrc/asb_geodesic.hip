@@ -402,14 +402,19 @@ __global__ __launch_bounds__(256) void k_face_field1(const int* __restrict__ row
         g[3 * t] = -q[0] / len; g[3 * t + 1] = -q[1] / len; g[3 * t + 2] = -q[2] / len;
     }
 }
+// y = A x, eight lanes per row (lane q of the group takes the entries q, q + 8, ... of the row; fixed combination order)
 __global__ __launch_bounds__(256) void k_spmv1(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                const double* __restrict__ vals, int rows, int rows_pad,
                                                const double* __restrict__ x, double* __restrict__ y) {
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows_pad; r += gridDim.x * 256) {
+    const int sub = threadIdx.x & 7;
+    for (int r = (blockIdx.x * 256 + threadIdx.x) >> 3; r < rows_pad; r += gridDim.x * 32) {      // uniform per group
         double a = 0.0;
         if (r < rows)
-            for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) a += vals[j] * x[colidx[j]];
-        y[r] = a;                                  // rows..rows_pad: explicit zeros (the buffer is shared with the batch path)
+            for (int j = rowptr[r] + sub; j < rowptr[r + 1]; j += 8) a += vals[j] * x[colidx[j]];
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        if (sub == 0) y[r] = a;                    // rows..rows_pad: explicit zeros (the buffer is shared with the batch path)
     }
 }
 // one block per tile (ib <= jb) of the symmetric matrix: prow[jb][i] = (T b_J)_i, pcol[ib][j] = (T^T b_I)_j (off-diagonal only)
@@ -454,13 +459,17 @@ __global__ __launch_bounds__(256) void k_symv_tiles(const double* __restrict__ P
 }
 __global__ __launch_bounds__(256) void k_symv_finish(const double* __restrict__ prow, const double* __restrict__ pcol, int np, int nb,
                                                      double* __restrict__ y) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= np) return;
-    const int mb = i / SV_T;
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;      // 64 entries per block, the nb partials in 4 ordered chunks
+    const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int q = 0; q < mb; ++q) s += pcol[(long long)q * np + i];
-    for (int q = mb; q < nb; ++q) s += prow[(long long)q * np + i];
-    y[i] = s;
+    if (i < np) {
+        const int mb = i / SV_T, q0 = g * nb / 4, q1 = (g + 1) * nb / 4;
+        for (int q = q0; q < q1; ++q) s += (q < mb ? pcol : prow)[(long long)q * np + i];
+    }
+    sh[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && i < np) y[i] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 // out[i] = max(y) - y[i]
 __global__ __launch_bounds__(1024) void k_max_minus(const double* __restrict__ y, int n, double* __restrict__ out) {
@@ -486,12 +495,12 @@ static int geodesic_solve1_dense(asb_ctx* ctx, const long long* src_dev) {
     // G->g (3M x 64), G->b and G->x (np x 64) are the batch buffers: their heads serve as the single columns
     hipLaunchKernelGGL(k_face_field1, dim3((ntri + 255) / 256), dim3(256), 0, ctx->stream, G->grad.rowptr, G->grad.colidx, G->grad.vals,
                        ntri, G->Hinv, np, src_dev, G->g);
-    hipLaunchKernelGGL(k_spmv1, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, G->div.rowptr, G->div.colidx, G->div.vals, n, np,
+    hipLaunchKernelGGL(k_spmv1, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, G->div.rowptr, G->div.colidx, G->div.vals, n, np,
                        G->g, G->b);
     double* prow = G->sv_part;
     double* pcol = G->sv_part + (size_t)nb * np;
     hipLaunchKernelGGL(k_symv_tiles, dim3(nb * (nb + 1) / 2), dim3(256), 0, ctx->stream, G->Pinv, np, nb, G->b, prow, pcol);
-    hipLaunchKernelGGL(k_symv_finish, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, prow, pcol, np, nb, G->x);
+    hipLaunchKernelGGL(k_symv_finish, dim3((np + 63) / 64), dim3(256), 0, ctx->stream, prow, pcol, np, nb, G->x);
     hipLaunchKernelGGL(k_max_minus, dim3(1), dim3(1024), 0, ctx->stream, G->x, n, ctx->geo_out);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;

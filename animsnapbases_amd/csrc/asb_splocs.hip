@@ -24,8 +24,9 @@ int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0
 // W[:,k] = project_weight(opt)  (clamp at 0, divide by the max unless it is 0).
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_bcd(double* __restrict__ W, const double* __restrict__ P,
-                                              const double* __restrict__ M, int F, int K) {
+                                              const double* __restrict__ M, int F, int K, const int* __restrict__ only_if) {
     extern __shared__ double sm[];       // K (column of M) + 16 (wave maxima)
+    if (only_if && !only_if[0]) return;  // fallback of k_bcd_wide: runs only when that one gave up
     double* mcol = sm;
     double* wmax = sm + K;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -57,6 +58,76 @@ __global__ __launch_bounds__(1024) void k_bcd(double* __restrict__ W, const doub
             for (int f = tid; f < F; f += nt) W[(long long)f * K + k] /= mx;
         __syncthreads();
     }
+}
+
+// k_bcd_wide: the same sweep spread over co-resident blocks, one weight row per thread held in LDS (column-major:
+// sw[j * nt + tid]), so the K dot products of a row never leave the CU.  The only coupling between rows is the column
+// maximum of project_weight: block b publishes its maximum of column k in slot[k * nblk + b] (armed to -1 by the host;
+// a maximum is >= 0) and every block polls the nblk slots of the column -- one exchange per column instead of the
+// single block's K passes through L2.  A poll that does not complete (blocks not co-resident) raises flag[0]; W is only
+// written at the very end, so the single-block kernel can redo the sweep from the untouched input in that case.
+__global__ __launch_bounds__(256) void k_bcd_wide(double* __restrict__ W, const double* __restrict__ P, const double* __restrict__ M,
+                                                  int F, int K, double* slot, int* flag) {
+    extern __shared__ double sm[];       // nt * K (rows) + K (column of M) + 4 (wave maxima)
+    const int tid = threadIdx.x, nt = blockDim.x, nblk = gridDim.x;
+    double* sw = sm;
+    double* mcol = sm + (size_t)nt * K;
+    double* wmax = mcol + K;
+    const int f = blockIdx.x * nt + tid;
+    const bool live = f < F;
+    for (int j = 0; j < K; ++j) sw[(size_t)j * nt + tid] = live ? W[(long long)f * K + j] : 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double nk = M[(long long)k * K + k];
+        if (nk <= 1.e-8) {               // (:147-150)
+            sw[(size_t)k * nt + tid] = 0.0;
+            continue;
+        }
+        __syncthreads();                 // the previous column's readers of mcol / wmax are done
+        for (int j = tid; j < K; j += nt) mcol[j] = M[(long long)j * K + k];
+        __syncthreads();
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += sw[(size_t)j * nt + tid] * mcol[j];
+        double opt = 0.0;
+        if (live) opt = fmax(0.0, (P[(long long)f * K + k] - s) / nk + sw[(size_t)k * nt + tid]);
+        double mx = wave_max(opt);
+        if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            mx = 0.0;
+            for (int q = 0; q < (nt >> 6); ++q) mx = fmax(mx, wmax[q]);
+            __hip_atomic_store(slot + (long long)k * nblk + blockIdx.x, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // all blocks' maxima of this column: thread q polls blocks q, q + nt, ...
+        mx = 0.0;
+        for (int q = tid; q < nblk; q += nt) {
+            double v = -1.0;
+            for (int spin = 0; spin < (1 << 20); ++spin) {
+                v = __hip_atomic_load(slot + (long long)k * nblk + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= 0.0) break;
+                if ((spin & 1023) == 1023 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!(v >= 0.0)) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0.0; }
+            mx = fmax(mx, v);
+        }
+        mx = wave_max(mx);
+        __syncthreads();                 // wmax was read by thread 0 above
+        if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+        __syncthreads();
+        mx = 0.0;
+        for (int q = 0; q < (nt >> 6); ++q) mx = fmax(mx, wmax[q]);
+        sw[(size_t)k * nt + tid] = (mx != 0.0) ? opt / mx : opt;
+    }
+    __syncthreads();
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    // (a block that gets here after some column got stuck has either timed out on that column itself or seen the flag,
+    // so nobody writes once the sweep is abandoned)
+    if (live)
+        for (int j = 0; j < K; ++j) W[(long long)f * K + j] = sw[(size_t)j * nt + tid];
+}
+__global__ void k_bcd_arm(double* slot, long long n, int* flag) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) slot[i] = -1.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
 }
 
 // per component: vertex with the largest |C_k[v]|^2 (first on ties) (:161)
@@ -205,7 +276,7 @@ struct asb_splocs {
     int64_t K = 0;
     double *C = nullptr, *Z = nullptr, *U = nullptr, *c = nullptr, *rhs = nullptr, *Lambda = nullptr, *Ct = nullptr;
     double *Wfk = nullptr, *P = nullptr, *M = nullptr, *G = nullptr, *Ginv = nullptr, *red = nullptr;
-    double *cen_val = nullptr;
+    double *cen_val = nullptr, *bcd_slot = nullptr;
     long long* cen_idx = nullptr;
     int* status = nullptr;
 };
@@ -277,7 +348,22 @@ extern "C" int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const doubl
     const int K = (int)s->K, F = (int)ctx->F;
     if (P_dev) ASB_HIP(ctx, hipMemcpyAsync(s->P, P_dev, (size_t)F * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (M_dev) ASB_HIP(ctx, hipMemcpyAsync(s->M, M_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_bcd, dim3(1), dim3(1024), (K + 16) * sizeof(double), ctx->stream, s->Wfk, s->P, s->M, F, K);
+    // rows per block so that the rows fit the LDS; the blocks must all be resident (one per CU at most)
+    int nt = (int)((150 * 1024 / sizeof(double) - 8) / (size_t)(K + 1)) / 64 * 64;
+    if (nt > 256) nt = 256;
+    const int nblk = nt >= 64 ? (F + nt - 1) / nt : 0;
+    const char* env = getenv("ASB_BCD_WIDE");
+    if (nt >= 64 && nblk <= ctx->n_cu && !(env && env[0] == '0')) {
+        int rc2;
+        if ((rc2 = asb_alloc(ctx, &s->bcd_slot, (size_t)K * nblk + 1))) return rc2;
+        int* flag = reinterpret_cast<int*>(s->bcd_slot + (size_t)K * nblk);
+        const size_t lds = ((size_t)nt * K + K + 4) * sizeof(double);
+        if (lds > 48 * 1024) ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_bcd_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bcd_arm, dim3(64), dim3(256), 0, ctx->stream, s->bcd_slot, (long long)K * nblk, flag);
+        hipLaunchKernelGGL(k_bcd_wide, dim3(nblk), dim3(nt), lds, ctx->stream, s->Wfk, s->P, s->M, F, K, s->bcd_slot, flag);
+        hipLaunchKernelGGL(k_bcd, dim3(1), dim3(1024), (K + 16) * sizeof(double), ctx->stream, s->Wfk, s->P, s->M, F, K, (const int*)flag);
+    } else
+        hipLaunchKernelGGL(k_bcd, dim3(1), dim3(1024), (K + 16) * sizeof(double), ctx->stream, s->Wfk, s->P, s->M, F, K, (const int*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
     int rc = asb_gemm_tn(ctx, s->Wfk, K, s->Wfk, K, F, K, K, s->G);
     if (rc) return rc;

@@ -272,6 +272,24 @@ def test_splocs_vs_oracle_medium():
     assert relerr(comp.splocs_weigs, s["W"]) < 1e-8
 
 
+def test_splocs_weight_sweep_blocks_agree(monkeypatch):
+    """The activation sweep spread over co-resident blocks (k_bcd_wide: rows in LDS, one exchange of the column maximum
+    per column) must give the single-block kernel's weights bit for bit (F = 700: three blocks, one of them ragged)."""
+    rest_v, tris = orc.synth_mesh(14, 20, seed=18)
+    verts = orc.synth_snapshots(rest_v, 700, rank=20, seed=18, kind="bumps")
+    param = _param(vertPos_numComponents=24, q_support="local", vertPos_bases_type="SPLOCS", vertPos_smooth_min_dist=0.1,
+                   vertPos_smooth_max_dist=0.4, splocs_max_itrs=3, splocs_admm_num_itrs=4, splocs_lambda=2.0, splocs_rho=10.0)
+    outs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("ASB_BCD_WIDE", wide)
+        snaps, comp = _run(verts, tris, param)
+        outs.append((comp.splocs_weigs.copy(), comp.splocs_comps.copy(), comp.splocs_trace.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][0].max() == 1.0 and outs[0][0].min() == 0.0
+
+
 def test_project_mode_stepwise_panel_protocol():
     """The multi-rank panel protocol (asb_panel_* steps, torch exchange buffers, assemble) driven on
     ONE GPU must reproduce the fused single-rank run bit for bit."""
