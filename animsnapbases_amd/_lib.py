@@ -89,6 +89,9 @@ PROTOTYPES = {
     "asb_splocs_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.POINTER(c_dbl)]),
     "asb_splocs_weights": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp]),
     "asb_splocs_admm": (c_int, [ctypes.c_void_p, c_dp, c_dbl, c_int]),
+    "asb_splocs_admm_fields": (c_int, [ctypes.c_void_p, c_dp, c_dbl, c_dbl, c_dbl, c_dbl, c_int]),
+    "asb_geodesic_cache_add": (c_int, [ctypes.c_void_p, c_dp, c_int, c_dbl, c_dp]),
+    "asb_geodesic_cache_clear": (c_int, [ctypes.c_void_p]),
     "asb_splocs_objective": (c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
                                      ctypes.POINTER(c_dbl)]),
     "asb_splocs_results": (c_int, [ctypes.c_void_p, c_dp, c_dp]),

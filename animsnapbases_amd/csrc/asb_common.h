@@ -139,6 +139,8 @@ int asb_project_begin(asb_ctx* ctx, int64_t K);
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
 void asb_splocs_free(asb_ctx* ctx);
 void asb_geo_free(asb_ctx* ctx);
+#define ASB_GEO_CACHE_SLABS 64          // x 64 distance fields
+const double* asb_geo_cached_field(asb_ctx* ctx, long long slot, long long* n_out);
 // small dense linear algebra on the device (asb_linalg.hip)
 // out[i*so_i + j*so_j] = sum_r A[r*lda + i*sa] * B[r*ldb + j]   (f64 MFMA; contraction index r slow in A and B)
 int asb_gemm_tn_s(asb_ctx* ctx, const double* A, long long lda, long long sa, const double* B, long long ldb, long long Rn,

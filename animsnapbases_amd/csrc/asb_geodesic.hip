@@ -31,6 +31,9 @@ struct asb_geo {
     int np = 0;
     double *Hinv = nullptr, *Pinv = nullptr;
     double* sv_part = nullptr;      // k_symv_tiles partial sums
+    // distance fields kept for SPLOCS (asb_geodesic_cache_add): slot q lives in slab[q / 64] at row q % 64
+    double* slab[ASB_GEO_CACHE_SLABS] = {};
+    long long cached = 0;
 };
 
 // Y = A X  (+ optional per-column partial sums of X .* Y for CG's p^T A p)
@@ -193,6 +196,8 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
     if (!ctx->geo) ctx->geo = new asb_geo();
     asb_geo* G = ctx->geo;
     G->n = n; G->m3 = m3;
+    G->dense = false;                  // a new mesh: explicit inverses and cached fields of the old one are void
+    G->cached = 0;
     int rc;
     if ((rc = upload_csr(ctx, G->heat, n, n, heat_rp, heat_ci, heat_v))) return rc;
     if ((rc = upload_csr(ctx, G->lap, n, n, lap_rp, lap_ci, lap_v))) return rc;
@@ -519,6 +524,43 @@ extern "C" int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (iters) { iters[0] = it1; iters[1] = it2; }
     return ASB_OK;
+}
+
+// ---- distance fields kept on the device (SPLOCS asks for the fields of its K centres in every outer iteration,
+// posComponents.py:158-165, and most centres stay): solve the fields of nsrc (<= 64) new sources and append them to the
+// cache; *slot0 = slot of the first one.  ASB_ERR_LIMIT when the cache is full (asb_geodesic_cache_clear empties it).
+extern "C" int asb_geodesic_cache_add(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, int64_t* slot0) {
+    if (!ctx || !ctx->geo || !sources || nsrc < 1 || nsrc > GB || !slot0) return ASB_ERR_ARG;
+    asb_geo* G = ctx->geo;
+    if (G->cached + nsrc > (long long)ASB_GEO_CACHE_SLABS * GB) ASB_FAIL(ctx, ASB_ERR_LIMIT, "geodesic field cache is full (%lld fields)", G->cached);
+    for (int c = 0; c < nsrc; ++c)
+        if (sources[c] < 0 || sources[c] >= G->n) ASB_FAIL(ctx, ASB_ERR_ARG, "geodesic source %lld outside the mesh", (long long)sources[c]);
+    if (!(tol >= 1e-14)) tol = 1e-14;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->geo_src, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = geodesic_solve_dev(ctx, ctx->geo_src, nsrc, tol, nullptr, nullptr))) return rc;
+    const size_t n = (size_t)G->n;
+    for (int c = 0; c < nsrc; ++c) {
+        const long long q = G->cached + c;
+        if ((rc = asb_alloc(ctx, &G->slab[q / GB], (size_t)GB * n))) return rc;      // keeps an existing slab (same size)
+        ASB_HIP(ctx, hipMemcpyAsync(G->slab[q / GB] + (size_t)(q % GB) * n, ctx->geo_out + (size_t)c * n, n * sizeof(double),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    *slot0 = G->cached;
+    G->cached += nsrc;
+    return ASB_OK;
+}
+extern "C" int asb_geodesic_cache_clear(asb_ctx* ctx) {
+    if (!ctx) return ASB_ERR_ARG;
+    if (ctx->geo) ctx->geo->cached = 0;
+    return ASB_OK;
+}
+// device address of a cached field (nullptr: no such slot) and the mesh size, for asb_splocs.hip
+const double* asb_geo_cached_field(asb_ctx* ctx, long long slot, long long* n_out) {
+    if (!ctx->geo || slot < 0 || slot >= ctx->geo->cached) return nullptr;
+    if (n_out) *n_out = ctx->geo->n;
+    return ctx->geo->slab[slot / GB] + (size_t)(slot % GB) * ctx->geo->n;
 }
 
 // ---- support='local' without a host round trip per component (posComponents.py:87-105 with the dense geodesics):

@@ -277,6 +277,7 @@ struct asb_splocs {
     double *C = nullptr, *Z = nullptr, *U = nullptr, *c = nullptr, *rhs = nullptr, *Lambda = nullptr, *Ct = nullptr;
     double *Wfk = nullptr, *P = nullptr, *M = nullptr, *G = nullptr, *Ginv = nullptr, *red = nullptr;
     double *cen_val = nullptr, *bcd_slot = nullptr;
+    const double** field_ptr = nullptr;
     long long* cen_idx = nullptr;
     int* status = nullptr;
 };
@@ -376,12 +377,55 @@ extern "C" int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const doubl
     return ASB_OK;
 }
 
-// ADMM (:168-181) with Lambda (K, n_loc) from the host; leaves C = Z.
+// ADMM (:168-181) with Lambda (K, n_loc) already in s->Lambda; leaves C = Z.
+static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter);
+
 extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, int n_iter) {
     if (!ctx || !ctx->splocs || !Lambda) return ASB_ERR_ARG;
     asb_splocs* s = ctx->splocs;
+    ASB_HIP(ctx, hipMemcpyAsync(s->Lambda, Lambda, (size_t)s->K * ctx->n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return splocs_admm_run(ctx, rho, n_iter);
+}
+
+// Lambda[k][i] = lambda * (clip(phi_k[v0 + i], dmin, dmax) - dmin) / (dmax - dmin)   (:162-165, utils/support.py:61-64)
+__global__ __launch_bounds__(256) void k_lambda_fields(const double* const* __restrict__ field, long long v0, long long n_loc,
+                                                       double lambda, double dmin, double dmax, double* __restrict__ L) {
+    const double* phi = field[blockIdx.y] + v0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_loc; i += (long long)gridDim.x * 256) {
+        const double p = fmin(fmax(phi[i], dmin), dmax);
+        L[(long long)blockIdx.y * n_loc + i] = lambda * ((p - dmin) / (dmax - dmin));
+    }
+}
+
+// the same step with the support maps built on the device from cached distance fields (asb_geodesic_cache_add):
+// slots (K, host) = cache slot of each component's centre
+extern "C" int asb_splocs_admm_fields(asb_ctx* ctx, const int64_t* slots, double lambda, double dmin, double dmax, double rho,
+                                      int n_iter) {
+    if (!ctx || !ctx->splocs || !slots) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    const int64_t K = s->K;
+    std::vector<const double*> ptrs((size_t)K);
+    for (int64_t k = 0; k < K; ++k) {
+        long long n = 0;
+        ptrs[(size_t)k] = asb_geo_cached_field(ctx, slots[k], &n);
+        if (!ptrs[(size_t)k]) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_splocs_admm_fields: no cached field in slot %lld", (long long)slots[k]);
+        if (n != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_splocs_admm_fields: the mesh has %lld vertices, the snapshots %lld", n,
+                                       (long long)ctx->N_glob);
+    }
+    int rc;
+    if ((rc = asb_alloc(ctx, &s->field_ptr, (size_t)K))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(s->field_ptr, ptrs.data(), (size_t)K * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // ptrs is a local
+    const int gx = (int)((ctx->n_loc + 255) / 256 < 64 ? (ctx->n_loc + 255) / 256 : 64);
+    hipLaunchKernelGGL(k_lambda_fields, dim3(gx, (unsigned)K), dim3(256), 0, ctx->stream, s->field_ptr, (long long)ctx->v0,
+                       (long long)ctx->n_loc, lambda, dmin, dmax, s->Lambda);
+    ASB_CHECK_LAUNCH(ctx);
+    return splocs_admm_run(ctx, rho, n_iter);
+}
+
+static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
+    asb_splocs* s = ctx->splocs;
     const int64_t K = s->K, n3 = 3 * ctx->n_loc, kn = K * ctx->n_loc;
-    ASB_HIP(ctx, hipMemcpyAsync(s->Lambda, Lambda, (size_t)kn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     // c = W^T X  (K x 3n): the deflation's projection kernel, 16 columns per pass over X
     for (int64_t k0 = 0; k0 < K; k0 += 16) {
         const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);

@@ -265,6 +265,12 @@ class HipEngine(object):
         assert Lambda_loc.shape == (self.K, self.n_loc)
         self._ck(self.lib.asb_splocs_admm(self.h, ptr(Lambda_loc), float(rho), int(n_iter)))
 
+    def splocs_admm_fields(self, slots, lam, dmin, dmax, rho, n_iter):
+        """ADMM step with Lambda built on the device from cached distance fields (geodesic_cache_add)."""
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        assert slots.shape == (self.K,)
+        self._ck(self.lib.asb_splocs_admm_fields(self.h, ptr(slots), float(lam), float(dmin), float(dmax), float(rho), int(n_iter)))
+
     def splocs_objective(self, P_dev_ptr=None, M_dev_ptr=None):
         wp, gm, sp = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         self._ck(self.lib.asb_splocs_objective(self.h, ctypes.c_void_p(P_dev_ptr) if P_dev_ptr else None,
@@ -305,6 +311,22 @@ class HipEngine(object):
 
     def apply_geodesic(self, k, dmin, dmax):
         self._ck(self.lib.asb_deflate_apply_geodesic(self.h, int(k), float(dmin), float(dmax)))
+
+    GEODESIC_CACHE_SLOTS = 64 * 64
+
+    def geodesic_cache_add(self, sources, tol=1e-13):
+        """Solves the distance fields of ``sources`` and keeps them on the device; returns their cache slots."""
+        src = np.ascontiguousarray(sources, dtype=np.int64)
+        slots = []
+        for b in range(0, src.shape[0], 64):
+            part = src[b:b + 64]
+            s0 = ctypes.c_int64()
+            self._ck(self.lib.asb_geodesic_cache_add(self.h, ptr(part), int(part.shape[0]), float(tol), ctypes.addressof(s0)))
+            slots.extend(range(s0.value, s0.value + part.shape[0]))
+        return slots
+
+    def geodesic_cache_clear(self):
+        self._ck(self.lib.asb_geodesic_cache_clear(self.h))
 
     def geodesic_solve(self, sources, tol=1e-13):
         src = np.ascontiguousarray(sources, dtype=np.int64)

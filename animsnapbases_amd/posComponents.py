@@ -220,24 +220,41 @@ class posComponents:  # Components == bases
 
         normX2 = comm.allreduce_sum(gram(True))[0]
         phi_cache = {}
+        # distance fields and support maps stay on the device when the geodesics run on this engine
+        fields_on_device = getattr(compute_geodesic_distance, "_engine", None) is eng and hasattr(eng, "splocs_admm_fields")
+        slot_of = {}
+        if fields_on_device:
+            eng.geodesic_cache_clear()
         trace, centres = [], []
         for it in range(num_iters_max):
             cidx, cval = eng.splocs_weights(*ptrs())                          # :144-156, :161
             if comm.multi:
                 cidx = comm.global_argmax(cidx, cval)
-            missing = [int(i) for i in dict.fromkeys(cidx.tolist()) if int(i) not in phi_cache]
-            if missing:
-                many = getattr(compute_geodesic_distance, "solve_many", None)
-                phis = many(missing) if many else [compute_geodesic_distance(i) for i in missing]
-                for i, phi in zip(missing, phis):
-                    phi_cache[i] = phi
-            Lambda = np.empty((K, n_loc))
-            for k in range(K):                                                # :162-165
-                phi = phi_cache[int(cidx[k])]
-                smap = (clip(phi, self.smooth_min_dist, self.smooth_max_dist) - self.smooth_min_dist) \
-                    / (self.smooth_max_dist - self.smooth_min_dist)
-                Lambda[k] = lam * smap[v0:v0 + n_loc]
-            eng.splocs_admm(Lambda, rho, num_admm_iterations)                 # :167-181
+            if fields_on_device:
+                wanted = [int(i) for i in dict.fromkeys(cidx.tolist())]
+                missing = [i for i in wanted if i not in slot_of]
+                if len(slot_of) + len(missing) > eng.GEODESIC_CACHE_SLOTS:    # cache full: start again with this iteration's centres
+                    eng.geodesic_cache_clear()
+                    slot_of, missing = {}, wanted
+                if missing:
+                    tol = getattr(compute_geodesic_distance, "_tol", 1e-13)
+                    slot_of.update(zip(missing, eng.geodesic_cache_add(missing, tol)))
+                eng.splocs_admm_fields([slot_of[int(i)] for i in cidx], lam, self.smooth_min_dist, self.smooth_max_dist,
+                                       rho, num_admm_iterations)              # :162-181
+            else:
+                missing = [int(i) for i in dict.fromkeys(cidx.tolist()) if int(i) not in phi_cache]
+                if missing:
+                    many = getattr(compute_geodesic_distance, "solve_many", None)
+                    phis = many(missing) if many else [compute_geodesic_distance(i) for i in missing]
+                    for i, phi in zip(missing, phis):
+                        phi_cache[i] = phi
+                Lambda = np.empty((K, n_loc))
+                for k in range(K):                                            # :162-165
+                    phi = phi_cache[int(cidx[k])]
+                    smap = (clip(phi, self.smooth_min_dist, self.smooth_max_dist) - self.smooth_min_dist) \
+                        / (self.smooth_max_dist - self.smooth_min_dist)
+                    Lambda[k] = lam * smap[v0:v0 + n_loc]
+                eng.splocs_admm(Lambda, rho, num_admm_iterations)             # :167-181
             gram()
             wp, gm, sp = eng.splocs_objective(*ptrs())
             sparsity = comm.allreduce_sum(sp)[0]

@@ -226,6 +226,11 @@ int asb_geodesic_dense_setup(asb_ctx* ctx);
  * asb_deflate_pick chose for component k on the device, solves its distance field, forms
  * s = 1 - (clip(phi, dmin, dmax) - dmin) / (dmax - dmin) (:61-64) for this shard and applies the deflation. */
 int asb_deflate_apply_geodesic(asb_ctx* ctx, int64_t k, double dmin, double dmax);
+/* Distance fields kept on the device for SPLOCS (posComponents.py:158-165 asks for the fields of the K centres in every
+ * outer iteration): solves the fields of nsrc (<= 64) new sources and appends them to the context's cache (4096 slots);
+ * *slot0 = slot of the first.  ASB_ERR_LIMIT when full; asb_geodesic_cache_clear empties the cache (buffers stay). */
+int asb_geodesic_cache_add(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, int64_t* slot0);
+int asb_geodesic_cache_clear(asb_ctx* ctx);
 
 /* ------------------------------------------------ snapshot ingest --------------- */
 /* align, utils/process.py:235-250 (find_rbm_procrustes :210-234 + transform :196-208 per frame): every
@@ -286,6 +291,9 @@ int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const double* M_dev,
                        int64_t* centre_idx, double* centre_val);
 /* :167-181 ADMM with Lambda (host, K x n_loc) = splocs_lambda * support_map; C = Z at the end */
 int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, int n_iter);
+/* the same step with Lambda built on the device: Lambda[k] = lambda * (clip(phi_k, dmin, dmax) - dmin) / (dmax - dmin)
+ * (:162-165, utils/support.py:61-64) from the cached distance field in slot slots[k] (K slots, host) */
+int asb_splocs_admm_fields(asb_ctx* ctx, const int64_t* slots, double lambda, double dmin, double dmax, double rho, int n_iter);
 /* :183-186 pieces of the objective for the new C (call asb_splocs_gram first):
  * wp = <W, P>, gm = <W^T W, M>  =>  |X - W C|^2 = |X|^2 - 2 wp + gm;
  * sparsity_local = sum Lambda |C_v| over the shard. */
