@@ -12,6 +12,8 @@
 #include "asb.h"
 
 // Device-resident state of one panel of the projection path (asb_project.hip).
+#define ASB_PANEL_COLS 16          // steps (weight columns) per panel = columns of one projection pass
+
 struct PanelState {
     double theta;          // upper bound on the energy of every NON-candidate vertex
     double margin;         // absolute safety margin on that bound (rounding of the energy recurrence)
@@ -19,6 +21,11 @@ struct PanelState {
     long long committed;   // components committed in this panel
     long long n_cand;
     long long pad;
+    // steps taken without proof (verified against every vertex's energy after the projection pass, k_correct<true>)
+    long long proven;      // length of the provable head of the panel (-1 until the panel kernel has set it)
+    long long spec_max;    // how many unproven steps the panel kernel may add
+    long long spec_ok;     // first unproven step the verification rejected (>= committed: none)
+    double e_win[16];      // energy of each step's winner
 };
 
 struct StreamCfg {
@@ -59,6 +66,11 @@ struct asb_ctx {
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
     // super-panels (asb_project.hip): how the next asb_panel_run behaves / what it did
     int run_writeback = 0, run_theta_band = 0, run_coop_used = 0;
+    int spec_panels = 1;              // ASB_SPEC_PANELS=0 -> provable steps only
+    int run_spec_max = 0;             // unproven steps the next asb_panel_run may take (0 outside asb_project_run)
+    int spec_budget = 16;             // adapted to how many unproven steps survived in the last panels
+    long long run_proven = 0;         // provable head of the last asb_panel_run
+    long long n_spec_steps = 0, n_spec_kept = 0;      // statistics (asb_deflate_stats)
     int super_panels = 0;             // ASB_SUPER_PANELS=1
     long long band_target = 12288, band_cap = 16384;
     long long* band_idx = nullptr;

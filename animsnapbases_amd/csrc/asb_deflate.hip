@@ -43,6 +43,8 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->local = local_support;
     ctx->k_done = 0;
     ctx->n_panels = ctx->n_refresh = 0;
+    ctx->n_spec_steps = ctx->n_spec_kept = 0;
+    ctx->spec_budget = ASB_PANEL_COLS;
     if (mode == ASB_DEFLATE_PROJECT) return asb_project_begin(ctx, K);
     const size_t rows = (size_t)ctx->n_loc * 3;
     int rc;
@@ -283,5 +285,12 @@ extern "C" int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_ref
     if (!ctx) return ASB_ERR_ARG;
     if (n_panels) *n_panels = ctx->n_panels;
     if (n_refresh) *n_refresh = ctx->n_refresh;
+    return ASB_OK;
+}
+
+extern "C" int asb_deflate_spec_stats(asb_ctx* ctx, int64_t* tried, int64_t* kept) {
+    if (!ctx) return ASB_ERR_ARG;
+    if (tried) *tried = ctx->n_spec_steps;
+    if (kept) *kept = ctx->n_spec_kept;
     return ASB_OK;
 }

@@ -25,7 +25,6 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define ASB_NBINS 2048
-#define ASB_PANEL_COLS 16
 
 // layout of ctx->scalar_dev (doubles)
 enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
@@ -282,7 +281,8 @@ __global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ 
 // arms the panel: every vertex outside the candidate buffer has energy <= theta
 __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
                             long long n_slots, double margin_rel, unsigned* __restrict__ coop_flags,
-                            unsigned long long* __restrict__ coop_rec, int n_rec, int theta_from_band = 0) {
+                            unsigned long long* __restrict__ coop_rec, int n_rec, int theta_from_band = 0,
+                            long long spec_max = 0) {
     // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4)
     if (coop_flags && threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
     if (coop_rec)
@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ pane
     panel->margin = margin_rel * sc[SC_E0MAX];
     panel->done = 0;
     panel->committed = 0;
+    panel->proven = -1;
+    panel->spec_max = spec_max;
+    panel->spec_ok = ASB_PANEL_COLS;
 }
 
 __global__ void k_sc_copy(double* __restrict__ sc, int dst, int src) { sc[dst] = sc[src]; }
@@ -371,14 +374,29 @@ __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W
 
 // vmap != nullptr: only the vertices vmap[0 .. bstate->n_cand) (global ids; the band of a super-panel) are treated, E is
 // their compact energy array and colpart is not written (the full pass accounts for every vertex later).
+// SPEC (panels with unproven steps, full shard only): the corrected coefficients are written, but the energies are
+// left alone; instead every vertex outside the candidate set (E <= tau at panel start) follows its energy through
+// the columns and reports the first unproven step t >= proven whose winner it would have beaten (or tied with,
+// within the margin): spec->spec_ok = the smallest such t.  k_commit_energy then applies the columns before it.
+template <bool SPEC>
 __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, long long comp_stride, long long n_vert,
                                                  int k0, int ncols, const double* __restrict__ G,
                                                  const double* __restrict__ wn2, double* __restrict__ E,
                                                  double* __restrict__ pmax, long long* __restrict__ pidx,
                                                  double* __restrict__ psum, double* __restrict__ colpart,
                                                  const long long* __restrict__ vmap = nullptr,
-                                                 const PanelState* __restrict__ bstate = nullptr, long long v0 = 0) {
+                                                 const PanelState* __restrict__ bstate = nullptr, long long v0 = 0,
+                                                 PanelState* __restrict__ spec = nullptr, const double* __restrict__ sc = nullptr) {
     if (vmap != nullptr) n_vert = bstate->n_cand;
+    __shared__ int sh_viol[4];
+    int viol = ASB_PANEL_COLS;
+    double ew[16], sp_tau = 0.0, sp_margin = 0.0;
+    int sp_proven = 0;
+    if (SPEC) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ew[t] = spec->e_win[t];
+        sp_tau = sc[SC_TAU]; sp_margin = spec->margin; sp_proven = (int)spec->proven;
+    }
     __shared__ double gs[64 * 16];
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
@@ -430,6 +448,21 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                 const double gq = (t < ncols) ? gs[j * 16 + t] : 0.0;
                 c[t][0] -= c[j][0] * gq; c[t][1] -= c[j][1] * gq; c[t][2] -= c[j][2] * gq;
             }
+        if (SPEC) {
+            if (valid) {
+                double e = E[vi];
+                const bool outside = !(e > sp_tau);           // the compaction took E > tau
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (t < ncols) {
+                        double* p = comps + (long long)(k0 + t) * comp_stride + v * 3;
+                        p[0] = c[t][0]; p[1] = c[t][1]; p[2] = c[t][2];
+                        if (outside && t >= sp_proven && t < viol && !(ew[t] > e + sp_margin)) viol = t;
+                        e -= (c[t][0] * c[t][0] + c[t][1] * c[t][1] + c[t][2] * c[t][2]) * inv[t];
+                    }
+            }
+            continue;
+        }
         if (valid) {
             double loss = 0.0;
 #pragma unroll
@@ -448,9 +481,69 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
             if (am_better(e, v, bmax, bidx)) { bmax = e; bidx = v; }
         }
     }
+    if (SPEC) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ov = __shfl_xor(viol, o, 64);
+            viol = ov < viol ? ov : viol;
+        }
+        if ((tid & 63) == 0) sh_viol[tid >> 6] = viol;
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < 4; ++q) viol = sh_viol[q] < viol ? sh_viol[q] : viol;
+            if (viol < ASB_PANEL_COLS) atomicMin(reinterpret_cast<long long*>(&spec->spec_ok), (long long)viol);
+        }
+        return;
+    }
     __syncthreads();
     block_sum<16>(csum, sh_d);
     if (tid < 16 && vmap == nullptr) colpart[(long long)blockIdx.x * 16 + tid] = csum[tid];
+    __syncthreads();
+    sh_d[tid] = bmax; sh_d[256 + tid] = bsum; sh_i[tid] = bidx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            sh_d[256 + tid] += sh_d[256 + tid + o];
+            if (am_better(sh_d[tid + o], sh_i[tid + o], sh_d[tid], sh_i[tid])) { sh_d[tid] = sh_d[tid + o]; sh_i[tid] = sh_i[tid + o]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; psum[blockIdx.x] = sh_d[256]; }
+}
+
+// second half of a panel with unproven steps: E -= sum over the columns that survived the check (t < spec_ok), block
+// records for the next selection and the per-column sums -- what k_correct<false> does in one go when nothing is in doubt
+__global__ __launch_bounds__(256) void k_commit_energy(const double* __restrict__ comps, long long comp_stride, long long n_vert,
+                                                       int k0, const PanelState* __restrict__ spec, const double* __restrict__ wn2,
+                                                       double* __restrict__ E, double* __restrict__ pmax,
+                                                       long long* __restrict__ pidx, double* __restrict__ psum,
+                                                       double* __restrict__ colpart) {
+    __shared__ double sh_d[512];
+    __shared__ long long sh_i[256];
+    const int tid = threadIdx.x;
+    const int ncols = (int)(spec->spec_ok < spec->committed ? spec->spec_ok : spec->committed);
+    double bmax = -1.0, bsum = 0.0, csum[16], inv[16];
+    long long bidx = 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { csum[t] = 0.0; inv[t] = wn2[t]; }
+    for (long long v = (long long)blockIdx.x * 256 + tid; v < n_vert; v += (long long)gridDim.x * 256) {
+        double loss = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < ncols) {
+                const double* p = comps + (long long)(k0 + t) * comp_stride + v * 3;
+                const double q = (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) * inv[t];
+                loss += q;
+                csum[t] += q;
+            }
+        double e = E[v] - loss;
+        if (e < 0.0) e = 0.0;
+        E[v] = e;
+        bsum += e;
+        if (am_better(e, v, bmax, bidx)) { bmax = e; bidx = v; }
+    }
+    block_sum<16>(csum, sh_d);
+    if (tid < 16) colpart[(long long)blockIdx.x * 16 + tid] = csum[tid];
     __syncthreads();
     sh_d[tid] = bmax; sh_d[256 + tid] = bsum; sh_i[tid] = bidx;
     __syncthreads();
@@ -866,8 +959,13 @@ __global__ __launch_bounds__(512) void k_project_wide(
 
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 __global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
-                                                double* __restrict__ scal) {
+                                                double* __restrict__ scal, PanelState* __restrict__ spec = nullptr) {
     __shared__ double sh[4];
+    if (spec != nullptr) {              // panel with unproven steps: the columns that survived; the host reads `committed`
+        ncols = (int)(spec->spec_ok < spec->committed ? spec->spec_ok : spec->committed);
+        __syncthreads();
+        if (threadIdx.x == 0) spec->committed = ncols;
+    }
     for (int t = 0; t < ncols; ++t) {
         double v[1] = {0.0};
         for (int b = threadIdx.x; b < nblk; b += blockDim.x) v[0] += colpart[(long long)b * 16 + t];
@@ -912,8 +1010,10 @@ static void launch_gather(asb_ctx* ctx, const StreamCfg& c, int grid, const long
 
 static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
-// one projection pass for components [k0, k0+ncols)
-static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
+// one projection pass for components [k0, k0+ncols); proven < ncols: the steps from `proven` on were taken without
+// proof -- they are checked against every vertex's energy and *kept (optional) returns how many columns survived
+static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_PANEL_COLS, int64_t* kept = nullptr) {
+    const bool spec = proven < ncols;
     const int NC = (int)(ctx->Fp / 16);
     const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
     int grid = ctx->n_cu * ((NC <= 16) ? 2 : 1);     // persistent blocks: 1 per CU (2 for the 256-thread variant)
@@ -928,13 +1028,32 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols) {
     hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(k0 + ncols)), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-    hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                       (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
-                       ctx->psum, ctx->colpart);
+    if (spec) {
+        hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0,
+                           ctx->pstate, ctx->scalar_dev);
+        hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)k0, ctx->pstate, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
+                           ctx->colpart);
+    } else
+        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart);
     ASB_CHECK_LAUNCH(ctx);
     ctx->nblk = cgrid;
-    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal);
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal,
+                       spec ? ctx->pstate : (PanelState*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
+    if (kept) {
+        *kept = ncols;
+        if (spec) {
+            PanelState h;
+            ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *kept = h.committed;
+        }
+    }
     return ASB_OK;
 }
 
@@ -971,14 +1090,14 @@ static int wide_correct_tile(asb_ctx* ctx, int ct, long long kb, int nc, bool ba
     if (band) {
         long long cw = (ctx->band_cap + 255) / 256;
         const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-        hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                            (long long)0, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->band_E, ctx->bpmax, ctx->bpidx, ctx->bpsum,
                            ctx->colpart, ctx->band_idx, ctx->bstate, (long long)ctx->v0);
         hipLaunchKernelGGL(k_band_max, dim3(1), dim3(256), 0, ctx->stream, ctx->bpmax, cgrid, ctx->scalar_dev, ctx->bstate);
     } else {
         long long cw = (ctx->n_loc + 255) / 256;
         const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-        hipLaunchKernelGGL(k_correct, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                            (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
                            ctx->psum, ctx->colpart);
         ctx->nblk = cgrid;
@@ -1639,6 +1758,10 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         return;
     }
     const double thr = panel->theta + panel->margin;
+    // steps beyond the provable ones (only with the complete candidate set): checked after the projection pass
+    const int spec_max = panel->pad ? 0 : (int)panel->spec_max;
+    const double e_floor = panel->margin;
+    int proven = -1, nrun = 0;
     const long long s = (long long)blockIdx.x * 4 + wv;          // this wave's candidate slot
     const bool have = s < n_cand && cand_idx[s] >= 0;
     double x[3][NJ];
@@ -1738,10 +1861,16 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
 #pragma unroll
         for (int q = 1; q < 4; ++q)
             if (am_better(sh_e[q], sh_i[q], be, bi)) { be = sh_e[q]; bi = sh_i[q]; bb = sh_b[q]; }
-        if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max: the panel ends here
-            if (blockIdx.x == 0 && tid == 0) panel->done = 1;
-            break;
+        if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max ...
+            if (proven < 0) proven = t;
+            // ... the panel ends here, unless it may go on unproven: the winner among the candidates is exact, whether
+            // a vertex outside beats it is decided once the projection pass has every vertex's energy
+            if (bi >= n_cand || !(be > e_floor) || t - proven >= spec_max) {
+                if (blockIdx.x == 0 && tid == 0) panel->done = 1;
+                break;
+            }
         }
+        nrun = t + 1;
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 3] = wall_clock64();
         const double wn2 = coop_load(&recs[bb].wn2);
         const double* ww = rec_w + ((size_t)(t & 1) * G + bb) * Fp;
@@ -1755,6 +1884,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
                 scal[k * 4 + 1] = wn2;
                 scal[k * 4 + 2] = __longlong_as_double(cand_idx[bi]);
                 panel->committed = t + 1;
+                panel->e_win[t] = be;
             }
         }
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 4] = wall_clock64();
@@ -1776,6 +1906,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         __syncthreads();              // w_sh and the wave records are rewritten in the next step
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 5] = wall_clock64();
     }
+    if (blockIdx.x == 0 && tid == 0) panel->proven = proven < 0 ? nrun : proven;
     // super-panels run several of these launches on the same candidates: the deflated rows become the next start rows
     if (rows_out != nullptr && have) {
         double* row = rows_out + s * 3 * (long long)Fp;
@@ -1827,7 +1958,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
                        want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all,
-                       ctx->run_theta_band);
+                       ctx->run_theta_band, (long long)(want_coop && !global_all && !assembled ? ctx->run_spec_max : 0));
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     bool coop = false;
     if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
@@ -1860,6 +1991,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *committed = h.committed;
+    ctx->run_proven = (h.proven < 0 || h.proven > h.committed) ? h.committed : h.proven;
     ctx->n_panels++;
     if (coop) {
         unsigned flags[4];
@@ -2059,7 +2191,30 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
         if ((rc = asb_panel_select(ctx, k, forced, forced >= 0 ? 1 : global_all, nullptr, nullptr, nullptr, nullptr))) return rc;
         const int steps = forced >= 0 ? 1 : (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
         int64_t done = 0;
-        if ((rc = asb_panel_run(ctx, k, steps, forced >= 0 ? 1 : global_all, 0, &done))) return rc;
+        // unproven steps only on the plain path: a stalled panel is repeated with provable steps alone
+        ctx->run_spec_max = (ctx->spec_panels && stalled == 0 && forced < 0 && !global_all) ? ctx->spec_budget : 0;
+        rc = asb_panel_run(ctx, k, steps, forced >= 0 ? 1 : global_all, 0, &done);
+        ctx->run_spec_max = 0;
+        if (rc) return rc;
+        if (done > ctx->run_proven) {          // the tail of the panel is unproven: the pass decides how much of it stands
+            const int64_t proven = ctx->run_proven, tried = done - proven;
+            if ((rc = project_pass(ctx, k, (int)done, (int)proven, &done))) return rc;
+            const int64_t gain = done - proven;
+            ctx->n_spec_steps += tried;
+            ctx->n_spec_kept += gain;
+            ctx->spec_budget = (gain == tried) ? (2 * ctx->spec_budget < ASB_PANEL_COLS ? 2 * ctx->spec_budget : ASB_PANEL_COLS)
+                                               : (int)(2 * gain + 2 < ASB_PANEL_COLS ? 2 * gain + 2 : ASB_PANEL_COLS);
+            if (getenv("ASB_DEBUG_PANELS"))
+                fprintf(stderr, "[asb] panel at k=%lld: %lld proven + %lld of %lld unproven steps kept\n", k, (long long)proven,
+                        (long long)gain, (long long)tried);
+            if (done > 0) {
+                stalled = 0;
+                ctx->k_done = k + done;
+                k += done;
+                continue;
+            }
+            // nothing stood (the very first step was already wrong): energies are untouched, fall through to the refresh
+        }
         if (done == 0) {
             // the energy recurrence could not prove any candidate: refresh ALL energies exactly and retry;
             // a second failure (massive exact ties) forces the first arg-max as the only candidate

@@ -235,7 +235,9 @@ class HipEngine(object):
     def deflate_stats(self):
         a, b = ctypes.c_int64(), ctypes.c_int64()
         self._ck(self.lib.asb_deflate_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
-        return dict(panels=a.value, refreshes=b.value)
+        c, d = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_spec_stats(self.h, ctypes.byref(c), ctypes.byref(d)))
+        return dict(panels=a.value, refreshes=b.value, unproven_tried=c.value, unproven_kept=d.value)
 
     def download_residual(self):
         out = np.empty((self.F, self.n_loc, 3))

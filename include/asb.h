@@ -170,6 +170,11 @@ int asb_panel_refresh(asb_ctx* ctx, int64_t k, double* best_energy, int64_t* bes
 /* projection mode statistics of the last run: streaming passes over X (panels) and exact
  * energy refreshes (fallback when the energy recurrence could not prove a candidate). */
 int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_refresh);
+/* panels may append steps whose winner could not be proven in advance (bound on the vertices outside the candidate set
+ * too stale); the projection pass then checks them against every vertex's energy and keeps the valid prefix, so the
+ * selected sequence stays that of the reference loop (posComponents.py:75-77).  tried / kept: such steps in the last
+ * run.  ASB_SPEC_PANELS=0 switches them off. */
+int asb_deflate_spec_stats(asb_ctx* ctx, int64_t* tried, int64_t* kept);
 /* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
 int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 

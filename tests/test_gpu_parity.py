@@ -290,10 +290,44 @@ def test_splocs_weight_sweep_blocks_agree(monkeypatch):
     assert outs[0][0].max() == 1.0 and outs[0][0].min() == 0.0
 
 
-def test_project_mode_stepwise_panel_protocol():
+def test_unproven_panel_steps_keep_the_reference_sequence(monkeypatch):
+    """Panels may append steps whose winner cannot be proven in advance; the projection pass checks them against every
+    vertex's energy and keeps the valid prefix.  On data where the provable panels are short (a common direction in
+    every vertex: uniform noise with rest_shape='first') this must save passes and still give the oracle's sequence;
+    with ASB_SPEC_PANELS=0 the same results come out of more panels."""
+    rng = np.random.default_rng(71)
+    F, N, K = 160, 30000, 40
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = _param(vertPos_numComponents=K)
+    from animsnapbases_amd import posComponents, posSnapshots
+    outs = []
+    for spec in ("1", "0"):
+        monkeypatch.setenv("ASB_SPEC_PANELS", spec)
+        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
+        comp = posComponents(param, snaps)
+        comp.deflate_mode = "project"
+        comp.compute_components_store_singvalues()
+        outs.append((comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(),
+                     comp.measures_at_largeDeforVerts.copy(), snaps._engine.deflate_stats()))
+    pre = orc.prepare_snapshots(verts, "first", True)
+    d = orc.extract_k_components(pre["snapTensor"], K, "global", None, 0.1, 0.4)
+    for o in outs:
+        assert o[0].tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(o[1], o[2], d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-9 and relerr(weigs, d["weigs"]) < 1e-9
+        assert relerr(o[3][:, 1:], d["measures"][:, 1:]) < 1e-8
+    st1, st0 = outs[0][4], outs[1][4]
+    assert st0["unproven_tried"] == 0 and st0["unproven_kept"] == 0
+    assert st1["unproven_kept"] > 0 and st1["panels"] < st0["panels"], (st1, st0)
+    assert relerr(outs[0][1], outs[1][1]) < 1e-11 and relerr(outs[0][2], outs[1][2]) < 1e-11
+
+
+def test_project_mode_stepwise_panel_protocol(monkeypatch):
     """The multi-rank panel protocol (asb_panel_* steps, torch exchange buffers, assemble) driven on
-    ONE GPU must reproduce the fused single-rank run bit for bit."""
+    ONE GPU must reproduce the fused single-rank run bit for bit (the fused run without unproven steps, which the
+    stepwise protocol does not take: the panel boundaries, and with them the rounding, would differ)."""
     import torch
+    monkeypatch.setenv("ASB_SPEC_PANELS", "0")
     rng = np.random.default_rng(33)
     F, N, K = 96, 4000, 20
     verts = rng.uniform(-1, 1, size=(F, N, 3))
