@@ -65,18 +65,32 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
                 const int j = t + i * T;
                 x[d][i] = (valid && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
             }
-        for (int q = 0; q < k0; ++q) {
-            const double* cq = comps + (long long)q * comp_stride + v * 3;
-            const double c0 = cq[0], c1 = cq[1], c2 = cq[2];
-            const double2* wq = reinterpret_cast<const double2*>(W) + (long long)q * F2;
+        for (int q0 = 0; q0 < k0; q0 += 4) {      // four components' loads in flight (same subtraction order as one by one)
+            double cc[4][3];
+            double2 w[4][E2];
 #pragma unroll
-            for (int i = 0; i < E2; ++i) {
-                const int j = t + i * T;
-                const double2 w = (j < F2) ? wq[j] : make_double2(0.0, 0.0);
-                x[0][i].x -= w.x * c0; x[0][i].y -= w.y * c0;
-                x[1][i].x -= w.x * c1; x[1][i].y -= w.y * c1;
-                x[2][i].x -= w.x * c2; x[2][i].y -= w.y * c2;
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u < k0 ? q0 + u : k0 - 1;
+                const double* cq = comps + (long long)q * comp_stride + v * 3;
+                const bool on = q0 + u < k0;
+                cc[u][0] = on ? cq[0] : 0.0; cc[u][1] = on ? cq[1] : 0.0; cc[u][2] = on ? cq[2] : 0.0;
+                const double2* wq = reinterpret_cast<const double2*>(W) + (long long)q * F2;
+#pragma unroll
+                for (int i = 0; i < E2; ++i) {
+                    const int j = t + i * T;
+                    w[u][i] = (on && j < F2) ? wq[j] : make_double2(0.0, 0.0);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + u < k0) {
+#pragma unroll
+                    for (int i = 0; i < E2; ++i) {
+                        x[0][i].x -= w[u][i].x * cc[u][0]; x[0][i].y -= w[u][i].y * cc[u][0];
+                        x[1][i].x -= w[u][i].x * cc[u][1]; x[1][i].y -= w[u][i].y * cc[u][1];
+                        x[2][i].x -= w[u][i].x * cc[u][2]; x[2][i].y -= w[u][i].y * cc[u][2];
+                    }
+                }
         }
         double e = 0.0;
         double2* out = dst ? reinterpret_cast<double2*>(dst) + s * 3 * (long long)F2 : nullptr;
@@ -424,14 +438,23 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
             __syncthreads();
             for (int q = tid; q < jn * 16; q += 256) gs[q] = G[(long long)j0 * 16 + q] / inv[q & 15];
             __syncthreads();
-            for (int j = 0; j < jn; ++j) {
-                const double* p = comps + (long long)(j0 + j) * comp_stride + v * 3;
-                const double a0 = valid ? p[0] : 0.0, a1 = valid ? p[1] : 0.0, a2 = valid ? p[2] : 0.0;
+            for (int j = 0; j < jn; j += 4) {      // four earlier components in flight: the loop is latency-bound otherwise
+                double a[4][3];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const double gq = gs[j * 16 + t];
-                    c[t][0] -= a0 * gq; c[t][1] -= a1 * gq; c[t][2] -= a2 * gq;
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = valid && j + u < jn;
+                    const double* p = comps + (long long)(j0 + j + u) * comp_stride + v * 3;
+                    a[u][0] = on ? p[0] : 0.0; a[u][1] = on ? p[1] : 0.0; a[u][2] = on ? p[2] : 0.0;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j + u < jn) {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const double gq = gs[(j + u) * 16 + t];
+                            c[t][0] -= a[u][0] * gq; c[t][1] -= a[u][1] * gq; c[t][2] -= a[u][2] * gq;
+                        }
+                    }
             }
         }
         // the same correction among the panel's own columns, in order (column t needs the corrected columns j < t):
@@ -958,21 +981,20 @@ __global__ __launch_bounds__(512) void k_project_wide(
 }
 
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
-__global__ __launch_bounds__(256) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
-                                                double* __restrict__ scal, PanelState* __restrict__ spec = nullptr) {
-    __shared__ double sh[4];
+// scal[(k0 + t) * 4 + 3] = sum over the blocks' partial column sums; one wave per column (launch with 1024 threads)
+__global__ __launch_bounds__(1024) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
+                                                 double* __restrict__ scal, PanelState* __restrict__ spec = nullptr) {
     if (spec != nullptr) {              // panel with unproven steps: the columns that survived; the host reads `committed`
         ncols = (int)(spec->spec_ok < spec->committed ? spec->spec_ok : spec->committed);
         __syncthreads();
         if (threadIdx.x == 0) spec->committed = ncols;
     }
-    for (int t = 0; t < ncols; ++t) {
-        double v[1] = {0.0};
-        for (int b = threadIdx.x; b < nblk; b += blockDim.x) v[0] += colpart[(long long)b * 16 + t];
-        block_sum<1>(v, sh);
-        if (threadIdx.x == 0) scal[(k0 + t) * 4 + 3] = v[0];
-        __syncthreads();
-    }
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (t >= ncols) return;
+    double v = 0.0;
+    for (int b = lane; b < nblk; b += 64) v += colpart[(long long)b * 16 + t];
+    v = wave_sum(v);
+    if (lane == 0) scal[(k0 + t) * 4 + 3] = v;
 }
 
 // --------------------------------------------------------------------------------------
@@ -1042,7 +1064,7 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
                            ctx->psum, ctx->colpart);
     ASB_CHECK_LAUNCH(ctx);
     ctx->nblk = cgrid;
-    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal,
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal,
                        spec ? ctx->pstate : (PanelState*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
     if (kept) {
@@ -1101,7 +1123,7 @@ static int wide_correct_tile(asb_ctx* ctx, int ct, long long kb, int nc, bool ba
                            (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
                            ctx->psum, ctx->colpart);
         ctx->nblk = cgrid;
-        hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, ctx->stream, ctx->colpart, ctx->nblk, nc, kb, ctx->scal);
+        hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, nc, kb, ctx->scal);
     }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
