@@ -57,6 +57,9 @@ PROTOTYPES = {
     "asb_panel_assemble": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_int, c_i64]),
     "asb_panel_run": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "asb_panel_project": (c_int, [ctypes.c_void_p, c_i64, c_int]),
+    "asb_panel_run_spec": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "asb_panel_project_spec": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
+    "asb_panel_commit": (c_int, [ctypes.c_void_p, c_i64, c_int]),
     "asb_panel_refresh": (c_int, [ctypes.c_void_p, c_i64, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_spec_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -13,7 +13,12 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
          rows and of vertex ids replicates the ~768 candidate rows on every rank;
       3. every rank runs the identical greedy steps on them (no per-component collective), then projects its shard.
     Three collectives and two host synchronisations per panel.  Ranks stay in lock-step because every decision is
-    a function of all-gathered data."""
+    a function of all-gathered data.
+    Unproven steps (ASB_SPEC_PANELS, default on): when the bound on the vertices outside the candidate set is too stale
+    to prove a winner, the panel goes on with the exact winner among the candidates (identical on every rank); the
+    pass over X then checks those steps against every vertex's energy, each rank on its shard, and one extra tiny
+    all-reduce (min) fixes how many of them stand -- fewer, longer panels for one more collective on such panels."""
+    import os
     dev = comm.exchange_device(eng.device_exchange)
     torch = comm._torch
     cap, rl = eng.panel_capacity(), eng.panel_row_len()
@@ -25,6 +30,7 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     top_loc = torch.empty(cap + 1, dtype=torch.float64, device=dev)
     top_all = torch.empty(comm.world * (cap + 1), dtype=torch.float64, device=dev)
     global_all = n_rows <= cap
+    spec_budget = 16 if (hasattr(eng, "panel_run_spec") and os.environ.get("ASB_SPEC_PANELS", "1") != "0") else 0
     k, stalled, forced_next = 0, 0, -1
     while k < K:
         forced = forced_next if stalled >= 2 else -1
@@ -59,7 +65,21 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             comm.all_gather_into(idx_g, idx_loc[:maxc])
             eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
             steps = 1 if forced >= 0 else min(16, K - k)
-            done = eng.panel_run(k, steps, take_all)
+            if spec_budget and not take_all and stalled == 0:
+                done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)
+            else:
+                done = proven = eng.panel_run(k, steps, take_all)
+            if done > proven:                             # the tail is unproven: the pass decides how much of it stands
+                tried = done - proven
+                mine = eng.panel_project_spec(k, done, proven)
+                done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
+                eng.panel_commit(k, done)
+                gain = done - proven
+                spec_budget = min(16, 2 * spec_budget) if gain == tried else min(16, 2 * gain + 2)
+                if done > 0:
+                    stalled = 0
+                    k += done
+                    continue
         if done == 0:
             # nothing provable (stale bound / exact ties): exact energies everywhere, retry; a second
             # failure forces the global first arg-max as the only candidate

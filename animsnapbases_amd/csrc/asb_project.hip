@@ -540,11 +540,12 @@ __global__ __launch_bounds__(256) void k_commit_energy(const double* __restrict_
                                                        int k0, const PanelState* __restrict__ spec, const double* __restrict__ wn2,
                                                        double* __restrict__ E, double* __restrict__ pmax,
                                                        long long* __restrict__ pidx, double* __restrict__ psum,
-                                                       double* __restrict__ colpart) {
+                                                       double* __restrict__ colpart, int force_ncols) {
     __shared__ double sh_d[512];
     __shared__ long long sh_i[256];
     const int tid = threadIdx.x;
-    const int ncols = (int)(spec->spec_ok < spec->committed ? spec->spec_ok : spec->committed);
+    // multi-rank: the host passes the minimum over the ranks
+    const int ncols = force_ncols >= 0 ? force_ncols : (int)(spec->spec_ok < spec->committed ? spec->spec_ok : spec->committed);
     double bmax = -1.0, bsum = 0.0, csum[16], inv[16];
     long long bidx = 0x7fffffffffffffffLL;
 #pragma unroll
@@ -1034,7 +1035,33 @@ static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
 // one projection pass for components [k0, k0+ncols); proven < ncols: the steps from `proven` on were taken without
 // proof -- they are checked against every vertex's energy and *kept (optional) returns how many columns survived
-static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_PANEL_COLS, int64_t* kept = nullptr) {
+// second half of a pass with unproven steps: energies of the columns that stood (force_ncols < 0: the count the check
+// left on the device; otherwise the host's value, e.g. the minimum over the ranks), column sums, *kept
+static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* kept) {
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)k0, ctx->pstate, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
+                       ctx->colpart, force_ncols);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->nblk = cgrid;
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, force_ncols, k0, ctx->scal,
+                       force_ncols < 0 ? ctx->pstate : (PanelState*)nullptr);
+    ASB_CHECK_LAUNCH(ctx);
+    if (kept) {
+        *kept = force_ncols;
+        if (force_ncols < 0) {
+            PanelState h;
+            ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *kept = h.committed;
+        }
+    }
+    return ASB_OK;
+}
+
+static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_PANEL_COLS, int64_t* kept = nullptr,
+                        bool check_only = false) {
     const bool spec = proven < ncols;
     const int NC = (int)(ctx->Fp / 16);
     const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
@@ -1055,27 +1082,19 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
                            (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
                            ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0,
                            ctx->pstate, ctx->scalar_dev);
-        hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                           (long long)ctx->n_loc, (int)k0, ctx->pstate, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
-                           ctx->colpart);
-    } else
-        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
-                           ctx->psum, ctx->colpart);
+        ASB_CHECK_LAUNCH(ctx);
+        if (check_only) return ASB_OK;
+        return project_commit(ctx, k0, -1, kept);
+    }
+    hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                       ctx->psum, ctx->colpart);
     ASB_CHECK_LAUNCH(ctx);
     ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal,
-                       spec ? ctx->pstate : (PanelState*)nullptr);
+                       (PanelState*)nullptr);
     ASB_CHECK_LAUNCH(ctx);
-    if (kept) {
-        *kept = ncols;
-        if (spec) {
-            PanelState h;
-            ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-            ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            *kept = h.committed;
-        }
-    }
+    if (kept) *kept = ncols;
     return ASB_OK;
 }
 
@@ -1980,7 +1999,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
                        want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all,
-                       ctx->run_theta_band, (long long)(want_coop && !global_all && !assembled ? ctx->run_spec_max : 0));
+                       ctx->run_theta_band, (long long)(want_coop && !global_all ? ctx->run_spec_max : 0));
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     bool coop = false;
     if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
@@ -2059,6 +2078,45 @@ extern "C" int asb_panel_project(asb_ctx* ctx, int64_t k0, int ncols) {
     int rc = project_pass(ctx, k0, ncols);
     if (rc) return rc;
     ctx->k_done = k0 + ncols;
+    return ASB_OK;
+}
+
+// ---- the same with unproven steps, split for several ranks: every rank checks the steps against ITS vertices, the host
+// takes the minimum over the ranks and hands it to asb_panel_commit
+extern "C" int asb_panel_run_spec(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int spec_max, int64_t* ran,
+                                  int64_t* proven) {
+    if (!ctx || !ran || !proven || spec_max < 0) return ASB_ERR_ARG;
+    ctx->run_spec_max = ctx->spec_panels ? spec_max : 0;
+    const int rc = asb_panel_run(ctx, k0, steps, global_all, assembled, ran);
+    ctx->run_spec_max = 0;
+    if (rc) return rc;
+    *proven = ctx->run_proven;
+    return ASB_OK;
+}
+// pass over X for all `ncols` steps of the panel (the first `proven` of them certain), coefficients written, energies
+// NOT yet updated; *first_rejected = first unproven step one of this shard's vertices contradicts (ncols: none)
+extern "C" int asb_panel_project_spec(asb_ctx* ctx, int64_t k0, int ncols, int proven, int64_t* first_rejected) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !first_rejected) return ASB_ERR_ARG;
+    if (ncols < 1 || ncols > ASB_PANEL_COLS || k0 < 0 || k0 + ncols > ctx->K || proven < 0 || proven >= ncols)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_project_spec: bad range");
+    int rc = project_pass(ctx, k0, ncols, proven, nullptr, true);
+    if (rc) return rc;
+    ctx->n_spec_steps += ncols - proven;
+    ctx->run_proven = proven;
+    PanelState h;
+    ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *first_rejected = h.spec_ok < ncols ? h.spec_ok : ncols;
+    return ASB_OK;
+}
+// energies / column sums of the first `kept` columns of that pass (0: nothing stood, the energies stay as they were)
+extern "C" int asb_panel_commit(asb_ctx* ctx, int64_t k0, int kept) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
+    if (kept < 0 || kept > ASB_PANEL_COLS || k0 < 0 || k0 + kept > ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_commit: bad range");
+    int rc = project_commit(ctx, k0, kept, nullptr);
+    if (rc) return rc;
+    if (kept > 0) ctx->k_done = k0 + kept;
+    if (kept > ctx->run_proven) ctx->n_spec_kept += kept - ctx->run_proven;
     return ASB_OK;
 }
 

@@ -227,6 +227,22 @@ class HipEngine(object):
     def panel_project(self, k0, ncols):
         self._ck(self.lib.asb_panel_project(self.h, int(k0), int(ncols)))
 
+    def panel_run_spec(self, k0, steps, global_all, spec_max):
+        """panel_run that may append up to ``spec_max`` unproven steps: (steps run, provable head)."""
+        ran, proven = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.asb_panel_run_spec(self.h, int(k0), int(steps), int(bool(global_all)), 1, int(spec_max),
+                                             ctypes.byref(ran), ctypes.byref(proven)))
+        return ran.value, proven.value
+
+    def panel_project_spec(self, k0, ncols, proven):
+        """Pass over X for all ``ncols`` steps, energies untouched; first unproven step this shard rejects (ncols: none)."""
+        r = ctypes.c_int64()
+        self._ck(self.lib.asb_panel_project_spec(self.h, int(k0), int(ncols), int(proven), ctypes.byref(r)))
+        return r.value
+
+    def panel_commit(self, k0, kept):
+        self._ck(self.lib.asb_panel_commit(self.h, int(k0), int(kept)))
+
     def panel_refresh(self, k):
         e, g = ctypes.c_double(), ctypes.c_int64()
         self._ck(self.lib.asb_panel_refresh(self.h, int(k), ctypes.byref(e), ctypes.byref(g)))

@@ -164,6 +164,15 @@ int asb_panel_assemble(asb_ctx* ctx, const double* rows_g_dev, const long long* 
 int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int64_t* committed);
 /* one pass over X for components [k0, k0+ncols): c_k on this shard, energies */
 int asb_panel_project(asb_ctx* ctx, int64_t k0, int ncols);
+/* Multi-rank form of the unproven steps (asb_deflate_spec_stats): asb_panel_run_spec lets the panel kernel append up to
+ * spec_max steps whose winner is not provable in advance (*ran steps in all, the first *proven of them certain; identical
+ * on every rank).  asb_panel_project_spec is the pass over X for all of them with the energies left untouched;
+ * *first_rejected = first unproven step that one of THIS shard's vertices contradicts (ncols: none).  The caller takes
+ * the minimum over the ranks and asb_panel_commit applies the energies of that many columns (0: nothing stood). */
+int asb_panel_run_spec(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int spec_max, int64_t* ran,
+                       int64_t* proven);
+int asb_panel_project_spec(asb_ctx* ctx, int64_t k0, int ncols, int proven, int64_t* first_rejected);
+int asb_panel_commit(asb_ctx* ctx, int64_t k0, int kept);
 /* fallback: exact energies of every vertex of the shard; optional first arg-max */
 int asb_panel_refresh(asb_ctx* ctx, int64_t k, double* best_energy, int64_t* best_gidx);
 

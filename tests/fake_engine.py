@@ -267,17 +267,26 @@ class FakeEngine(object):
         self.candR = np.concatenate([rows[r, :counts[r]] for r in range(world)], axis=0).copy()
         self.cand_idx = np.concatenate([ids[r, :counts[r]] for r in range(world)]).copy()
 
-    def panel_run(self, k0, steps, global_all=False):
+    def panel_run_spec(self, k0, steps, global_all, spec_max):
+        done = self.panel_run(k0, steps, global_all, spec_max)
+        return done, self.proven
+
+    def panel_run(self, k0, steps, global_all=False, spec_max=0):
         theta = -np.inf if global_all else self.tau
         margin = 1e-11 * self.e0max
         done = 0
         self.n_panels += 1
+        self.proven, self.e_win = -1, []
         for t in range(steps):
             k = k0 + t
             e = (self.candR ** 2).sum(axis=(1, 2))
             b = int(np.argmax(e))
             if not e[b] > theta + margin:
-                break
+                if self.proven < 0:
+                    self.proven = t
+                if not e[b] > margin or t - self.proven >= spec_max:
+                    break
+            self.e_win.append(e[b])
             slab = self.candR[b]
             lam, U = np.linalg.eigh(slab @ slab.T)
             u = U[:, -1]
@@ -288,7 +297,38 @@ class FakeEngine(object):
             c = self.candR @ w / self.wn2[k]                 # (m, 3)
             self.candR -= c[:, :, None] * w[None, None, :]
             done += 1
+        if self.proven < 0:
+            self.proven = done
         return done
+
+    def panel_project_spec(self, k0, ncols, proven):
+        """Coefficients of all ncols columns; energies untouched.  First unproven step a vertex outside the candidate
+        set (E <= tau) would have won or tied within the margin."""
+        margin = 1e-11 * self.e0max
+        outside = ~(self.E > self.tau)
+        e = self.E.copy()
+        self._spec_loss = []
+        first = ncols
+        self.n_spec_tried = getattr(self, "n_spec_tried", 0) + ncols - proven
+        self._spec_proven = proven
+        for t in range(ncols):
+            k = k0 + t
+            y = np.tensordot(self.W[k], self.X, (0, 0))
+            for j in range(k):
+                y -= self.C[j] * (self.W[j] @ self.W[k])
+            self.C[k] = y / self.wn2[k]
+            if t >= proven and first == ncols and outside.any() and not (self.e_win[t] > e[outside].max() + margin):
+                first = t
+            loss = (self.C[k] ** 2).sum(axis=1) * self.wn2[k]
+            self._spec_loss.append(loss)
+            e = e - loss
+        return first
+
+    def panel_commit(self, k0, kept):
+        self.n_spec_kept = getattr(self, "n_spec_kept", 0) + max(0, kept - self._spec_proven)
+        for t in range(kept):
+            self.E = np.maximum(self.E - self._spec_loss[t], 0.0)
+            self.colsum[k0 + t] = self._spec_loss[t].sum()
 
     def panel_project(self, k0, ncols):
         for t in range(ncols):
@@ -309,4 +349,5 @@ class FakeEngine(object):
         return float(self.E[b]), int(self.v0 + b)
 
     def deflate_stats_project(self):
-        return dict(panels=self.n_panels, refreshes=self.n_refresh)
+        return dict(panels=self.n_panels, refreshes=self.n_refresh, unproven_tried=getattr(self, "n_spec_tried", 0),
+                    unproven_kept=getattr(self, "n_spec_kept", 0))

@@ -300,12 +300,15 @@ def test_unproven_panel_steps_keep_the_reference_sequence(monkeypatch):
     verts = rng.uniform(-1, 1, size=(F, N, 3))
     param = _param(vertPos_numComponents=K)
     from animsnapbases_amd import posComponents, posSnapshots
+    from animsnapbases_amd import HipEngine
     outs = []
-    for spec in ("1", "0"):
+    for spec, stepwise in (("1", False), ("0", False), ("1", True)):      # third: the multi-rank protocol's form of it
         monkeypatch.setenv("ASB_SPEC_PANELS", spec)
-        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
+        eng = HipEngine(0, stream=0) if stepwise else None
+        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False, engine=eng)
         comp = posComponents(param, snaps)
         comp.deflate_mode = "project"
+        comp._stepwise_panels = stepwise
         comp.compute_components_store_singvalues()
         outs.append((comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(),
                      comp.measures_at_largeDeforVerts.copy(), snaps._engine.deflate_stats()))
@@ -316,10 +319,12 @@ def test_unproven_panel_steps_keep_the_reference_sequence(monkeypatch):
         comps, weigs = align_signs(o[1], o[2], d["comps"])
         assert relerr(comps, d["comps"]) < 1e-9 and relerr(weigs, d["weigs"]) < 1e-9
         assert relerr(o[3][:, 1:], d["measures"][:, 1:]) < 1e-8
-    st1, st0 = outs[0][4], outs[1][4]
+    st1, st0, st2 = outs[0][4], outs[1][4], outs[2][4]
     assert st0["unproven_tried"] == 0 and st0["unproven_kept"] == 0
     assert st1["unproven_kept"] > 0 and st1["panels"] < st0["panels"], (st1, st0)
+    assert st2["unproven_kept"] > 0 and st2["panels"] < st0["panels"], (st2, st0)
     assert relerr(outs[0][1], outs[1][1]) < 1e-11 and relerr(outs[0][2], outs[1][2]) < 1e-11
+    assert relerr(outs[2][1], outs[1][1]) < 1e-11 and relerr(outs[2][2], outs[1][2]) < 1e-11
 
 
 def test_project_mode_stepwise_panel_protocol(monkeypatch):

@@ -56,6 +56,8 @@ def _worker(rank, world, port, support, tmpdir, mode=None, device_select=True):
         if mode == "project":
             st = snaps._engine.deflate_stats_project()
             assert st["panels"] >= 2, st           # several panels really happened (tiny candidate capacity)
+            # ... and some of them went on with unproven steps that the all-reduced check then kept or cut
+            assert st["unproven_tried"] > 0 and 0 <= st["unproven_kept"] <= st["unproven_tried"], st
         assert snaps._engine.n_loc == comm.my_shard(65)[1] and sum(n for _, n in comm.shards(65)) == 65
         pre = orc.prepare_snapshots(verts, "first", True)
         assert abs(snaps.pre_scale_factor - pre["pre_scale_factor"]) < 1e-12 * pre["pre_scale_factor"]
@@ -97,3 +99,44 @@ def test_two_rank_gloo_projection_mode(tmp_path, device_select):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(2, port, "global", str(tmp_path), "project", device_select), nprocs=2, join=True)
+
+
+def test_unproven_steps_protocol_keeps_the_sequence(monkeypatch, tmp_path):
+    """The panel driver's unproven steps (run_spec -> project_spec -> min over ranks -> commit) on the CPU test double, one
+    process: uniform noise with rest_shape='first' makes the provable panels short; the checked extra steps must save
+    panels and leave the oracle's vertex sequence untouched."""
+    import contextlib
+    import io
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from animsnapbases_amd import Comm, posComponents, posSnapshots
+    from fake_engine import FakeEngine
+    from oracle import asb_oracle as orc
+    from conftest import align_signs, relerr
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(5)
+    F, N, K = 48, 1500, 24
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = types.SimpleNamespace(vertPos_bases_type="PCA", vertPos_numComponents=K, q_support="global",
+                                  store_vertPos_PCA_sing_val=False, vertPos_smooth_min_dist=0.1,
+                                  vertPos_smooth_max_dist=0.35, q_standarize=True, q_massWeight=False,
+                                  q_orthogonal=False, vertPos_output_directory=".", name="spec")
+    pre = orc.prepare_snapshots(verts, "first", True)
+    d = orc.extract_k_components(pre["snapTensor"], K, "global", None, 0.1, 0.4)
+    stats = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("ASB_SPEC_PANELS", spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False, engine=FakeEngine(),
+                                             comm=Comm(force_single=True))
+            comp = posComponents(param, snaps)
+            comp.deflate_mode = "project"
+            comp._stepwise_panels = True
+            comp.compute_components_store_singvalues()
+        assert comp.selected_vertices.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comp.comps, comp.weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-9 and relerr(weigs, d["weigs"]) < 1e-9
+        stats[spec] = snaps._engine.deflate_stats_project()
+    assert stats["0"]["unproven_tried"] == 0
+    assert stats["1"]["unproven_kept"] > 0 and stats["1"]["panels"] < stats["0"]["panels"], stats
