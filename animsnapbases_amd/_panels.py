@@ -70,12 +70,13 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             else:
                 done = proven = eng.panel_run(k, steps, take_all)
             if done > proven:                             # the tail is unproven: the pass decides how much of it stands
-                tried = done - proven
                 mine = eng.panel_project_spec(k, done, proven)
                 done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
                 eng.panel_commit(k, done)
                 gain = done - proven
-                spec_budget = min(16, 2 * spec_budget) if gain == tried else min(16, 2 * gain + 2)
+                # a kept step saves 1/16 of a panel, a rejected one costs one step of the panel kernel: back off only
+                # after complete failures
+                spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
                 if done > 0:
                     stalled = 0
                     k += done
