@@ -891,6 +891,112 @@ __global__ __launch_bounds__(512) void k_project_l2(
     }
 }
 
+// k_project_l2s: the same product with S waves sharing one row tile (each takes every S-th group of G frame chunks and
+// the partial accumulators are summed through LDS in a fixed order).  A wave's pass over its tile is a chain of dependent
+// load -> MFMA groups, i.e. latency-bound (~60 groups x the HBM latency for F = 2000): with one wave per tile the queue
+// drains for that long at the end of every launch with fewer and fewer loads in flight; S waves per tile cut that tail
+// S times while the bytes in flight per CU stay the same.  The quad also reads S * G * 128 B contiguous bytes of a row at
+// a time instead of G * 128.
+template <int NT, int G, int S, int NQ>
+__global__ __launch_bounds__(64 * S * NQ) void k_project_l2s(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    int ncols, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
+    // NQ tiles in flight per block (NQ * S waves): NQ = 1 keeps the barriers inside the group of waves that shares a tile
+    __shared__ double red[NQ][S - 1][NT][4][64];
+    __shared__ unsigned int tile_sh[NQ];
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4, w = threadIdx.x >> 6, quad = w / S, sub = w % S;
+    constexpr int TR = 16 * NT;
+    const long long ntiles = (rows + TR - 1) / TR;
+    const int nchunk = Fp / 16;
+    const double4* wq = reinterpret_cast<const double4*>(Wq) + (g * 16 + i);      // chunk c: wq[64 * c]
+    for (;;) {
+        if (sub == 0 && l == 0) tile_sh[quad] = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int t = tile_sh[quad];
+        const bool live = (long long)t < ntiles;
+        if (!__syncthreads_or(live)) break;                     // tile ids only grow: every group of waves is past the end
+        d4 acc[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (live) {
+            const double4* xp[NT];                              // chunk c: xp[m][4 * c]
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                long long r = (long long)t * TR + 16 * m + i;
+                if (r >= rows) r = rows - 1;
+                xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+            }
+            double4 a[NT][G], bq[G], an[NT][G], bn[G];
+            int gi = sub;                                       // group gi = chunks gi * G .. gi * G + G - 1
+            if (gi * G < nchunk) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int c = gi * G + q < nchunk ? gi * G + q : nchunk - 1;
+                    bq[q] = wq[64 * c];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) a[m][q] = xp[m][4 * c];
+                }
+            }
+            while (gi * G < nchunk) {
+                const int gn = gi + S;
+                if (gn * G < nchunk) {                          // the next group's operands fly while this one's MFMAs issue
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        const int c = gn * G + q < nchunk ? gn * G + q : nchunk - 1;
+                        bn[q] = wq[64 * c];
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) an[m][q] = xp[m][4 * c];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (gi * G + q < nchunk) {
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].x, bq[q].x, acc[m], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].y, bq[q].y, acc[m], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].z, bq[q].z, acc[m], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].w, bq[q].w, acc[m], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    bq[q] = bn[q];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
+                }
+                gi = gn;
+            }
+            if (sub > 0) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[quad][sub - 1][m][q][l] = acc[m][q];
+            }
+        }
+        __syncthreads();
+        if (live && sub == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < S - 1; ++s2)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[m][q] += red[quad][s2][m][q][l];
+            if (i < ncols) {
+                const double inv = wn2[i];
+                double* dst = comps + (long long)i * comp_stride + (long long)t * TR + g;
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((long long)t * TR + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = acc[m][q] / inv;
+            }
+        }
+        // the next iteration's first barrier (tile ids) also orders these reads of `red` before its next writes
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // k_project_wide: the same product for NCT column tiles in ONE read of X (super-panels: up to 3 sub-panels of <= 16
 // committed components each).  Wq / wn2 hold the tiles back to back (tile ct at Wq + ct * Fp * 16, wn2 + 16 ct); tile
@@ -1227,7 +1333,7 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq, ctx->tile_counter);
     const int variant = ctx->l2_variant;
-    const int NT = variant == 0 ? 2 : (variant == 1 ? 3 : 4);
+    const int NT = (variant == 0 || variant == 8) ? 2 : ((variant == 1 || variant == 9) ? 3 : 4);      // 3, 4, 5: k_project_l2s<4, 2, S> with S = 2, 4, 8 waves per tile
     const long long ntiles = (rows + 16 * NT - 1) / (16 * NT);
     long long wantb = (ntiles + 7) / 8;
     const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
@@ -1238,6 +1344,33 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else if (variant == 1)
         hipLaunchKernelGGL((k_project_l2<3, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 3)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 4>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 4)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 5)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 4, 1>), dim3(2 * ctx->n_cu), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 6)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 2>), dim3(2 * ctx->n_cu), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 8)
+        hipLaunchKernelGGL((k_project_l2s<2, 4, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 9)
+        hipLaunchKernelGGL((k_project_l2s<3, 2, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 10)
+        hipLaunchKernelGGL((k_project_l2s<4, 3, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 11)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 3, 1>), dim3(2 * ctx->n_cu), dim3(192), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 7)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 8, 1>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else
         hipLaunchKernelGGL((k_project_l2<4, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,

@@ -163,10 +163,10 @@ def main():
         traffic = None
         pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")))["kernels"]
-            kname = {2: "k_project_lds", 3: "k_project_l2<4, 2>"}.get(pk)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))["kernels"]
+            kname = {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
             if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1) and \
-                    os.environ.get("ASB_SUPER_PANELS", "0") != "1":
+                    os.environ.get("ASB_SUPER_PANELS", "0") != "1" and os.environ.get("ASB_L2_VARIANT", "4") == "4":
                 traffic = pm[kname]["hbm_bytes"]
         except Exception:
             traffic = None
@@ -187,7 +187,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": (("k_project_wide<NT,G,1..3> (super-panels: up to 48 columns per read of X)"
                                      if os.environ.get("ASB_SUPER_PANELS", "0") == "1" and mode == "project" else
-                                     {2: "k_project_lds", 3: "k_project_l2<4,2>"}.get(pk, "k_project_mfma")) +
+                                     {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma")) +
                                     " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
