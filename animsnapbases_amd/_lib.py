@@ -55,6 +55,7 @@ PROTOTYPES = {
                                  ctypes.POINTER(c_int)]),
     "asb_panel_capacity": (c_i64, [ctypes.c_void_p]),
     "asb_panel_assemble": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_int, c_i64]),
+    "asb_panel_assemble_packed": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_int, c_i64]),
     "asb_panel_run": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "asb_panel_project": (c_int, [ctypes.c_void_p, c_i64, c_int]),
     "asb_panel_run_spec": (c_int, [ctypes.c_void_p, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -12,8 +12,8 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
       2. each rank rebuilds the exact residual rows of its own candidates (energy > tau); a padded all-gather of
          rows and of vertex ids replicates the ~768 candidate rows on every rank;
       3. every rank runs the identical greedy steps on them (no per-component collective), then projects its shard.
-    Three collectives and two host synchronisations per panel.  Ranks stay in lock-step because every decision is
-    a function of all-gathered data.
+    Two collectives (energies; rows with their vertex ids packed behind them) and two host synchronisations per panel.
+    Ranks stay in lock-step because every decision is a function of all-gathered data.
     Unproven steps (ASB_SPEC_PANELS, default on): when the bound on the vertices outside the candidate set is too stale
     to prove a winner, the panel goes on with the exact winner among the candidates (identical on every rank); the
     pass over X then checks those steps against every vertex's energy, each rank on its shard, and one extra tiny
@@ -25,8 +25,9 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     m_target = eng.panel_target()
     _, e0 = eng.panel_scale()
     eng.panel_scale(set_e0max=float(comm.allreduce_max(e0)[0]))
-    rows_loc = torch.zeros(cap * rl, dtype=torch.float64, device=dev)
+    rows_loc = torch.zeros(cap * (rl + 1), dtype=torch.float64, device=dev)      # rows, then (packed exchange) the ids
     idx_loc = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    packed_ok = hasattr(eng, "panel_assemble_packed")
     top_loc = torch.empty(cap + 1, dtype=torch.float64, device=dev)
     top_all = torch.empty(comm.world * (cap + 1), dtype=torch.float64, device=dev)
     global_all = n_rows <= cap
@@ -49,9 +50,15 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                 tau = torch.maximum(kth, tab[:, cap].max()).reshape(1).contiguous()
                 eng.panel_set_tau(tau.data_ptr())
                 counts = (tab[:, :cap] > tau).sum(dim=1).cpu().numpy().astype(np.int64)
-            eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), -1, False, want_counts=False)
+            packed = packed_ok and 0 < int(counts.sum()) <= cap
+            if packed:      # the ids go right behind this rank's maxc rows: rows and ids travel in ONE all-gather
+                maxc = int(counts.max())
+                eng.panel_select(k, rows_loc.data_ptr(), rows_loc.data_ptr() + 8 * maxc * rl, -1, False, want_counts=False)
+            else:
+                eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), -1, False, want_counts=False)
             overflow = False
         else:
+            packed = False
             n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), forced, True)
             info = comm.all_gather_ints([n_c, int(ov)])
             counts, overflow = info[:, 0].copy(), bool(info[:, 1].any())
@@ -59,11 +66,17 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
         done = 0
         if not overflow and 0 < total <= cap:
             maxc = int(counts.max())
-            rows_g = torch.empty(comm.world * maxc * rl, dtype=torch.float64, device=dev)
-            idx_g = torch.empty(comm.world * maxc, dtype=torch.int64, device=dev)
-            comm.all_gather_into(rows_g, rows_loc[:maxc * rl])
-            comm.all_gather_into(idx_g, idx_loc[:maxc])
-            eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
+            if packed:
+                piece = maxc * (rl + 1)
+                buf_g = torch.empty(comm.world * piece, dtype=torch.float64, device=dev)
+                comm.all_gather_into(buf_g, rows_loc[:piece])
+                eng.panel_assemble_packed(buf_g.data_ptr(), counts, maxc)
+            else:
+                rows_g = torch.empty(comm.world * maxc * rl, dtype=torch.float64, device=dev)
+                idx_g = torch.empty(comm.world * maxc, dtype=torch.int64, device=dev)
+                comm.all_gather_into(rows_g, rows_loc[:maxc * rl])
+                comm.all_gather_into(idx_g, idx_loc[:maxc])
+                eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
             steps = 1 if forced >= 0 else min(16, K - k)
             if spec_budget and not take_all and stalled == 0:
                 done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)

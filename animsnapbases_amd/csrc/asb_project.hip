@@ -1773,22 +1773,40 @@ extern "C" int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, in
 // per-rank pieces: rows_g (world, maxcount, 3, Fp), idx_g (world, maxcount), counts (world).
 struct RankCounts { long long c[16]; };
 // one block per candidate slot: slot -> (rank, position in that rank's padded piece) -> copy the row and its vertex id
+// (stride_rows / stride_idx: distance between two ranks' pieces in 8-byte words)
 __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ rows_g, const long long* __restrict__ idx_g, RankCounts cnt,
-                                                  int world, long long maxcount, long long row_len, double* __restrict__ candR,
-                                                  long long* __restrict__ cand_idx, long long total) {
+                                                  int world, long long stride_rows, long long stride_idx, long long row_len,
+                                                  double* __restrict__ candR, long long* __restrict__ cand_idx, long long total) {
     for (long long s = blockIdx.x; s < total; s += gridDim.x) {
         long long off = s;
         int r = 0;
         while (r < world - 1 && off >= cnt.c[r]) { off -= cnt.c[r]; ++r; }
-        const double2* src = reinterpret_cast<const double2*>(rows_g + ((long long)r * maxcount + off) * row_len);
+        const double2* src = reinterpret_cast<const double2*>(rows_g + (long long)r * stride_rows + off * row_len);
         double2* dst = reinterpret_cast<double2*>(candR + s * row_len);
         for (long long j = threadIdx.x; j < row_len / 2; j += 256) dst[j] = src[j];
-        if (threadIdx.x == 0) cand_idx[s] = idx_g[(long long)r * maxcount + off];
+        if (threadIdx.x == 0) cand_idx[s] = idx_g[(long long)r * stride_idx + off];
     }
 }
 
+static int panel_assemble(asb_ctx* ctx, const double* rows_g, const long long* idx_g, const int64_t* counts, int world,
+                          int64_t maxcount, long long stride_rows, long long stride_idx);
+
 extern "C" int asb_panel_assemble(asb_ctx* ctx, const double* rows_g, const long long* idx_g, const int64_t* counts,
                                   int world, int64_t maxcount) {
+    if (!ctx) return ASB_ERR_ARG;
+    return panel_assemble(ctx, rows_g, idx_g, counts, world, maxcount, (long long)maxcount * 3 * ctx->Fp, (long long)maxcount);
+}
+// the same from ONE all-gathered buffer: every rank's piece is its maxcount rows (3*Fp doubles each) followed by its
+// maxcount vertex ids (int64), i.e. maxcount * (3*Fp + 1) eight-byte words per rank
+extern "C" int asb_panel_assemble_packed(asb_ctx* ctx, const double* packed_g, const int64_t* counts, int world, int64_t maxcount) {
+    if (!ctx || !packed_g || maxcount < 0) return ASB_ERR_ARG;
+    const long long rl = 3 * ctx->Fp, stride = (long long)maxcount * (rl + 1);
+    return panel_assemble(ctx, packed_g, reinterpret_cast<const long long*>(packed_g + (long long)maxcount * rl), counts, world, maxcount,
+                          stride, stride);
+}
+
+static int panel_assemble(asb_ctx* ctx, const double* rows_g, const long long* idx_g, const int64_t* counts, int world,
+                          int64_t maxcount, long long stride_rows, long long stride_idx) {
     if (!ctx || !ctx->candR || !rows_g || !idx_g || !counts) return ASB_ERR_ARG;
     if (world < 1 || world > 16) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_panel_assemble: at most 16 ranks (got %d)", world);
     RankCounts rc_;
@@ -1804,7 +1822,7 @@ extern "C" int asb_panel_assemble(asb_ctx* ctx, const double* rows_g, const long
     }
     if (off > 0) {
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)(off < 2048 ? off : 2048)), dim3(256), 0, ctx->stream, rows_g, idx_g, rc_, world,
-                           (long long)maxcount, (long long)(3 * ctx->Fp), ctx->candR, ctx->cand_idx, (long long)off);
+                           stride_rows, stride_idx, (long long)(3 * ctx->Fp), ctx->candR, ctx->cand_idx, (long long)off);
         ASB_CHECK_LAUNCH(ctx);
     }
     ctx->n_slots_host = off;

@@ -219,6 +219,12 @@ class HipEngine(object):
         self._ck(self.lib.asb_panel_assemble(self.h, ctypes.c_void_p(rows_g_ptr), ctypes.c_void_p(idx_g_ptr), ptr(counts),
                                              int(counts.shape[0]), int(maxcount)))
 
+    def panel_assemble_packed(self, packed_g_ptr, counts, maxcount):
+        """One all-gathered buffer: per rank ``maxcount`` rows followed by ``maxcount`` vertex ids."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        self._ck(self.lib.asb_panel_assemble_packed(self.h, ctypes.c_void_p(packed_g_ptr), ptr(counts), int(counts.shape[0]),
+                                                    int(maxcount)))
+
     def panel_run(self, k0, steps, global_all=False):
         c = ctypes.c_int64()
         self._ck(self.lib.asb_panel_run(self.h, int(k0), int(steps), int(bool(global_all)), 1, ctypes.byref(c)))

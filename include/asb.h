@@ -129,10 +129,11 @@ int asb_deflate_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
  * rank; the multi-rank driver interleaves the collectives marked [ALL-*]) ------------------
  *   asb_panel_scale                     [ALL-REDUCE max of e0max, then set it on every rank]
  *   per panel:
- *     asb_panel_hist(1) [ALL-REDUCE sum] asb_panel_tau(1) asb_panel_hist(2) [ALL-REDUCE sum] asb_panel_tau(2)
- *     asb_panel_select(rows, idx)       [ALL-GATHER counts, rows, idx]  asb_panel_assemble
- *     asb_panel_run        -> committed (identical on every rank: same data, same arithmetic)
- *     asb_panel_project    (local shard)                                                        */
+ *     asb_panel_hist/tau(1), (2)  (local)  asb_panel_top_energies  [ALL-GATHER cap+1 doubles]  asb_panel_global_tau
+ *     asb_panel_select(rows, ids behind the rows)  [ALL-GATHER rows+ids]  asb_panel_assemble_packed
+ *     asb_panel_run(_spec) -> steps (identical on every rank: same data, same arithmetic)
+ *     asb_panel_project    (local shard)   | with unproven steps: asb_panel_project_spec [ALL-REDUCE min] asb_panel_commit
+ *   (older form, still supported: histograms all-reduced per level, rows and ids gathered separately)           */
 int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max_local, double set_e0max);
 /* local energy histogram (ASB_NBINS = 2048 ints) into hist_dev (NULL: internal) */
 int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev);
@@ -160,6 +161,10 @@ int64_t asb_panel_capacity(const asb_ctx* ctx);
  * rows_g_dev (world, maxcount, 3, Fp), idx_g_dev (world, maxcount), counts (host, world) */
 int asb_panel_assemble(asb_ctx* ctx, const double* rows_g_dev, const long long* idx_g_dev,
                        const int64_t* counts, int world, int64_t maxcount);
+/* the same from ONE all-gathered buffer (one collective instead of two): every rank's piece is its maxcount rows
+ * followed by its maxcount vertex ids (int64), maxcount * (3*Fp + 1) eight-byte words per rank -- i.e. asb_panel_select
+ * was given idx_out_dev = (long long*)(rows_out_dev + maxcount * 3*Fp) */
+int asb_panel_assemble_packed(asb_ctx* ctx, const double* packed_g_dev, const int64_t* counts, int world, int64_t maxcount);
 /* up to `steps` (<= 16) greedy steps on the candidate buffer; *committed of them are final */
 int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all, int assembled, int64_t* committed);
 /* one pass over X for components [k0, k0+ncols): c_k on this shard, energies */

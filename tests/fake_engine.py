@@ -267,6 +267,17 @@ class FakeEngine(object):
         self.candR = np.concatenate([rows[r, :counts[r]] for r in range(world)], axis=0).copy()
         self.cand_idx = np.concatenate([ids[r, :counts[r]] for r in range(world)]).copy()
 
+    def panel_assemble_packed(self, packed_g_ptr, counts, maxcount):
+        world, rl = len(counts), 3 * self.F
+        stride = maxcount * (rl + 1)
+        rows, ids = [], []
+        for r in range(world):
+            base = packed_g_ptr + 8 * r * stride
+            rows.append(_view(base, maxcount * rl).reshape(maxcount, 3, self.F)[:counts[r]])
+            ids.append(np.ctypeslib.as_array((ctypes.c_int64 * maxcount).from_address(base + 8 * maxcount * rl))[:counts[r]])
+        self.candR = np.concatenate(rows, axis=0).copy()
+        self.cand_idx = np.concatenate(ids).copy()
+
     def panel_run_spec(self, k0, steps, global_all, spec_max):
         done = self.panel_run(k0, steps, global_all, spec_max)
         return done, self.proven
