@@ -65,11 +65,12 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
                 const int j = t + i * T;
                 x[d][i] = (valid && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
             }
-        for (int q0 = 0; q0 < k0; q0 += 4) {      // four components' loads in flight (same subtraction order as one by one)
-            double cc[4][3];
-            double2 w[4][E2];
+        constexpr int U = E2 <= 4 ? 4 : (E2 <= 8 ? 2 : 1);      // components in flight (bounded by the register file)
+        for (int q0 = 0; q0 < k0; q0 += U) {      // U components' loads in flight (same subtraction order as one by one)
+            double cc[U][3];
+            double2 w[U][E2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int q = q0 + u < k0 ? q0 + u : k0 - 1;
                 const double* cq = comps + (long long)q * comp_stride + v * 3;
                 const bool on = q0 + u < k0;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
                 if (q0 + u < k0) {
 #pragma unroll
                     for (int i = 0; i < E2; ++i) {
@@ -2066,7 +2067,16 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 3] = wall_clock64();
         const double wn2 = coop_load(&recs[bb].wn2);
         const double* ww = rec_w + ((size_t)(t & 1) * G + bb) * Fp;
-        for (int f = tid; f < NJ * 64; f += 256) w_sh[f] = (f < Fp) ? coop_load(ww + f) : 0.0;
+        {       // all loads of a thread first, then the LDS stores: one memory round trip instead of NJ / 4 dependent ones
+            double tmp[NJ / 4];
+#pragma unroll
+            for (int q = 0; q < NJ / 4; ++q) {
+                const int f = tid + 256 * q;
+                tmp[q] = (f < Fp) ? coop_load(ww + f) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NJ / 4; ++q) w_sh[tid + 256 * q] = tmp[q];
+        }
         __syncthreads();
         if (blockIdx.x == 0) {
             const long long k = k0 + t;
