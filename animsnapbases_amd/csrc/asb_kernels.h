@@ -208,7 +208,7 @@ __host__ __device__ inline void eig3_top(double a00, double a01, double a02, dou
 
 // Largest eigen-pair of a symmetric 3 x 3 matrix without the Jacobi sweeps (~6 sweeps x 3 rotations of dependent
 // sqrt / divide chains, about 5 us on one lane): trigonometric root of the characteristic polynomial, eigenvector from
-// the largest cross product of two rows of A - lambda I, two Rayleigh-quotient refinements, and a residual test
+// the largest cross product of two rows of A - lambda I, one to three Rayleigh-quotient refinements, and a residual test
 // |A u - lambda u| <= 4 eps |A|; anything that fails it (near-degenerate top eigenvalues) goes to eig3_top.
 __host__ __device__ inline void eig3_top_fast(double a00, double a01, double a02, double a11, double a12, double a22,
                                               double& lam, double& u0, double& u1, double& u2) {
@@ -242,7 +242,12 @@ __host__ __device__ inline void eig3_top_fast(double a00, double a01, double a02
             if (!(nn > 1.0e-20)) { ok = false; break; }        // rank(B - l I) < 2: the top eigenvalue is (nearly) double
             const double inn = 1.0 / sqrt(nn);
             x *= inn; y *= inn; z *= inn;
-            l = x * (b00 * x + b01 * y + b02 * z) + y * (b01 * x + b11 * y + b12 * z) + z * (b02 * x + b12 * y + b22 * z);
+            const double ln = x * (b00 * x + b01 * y + b02 * z) + y * (b01 * x + b11 * y + b12 * z) + z * (b02 * x + b12 * y + b22 * z);
+            // the trigonometric root is already good to a few ulps unless the top eigenvalues are close: one refinement
+            // that moves it by no more than rounding ends the loop (the residual test below still decides)
+            const bool settled = fabs(ln - l) <= 8.9e-16 * fabs(ln);
+            l = ln;
+            if (settled) break;
         }
     }
     if (ok) {
