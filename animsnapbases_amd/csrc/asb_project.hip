@@ -2091,18 +2091,17 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         }
         if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 4] = wall_clock64();
         if (t + 1 < steps || rows_out != nullptr) {          // explicit deflation of this wave's row
-            double acc[3] = {0.0, 0.0, 0.0};
+            double acc[3] = {0.0, 0.0, 0.0}, wr[NJ];       // w once from LDS (four waves read all of it), then from registers
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const double wj = w_sh[lane + 64 * j];
-                acc[0] += x[0][j] * wj; acc[1] += x[1][j] * wj; acc[2] += x[2][j] * wj;
+                wr[j] = w_sh[lane + 64 * j];
+                acc[0] += x[0][j] * wr[j]; acc[1] += x[1][j] * wr[j]; acc[2] += x[2][j] * wr[j];
             }
 #pragma unroll
             for (int d = 0; d < 3; ++d) acc[d] = wave_sum(acc[d]) / wn2;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const double wj = w_sh[lane + 64 * j];
-                x[0][j] -= acc[0] * wj; x[1][j] -= acc[1] * wj; x[2][j] -= acc[2] * wj;
+                x[0][j] -= acc[0] * wr[j]; x[1][j] -= acc[1] * wr[j]; x[2][j] -= acc[2] * wr[j];
             }
         }
         __syncthreads();              // w_sh and the wave records are rewritten in the next step
