@@ -1968,10 +1968,10 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
                 x[d][j] = (have && f < Fp) ? row[(long long)d * Fp + f] : 0.0;
             }
     }
-    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(bar + 4);      // [16][6] timestamps of block 0 (debug)
+    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(bar + 4);      // [16][12] timestamps of block 0 (debug)
     for (int t = 0; t < steps; ++t) {
         const unsigned long long seq = (unsigned long long)t + 1;
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 0] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 0] = wall_clock64();
         // ---- 1. block-local best and its record
         double e = 0.0;
 #pragma unroll
@@ -1988,6 +1988,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         CoopRec* myrec = rec + (size_t)(t & 1) * G + blockIdx.x;
         double* myw = rec_w + ((size_t)(t & 1) * G + blockIdx.x) * Fp;
         if (wv == ow) {
+            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 6] = wall_clock64();
             double g[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -1997,13 +1998,15 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
 #pragma unroll
             for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
             double lam, u0, u1, u2;
+            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 7] = wall_clock64();
             eig3_top_fast(g[0], g[1], g[2], g[3], g[4], g[5], lam, u0, u1, u2);     // every lane: identical inputs and result
+            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 8] = wall_clock64();
             double wn = 0.0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int f = lane + 64 * j;
                 const double wvv = (f < F) ? (u0 * x[0][j] + u1 * x[1][j] + u2 * x[2][j]) : 0.0;
-                if (f < Fp) coop_store(myw + f, wvv);
+                w_sh[f] = wvv;                          // staged in LDS (free until the winner's w arrives): all four waves store it
                 wn += wvv * wvv;
             }
             wn = wave_sum(wn);
@@ -2013,11 +2016,23 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
                 coop_store(&myrec->wn2, wn);
                 __hip_atomic_store(&myrec->slot, wv_i[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_s_waitcnt(0);              // every store of this wave has been acknowledged ...
+            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 9] = wall_clock64();
+        }
+        __syncthreads();
+        // a wave's write-through stores are the slow part of the record (32 of them took 3 us from one wave): 8 per wave
+#pragma unroll
+        for (int q = 0; q < NJ / 4; ++q) {
+            const int f = tid + 256 * q;
+            if (f < Fp) coop_store(myw + f, w_sh[f]);
+        }
+        __builtin_amdgcn_s_waitcnt(0);                  // every store of this wave has been acknowledged ...
+        __syncthreads();                                // ... and of the other three
+        if (wv == ow) {
+            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 10] = wall_clock64();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_store(&myrec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
         }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 1] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 1] = wall_clock64();
         // ---- 2. + 3. poll every record until it is this step's, reduce to the same winner in every block
         const CoopRec* recs = rec + (size_t)(t & 1) * G;
         double be = -1.0;
@@ -2040,7 +2055,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             if (tid == 0) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 2] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 2] = wall_clock64();
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double oe = __shfl_xor(be, o, 64);
@@ -2064,7 +2079,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             }
         }
         nrun = t + 1;
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 3] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 3] = wall_clock64();
         const double wn2 = coop_load(&recs[bb].wn2);
         const double* ww = rec_w + ((size_t)(t & 1) * G + bb) * Fp;
         {       // all loads of a thread first, then the LDS stores: one memory round trip instead of NJ / 4 dependent ones
@@ -2089,7 +2104,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
                 panel->e_win[t] = be;
             }
         }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 4] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 4] = wall_clock64();
         if (t + 1 < steps || rows_out != nullptr) {          // explicit deflation of this wave's row
             double acc[3] = {0.0, 0.0, 0.0}, wr[NJ];       // w once from LDS (four waves read all of it), then from registers
 #pragma unroll
@@ -2105,7 +2120,7 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             }
         }
         __syncthreads();              // w_sh and the wave records are rewritten in the next step
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 6 + 5] = wall_clock64();
+        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 5] = wall_clock64();
     }
     if (blockIdx.x == 0 && tid == 0) panel->proven = proven < 0 ? nrun : proven;
     // super-panels run several of these launches on the same candidates: the deflated rows become the next start rows
@@ -2152,7 +2167,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     const int cgrid_all = (int)((ctx->m_cap + 3) / 4);
     const bool want_coop = ctx->panel_coop && ctx->Fp <= 2048;
     if (want_coop) {
-        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 6))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 12))) return rc;
         if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid_all * 8))) return rc;
         if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid_all * ctx->Fp))) return rc;
     }
@@ -2209,12 +2224,15 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
         }
     }
     if (coop && getenv("ASB_DEBUG_PANELS")) {
-        unsigned long long tl[16 * 6];
+        unsigned long long tl[16 * 12];
         (void)hipMemcpy(tl, ctx->coop_bar + 4, sizeof(tl), hipMemcpyDeviceToHost);
         for (int t = 0; t < (int)h.committed && t < 16; ++t)
-            fprintf(stderr, "[asb]   step %2d: record %.2f us | poll %.2f | reduce %.2f | w_sh+publish %.2f | deflate %.2f\n", t,
-                    (tl[t * 6 + 1] - tl[t * 6 + 0]) * 0.01, (tl[t * 6 + 2] - tl[t * 6 + 1]) * 0.01, (tl[t * 6 + 3] - tl[t * 6 + 2]) * 0.01,
-                    (tl[t * 6 + 4] - tl[t * 6 + 3]) * 0.01, (tl[t * 6 + 5] - tl[t * 6 + 4]) * 0.01);
+            fprintf(stderr, "[asb]   step %2d: record %.2f us (energy+select %.2f, Gram %.2f, eigen %.2f, w+stores %.2f, acks %.2f) | poll %.2f | "
+                            "reduce %.2f | w_sh+publish %.2f | deflate %.2f\n", t,
+                    (tl[t * 12 + 1] - tl[t * 12 + 0]) * 0.01, (tl[t * 12 + 6] - tl[t * 12 + 0]) * 0.01, (tl[t * 12 + 7] - tl[t * 12 + 6]) * 0.01,
+                    (tl[t * 12 + 8] - tl[t * 12 + 7]) * 0.01, (tl[t * 12 + 9] - tl[t * 12 + 8]) * 0.01, (tl[t * 12 + 10] - tl[t * 12 + 9]) * 0.01,
+                    (tl[t * 12 + 2] - tl[t * 12 + 1]) * 0.01, (tl[t * 12 + 3] - tl[t * 12 + 2]) * 0.01,
+                    (tl[t * 12 + 4] - tl[t * 12 + 3]) * 0.01, (tl[t * 12 + 5] - tl[t * 12 + 4]) * 0.01);
     }
     if (getenv("ASB_DEBUG_PANELS")) {
         double sc[8];
