@@ -111,7 +111,7 @@ struct asb_ctx {
     double* ypart = nullptr;     // partial 16x16 tiles between sweeps of k_project_lds
     unsigned int* tile_counter = nullptr;
     double* Wq = nullptr;        // (Fp/16, 4, 16, 4) panel in MFMA lane order (k_project_l2)
-    int l2_variant = 4;          // ASB_L2_VARIANT: 4 = k_project_l2s<4,2,2,1> (two waves per 64-row tile); 0..2 = k_project_l2 (one wave per tile: 32 rows x 4 chunks, 48 x 2, 64 x 2); others: experiments
+    int l2_variant = 4;          // ASB_L2_VARIANT: 4 = k_project_l2s<4,2,2,1> (two waves per 64-row tile); 0..2 = k_project_l2 (one wave per tile: 32 rows x 4 chunks, 48 x 2, 64 x 2); 5 = four waves per tile
     int project_kernel = 3;      // 1: k_project_mfma (Wt in registers), 2: k_project_lds (Wt in LDS), 3: k_project_l2 (Wt from L2)
     long long* ctmp = nullptr;   // compaction scratch
     long long* ccnt = nullptr;

@@ -1334,7 +1334,7 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq, ctx->tile_counter);
     const int variant = ctx->l2_variant;
-    const int NT = (variant == 0 || variant == 8) ? 2 : ((variant == 1 || variant == 9) ? 3 : 4);      // 3, 4, 5: k_project_l2s<4, 2, S> with S = 2, 4, 8 waves per tile
+    const int NT = variant == 0 ? 2 : (variant == 1 ? 3 : 4);      // 4, 5: k_project_l2s<4, 2, S, 1> with S = 2, 4 waves per tile
     const long long ntiles = (rows + 16 * NT - 1) / (16 * NT);
     long long wantb = (ntiles + 7) / 8;
     const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
@@ -1346,32 +1346,11 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     else if (variant == 1)
         hipLaunchKernelGGL((k_project_l2<3, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 3)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 4>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+    else if (variant == 4)      // default: two waves (one 128-thread block) per 64-row tile
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 4)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 5)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 4, 1>), dim3(2 * ctx->n_cu), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 6)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 2>), dim3(2 * ctx->n_cu), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 8)
-        hipLaunchKernelGGL((k_project_l2s<2, 4, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 9)
-        hipLaunchKernelGGL((k_project_l2s<3, 2, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 10)
-        hipLaunchKernelGGL((k_project_l2s<4, 3, 2, 1>), dim3(4 * ctx->n_cu), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 11)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 3, 1>), dim3(2 * ctx->n_cu), dim3(192), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 7)
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 8, 1>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+    else if (variant == 5)      // four waves per tile: loses at the barriers what it gains at the end of the launch
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 4, 1>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else
         hipLaunchKernelGGL((k_project_l2<4, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
