@@ -67,6 +67,7 @@ struct asb_ctx {
     // super-panels (asb_project.hip): how the next asb_panel_run behaves / what it did
     int run_writeback = 0, run_theta_band = 0, run_coop_used = 0;
     int spec_panels = 1;              // ASB_SPEC_PANELS=0 -> provable steps only
+    int gather_cpt = 2;               // ASB_GATHER_CPT=1 -> one candidate per block in k_gather<256,4>
     int run_spec_max = 0;             // unproven steps the next asb_panel_run may take (0 outside asb_project_run)
     int spec_budget = 16;             // adapted to how many unproven steps survived in the last panels
     long long run_proven = 0;         // provable head of the last asb_panel_run

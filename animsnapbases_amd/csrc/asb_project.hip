@@ -35,7 +35,9 @@ enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE 
 //   R_v = X_v - sum_{j<k0} w_j (x) c_j[v]   exactly, optionally stores it (dst) and
 // always returns its energy (+ per-block max / first index / sum).
 // --------------------------------------------------------------------------------------
-template <int T, int E2>
+// CPT items per thread group: the weights w_j (read from L2 by every block: K x 8 F bytes per item, the kernel's bound)
+// are loaded once for CPT items.
+template <int T, int E2, int CPT = 1>
 __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
     const double* __restrict__ X, const long long* __restrict__ idx_map, long long v0, long long n_items,
     const PanelState* __restrict__ panel, const double* __restrict__ comps, long long comp_stride,
@@ -52,29 +54,37 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
     if (panel != nullptr && panel->n_cand < n_items) n_items = panel->n_cand;
     double bmax = -1.0, bsum = 0.0;
     long long bidx = 0x7fffffffffffffffLL;
-    for (long long base = (long long)blockIdx.x * VPB; base < n_items; base += (long long)gridDim.x * VPB) {
-        const long long s = base + g;
-        const bool valid = s < n_items;
-        const long long v = valid ? (idx_map ? idx_map[s] - v0 : s) : 0;
-        const double2* row = reinterpret_cast<const double2*>(X) + v * 3 * (long long)F2;
-        double2 x[3][E2];
+    for (long long base = (long long)blockIdx.x * VPB * CPT; base < n_items; base += (long long)gridDim.x * VPB * CPT) {
+        long long s[CPT], v[CPT];
+        bool valid[CPT];
+        double2 x[CPT][3][E2];
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+        for (int cc = 0; cc < CPT; ++cc) {
+            s[cc] = base + (long long)g * CPT + cc;
+            valid[cc] = s[cc] < n_items;
+            v[cc] = valid[cc] ? (idx_map ? idx_map[s[cc]] - v0 : s[cc]) : 0;
+            const double2* row = reinterpret_cast<const double2*>(X) + v[cc] * 3 * (long long)F2;
 #pragma unroll
-            for (int i = 0; i < E2; ++i) {
-                const int j = t + i * T;
-                x[d][i] = (valid && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
-            }
-        constexpr int U = E2 <= 4 ? 4 : (E2 <= 8 ? 2 : 1);      // components in flight (bounded by the register file)
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int i = 0; i < E2; ++i) {
+                    const int j = t + i * T;
+                    x[cc][d][i] = (valid[cc] && j < F2) ? row[(long long)d * F2 + j] : make_double2(0.0, 0.0);
+                }
+        }
+        constexpr int U = E2 * CPT <= 4 ? 4 : (E2 * CPT <= 8 ? 2 : 1);      // components in flight (bounded by the register file)
         for (int q0 = 0; q0 < k0; q0 += U) {      // U components' loads in flight (same subtraction order as one by one)
-            double cc[U][3];
+            double cf[U][CPT][3];
             double2 w[U][E2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int q = q0 + u < k0 ? q0 + u : k0 - 1;
-                const double* cq = comps + (long long)q * comp_stride + v * 3;
                 const bool on = q0 + u < k0;
-                cc[u][0] = on ? cq[0] : 0.0; cc[u][1] = on ? cq[1] : 0.0; cc[u][2] = on ? cq[2] : 0.0;
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const double* cq = comps + (long long)q * comp_stride + v[cc] * 3;
+                    cf[u][cc][0] = on ? cq[0] : 0.0; cf[u][cc][1] = on ? cq[1] : 0.0; cf[u][cc][2] = on ? cq[2] : 0.0;
+                }
                 const double2* wq = reinterpret_cast<const double2*>(W) + (long long)q * F2;
 #pragma unroll
                 for (int i = 0; i < E2; ++i) {
@@ -86,37 +96,42 @@ __global__ __launch_bounds__((T >= 256 ? T : 256)) void k_gather(
             for (int u = 0; u < U; ++u)
                 if (q0 + u < k0) {
 #pragma unroll
-                    for (int i = 0; i < E2; ++i) {
-                        x[0][i].x -= w[u][i].x * cc[u][0]; x[0][i].y -= w[u][i].y * cc[u][0];
-                        x[1][i].x -= w[u][i].x * cc[u][1]; x[1][i].y -= w[u][i].y * cc[u][1];
-                        x[2][i].x -= w[u][i].x * cc[u][2]; x[2][i].y -= w[u][i].y * cc[u][2];
-                    }
+                    for (int cc = 0; cc < CPT; ++cc)
+#pragma unroll
+                        for (int i = 0; i < E2; ++i) {
+                            x[cc][0][i].x -= w[u][i].x * cf[u][cc][0]; x[cc][0][i].y -= w[u][i].y * cf[u][cc][0];
+                            x[cc][1][i].x -= w[u][i].x * cf[u][cc][1]; x[cc][1][i].y -= w[u][i].y * cf[u][cc][1];
+                            x[cc][2][i].x -= w[u][i].x * cf[u][cc][2]; x[cc][2][i].y -= w[u][i].y * cf[u][cc][2];
+                        }
                 }
         }
-        double e = 0.0;
-        double2* out = dst ? reinterpret_cast<double2*>(dst) + s * 3 * (long long)F2 : nullptr;
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+        for (int cc = 0; cc < CPT; ++cc) {
+            double e = 0.0;
+            double2* out = dst ? reinterpret_cast<double2*>(dst) + s[cc] * 3 * (long long)F2 : nullptr;
 #pragma unroll
-            for (int i = 0; i < E2; ++i) {
-                const int j = t + i * T;
-                if (out && valid && j < F2) out[(long long)d * F2 + j] = x[d][i];
-                e += x[d][i].x * x[d][i].x + x[d][i].y * x[d][i].y;
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int i = 0; i < E2; ++i) {
+                    const int j = t + i * T;
+                    if (out && valid[cc] && j < F2) out[(long long)d * F2 + j] = x[cc][d][i];
+                    e += x[cc][d][i].x * x[cc][d][i].x + x[cc][d][i].y * x[cc][d][i].y;
+                }
+            e = wave_sum(e);
+            if (NW > 1) {
+                __syncthreads();
+                if (lane == 0) red[g][wig] = e;
+                __syncthreads();
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) sum += red[g][q];
+                e = sum;
             }
-        e = wave_sum(e);
-        if (NW > 1) {
-            __syncthreads();
-            if (lane == 0) red[g][wig] = e;
-            __syncthreads();
-            double sum = 0.0;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) sum += red[g][q];
-            e = sum;
-        }
-        if (t == 0 && valid) {
-            energy_out[s] = e;
-            bsum += e;
-            if (am_better(e, s, bmax, bidx)) { bmax = e; bidx = s; }
+            if (t == 0 && valid[cc]) {
+                energy_out[s[cc]] = e;
+                bsum += e;
+                if (am_better(e, s[cc], bmax, bidx)) { bmax = e; bidx = s[cc]; }
+            }
         }
     }
     if (t == 0) { lead_e[g] = bmax; lead_i[g] = bidx; lead_s[g] = bsum; }
@@ -1112,6 +1127,15 @@ template <int T, int E2>
 static void launch_gather_te(asb_ctx* ctx, int grid, const long long* idx_map, long long n_items, const PanelState* panel,
                              int k0, double* dst, double* e_out, double* pm, long long* pi, double* ps) {
     constexpr int BLOCK = (T >= 256 ? T : 256);
+    if constexpr (T == 256 && E2 == 4) {
+        if (dst != nullptr && k0 >= 8 && ctx->gather_cpt == 2) {      // candidate rows late in a run: the L2 reads of W dominate
+            // (same grid: the blocks without items still write their neutral partial records, which the caller counts)
+            hipLaunchKernelGGL((k_gather<T, E2, 2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->X, idx_map,
+                               (long long)ctx->v0, n_items, panel, ctx->comps, (long long)(3 * ctx->n_loc), ctx->W, k0,
+                               (int)(ctx->Fp / 2), dst, e_out, pm, pi, ps);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_gather<T, E2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->X, idx_map, (long long)ctx->v0,
                        n_items, panel, ctx->comps, (long long)(3 * ctx->n_loc), ctx->W, k0, (int)(ctx->Fp / 2), dst,
                        e_out, pm, pi, ps);
@@ -1140,8 +1164,6 @@ static void launch_gather(asb_ctx* ctx, const StreamCfg& c, int grid, const long
 
 static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
-// one projection pass for components [k0, k0+ncols); proven < ncols: the steps from `proven` on were taken without
-// proof -- they are checked against every vertex's energy and *kept (optional) returns how many columns survived
 // second half of a pass with unproven steps: energies of the columns that stood (force_ncols < 0: the count the check
 // left on the device; otherwise the host's value, e.g. the minimum over the ranks), column sums, *kept
 static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* kept) {
@@ -1167,6 +1189,9 @@ static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* 
     return ASB_OK;
 }
 
+// one projection pass for components [k0, k0+ncols); proven < ncols: the steps from `proven` on were taken without
+// proof -- they are checked against every vertex's energy and *kept (optional) returns how many columns survived
+// (check_only: the energies are left to a later project_commit)
 static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_PANEL_COLS, int64_t* kept = nullptr,
                         bool check_only = false) {
     const bool spec = proven < ncols;
