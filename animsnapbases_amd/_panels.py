@@ -25,11 +25,21 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     m_target = eng.panel_target()
     _, e0 = eng.panel_scale()
     eng.panel_scale(set_e0max=float(comm.allreduce_max(e0)[0]))
-    rows_loc = torch.zeros(cap * (rl + 1), dtype=torch.float64, device=dev)      # rows, then (packed exchange) the ids
-    idx_loc = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    # exchange buffers, kept on the engine between calls (49 MB: allocating and clearing them cost 1.3 ms per call).
+    # Nothing reads the padding: the assembly takes counts[r] rows of rank r's piece.
+    key = (cap, rl, comm.world, str(dev))
+    bufs = getattr(eng, "_panel_bufs", None)
+    if bufs is None or bufs[0] != key:
+        bufs = (key, torch.empty(cap * (rl + 1), dtype=torch.float64, device=dev),      # rows, then (packed exchange) the ids
+                torch.empty(cap, dtype=torch.int64, device=dev),
+                torch.empty(cap + 1, dtype=torch.float64, device=dev),
+                torch.empty(comm.world * (cap + 1), dtype=torch.float64, device=dev))
+        try:
+            eng._panel_bufs = bufs
+        except AttributeError:
+            pass
+    _, rows_loc, idx_loc, top_loc, top_all = bufs
     packed_ok = hasattr(eng, "panel_assemble_packed")
-    top_loc = torch.empty(cap + 1, dtype=torch.float64, device=dev)
-    top_all = torch.empty(comm.world * (cap + 1), dtype=torch.float64, device=dev)
     global_all = n_rows <= cap
     spec_budget = 16 if (hasattr(eng, "panel_run_spec") and os.environ.get("ASB_SPEC_PANELS", "1") != "0") else 0
     k, stalled, forced_next = 0, 0, -1
