@@ -29,7 +29,7 @@ from . import _lib
 from ._panels import deflate_panels_multirank
 from .distributed import Comm
 from .engine import HipEngine
-from .utils import log_time, qr_factor, summed_grams, testSparsity, test_linear_dependency
+from .utils import log_time, qr_factor, summed_grams, testSparsity, test_linear_dependency, test_linear_dependency_grams
 
 constProj_output_directory = ""
 
@@ -423,7 +423,10 @@ class constraintsComponents:  # Components == bases
         eng, comm = ns._engine, ns._comm
         p_size = ns.constraintsSize
         K = self.numComp
-        test_linear_dependency(self.comps.swapaxes(0, 1), 3, K)
+        if self._comps_on_device and hasattr(eng, "orth_gram_get"):      # the rank diagnostic (:801) from the device's K x K Gram matrices
+            test_linear_dependency_grams(summed_grams(eng, comm, K), K, lambda j: self.comps[:, :, j].T)
+        else:
+            test_linear_dependency(self.comps.swapaxes(0, 1), 3, K)
         rows = np.zeros((K, K, 3))          # rows[m, j, i] = V[Pt[m], j, i]
         Pt, e_points, e_range = [], [], []
         # The reference solves the growing k x k system from scratch with lstsq at every step (O(K^4) in all).

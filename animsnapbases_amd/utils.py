@@ -157,6 +157,22 @@ def test_linear_dependency(mat, test_dim_range, expected_rank):
             print("... not linear independent, with rank: " + str(rk) + " != " + str(expected_rank) + ".")
 
 
+def test_linear_dependency_grams(G, expected_rank, host_slice):
+    """The same printed check from the per-dimension Gram matrices G (3, K, K) of a device-resident basis (one MFMA
+    product on the GPU instead of a host product over all rows): clear-cut cases by the rule of ``_rank``; anything
+    closer is decided on the host, ``host_slice(j)`` supplying the (rows, K) slice."""
+    for j in range(G.shape[0]):
+        lam = np.linalg.eigvalsh(G[j])
+        if np.all(np.isfinite(lam)) and lam[-1] > 0 and lam[0] > 1e-12 * lam[-1]:
+            rk = G.shape[1]
+        else:
+            rk = _rank(host_slice(j))
+        if rk == expected_rank:
+            print(".. linear independent.")
+        else:
+            print("... not linear independent, with rank: " + str(rk) + " != " + str(expected_rank) + ".")
+
+
 # ------------------------------------------------------------------ masses
 def read_mass_bin(fileName, N):
     """snapbases/posSnapshots.py:142-149: ``<i n><i m>`` + n doubles."""
