@@ -399,6 +399,41 @@ def test_multirank_hip_path_on_one_gpu(world, mode, support):
         assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1], outs[0][1])
 
 
+def test_eight_ranks_projection_protocol_on_one_gpu(monkeypatch):
+    """The panel protocol with EIGHT vertex shards (the node size the scaling bench runs): per-rank exports, the global
+    threshold selection over 8 x capacity energies, the packed all-gather and its assembly.  Eight contexts share one
+    GPU here, so the co-resident panel kernel (which wants the whole GPU per context) is replaced by its two-kernel
+    form; the exchange logic is the same."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    monkeypatch.setenv("ASB_PANEL_COOP", "0")
+    rng = np.random.default_rng(58)
+    verts, K = rng.uniform(-1, 1, size=(72, 12011, 3)), 30
+    param = _param(vertPos_numComponents=K)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.deflate_mode = "project"
+            comp.compute_components_store_singvalues()
+        return comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), snaps._engine.deflate_stats()
+
+    outs = run_ranks(8, rank_fn)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    ref = orc.extract_k_components(pre["snapTensor"], K, "global", None, 0.1, 0.35)
+    assert outs[0][3]["panels"] >= 3
+    for idx, comps, weigs, _ in outs:
+        assert idx.tolist() == ref["idx"].tolist()
+        comps, weigs = align_signs(comps, weigs, ref["comps"])
+        assert relerr(comps, ref["comps"]) < 1e-8 and relerr(weigs, ref["weigs"]) < 1e-8
+    for o in outs[1:]:
+        assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1], outs[0][1])
+
+
 def test_multirank_splocs_on_one_gpu():
     """SPLOCS over 2 vertex shards on one GPU: partial Gram matrices summed over ranks."""
     import contextlib
