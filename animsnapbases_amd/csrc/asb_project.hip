@@ -1164,6 +1164,18 @@ static void launch_gather(asb_ctx* ctx, const StreamCfg& c, int grid, const long
 
 static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
+// Per-panel read-back of the panel state (and the panel kernel's flags) through pinned host memory: ONE wait, no staging
+// copy (a pageable destination costs an extra copy kernel and a second round trip for the flags).
+static int read_panel_state(asb_ctx* ctx, PanelState* h, unsigned* flags) {
+    if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToHost, ctx->stream));
+    if (flags) ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin + 256, ctx->coop_bar, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h, ctx->host_pin, sizeof(PanelState));
+    if (flags) memcpy(flags, ctx->host_pin + 256, 4 * sizeof(unsigned));
+    return ASB_OK;
+}
+
 // second half of a pass with unproven steps: energies of the columns that stood (force_ncols < 0: the count the check
 // left on the device; otherwise the host's value, e.g. the minimum over the ranks), column sums, *kept
 static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* kept) {
@@ -1181,8 +1193,8 @@ static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* 
         *kept = force_ncols;
         if (force_ncols < 0) {
             PanelState h;
-            ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-            ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            int rc = read_panel_state(ctx, &h, nullptr);
+            if (rc) return rc;
             *kept = h.committed;
         }
     }
@@ -2208,14 +2220,12 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     ASB_CHECK_LAUNCH(ctx);
     ctx->run_coop_used = coop ? 1 : 0;
     PanelState h;
-    ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned flags[4] = {0, 0, 0, 0};
+    if ((rc = read_panel_state(ctx, &h, coop ? flags : nullptr))) return rc;
     *committed = h.committed;
     ctx->run_proven = (h.proven < 0 || h.proven > h.committed) ? h.committed : h.proven;
     ctx->n_panels++;
     if (coop) {
-        unsigned flags[4];
-        ASB_HIP(ctx, hipMemcpy(flags, ctx->coop_bar, sizeof(flags), hipMemcpyDeviceToHost));
         if (flags[1]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "panel kernel: the grid barrier timed out (blocks not co-resident?)");
         if (flags[2]) {               // more candidates than resident waves: this panel runs through the two-kernel loop
             const int save = ctx->panel_coop;
@@ -2286,8 +2296,7 @@ extern "C" int asb_panel_project_spec(asb_ctx* ctx, int64_t k0, int ncols, int p
     ctx->n_spec_steps += ncols - proven;
     ctx->run_proven = proven;
     PanelState h;
-    ASB_HIP(ctx, hipMemcpyAsync(&h, ctx->pstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = read_panel_state(ctx, &h, nullptr))) return rc;
     *first_rejected = h.spec_ok < ncols ? h.spec_ok : ncols;
     return ASB_OK;
 }

@@ -167,6 +167,7 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
     }
     asb_splocs_free(ctx);
     asb_geo_free(ctx);
+    if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
     for (auto& e : ctx->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
