@@ -71,6 +71,7 @@ struct asb_ctx {
     int run_spec_max = 0;             // unproven steps the next asb_panel_run may take (0 outside asb_project_run)
     int spec_budget = 16;             // adapted to how many unproven steps survived in the last panels
     long long run_proven = 0;         // provable head of the last asb_panel_run
+    double* w_fk = nullptr;                 // weights in the reference's (F, K) order for the read-back
     unsigned char* host_pin = nullptr;      // pinned host memory for the per-panel read-backs (PanelState + flags)
     long long n_spec_steps = 0, n_spec_kept = 0;      // statistics (asb_deflate_stats)
     int super_panels = 0;             // ASB_SUPER_PANELS=1

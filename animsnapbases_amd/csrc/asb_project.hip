@@ -2501,6 +2501,13 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     return ASB_OK;
 }
 
+// weigs (F, K) = W^T (W: K rows of Fp frames)
+__global__ __launch_bounds__(256) void k_weights_fk(const double* __restrict__ W, long long Fp, long long F, long long K,
+                                                    double* __restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < F * K; e += (long long)gridDim.x * 256)
+        out[e] = W[(e % K) * Fp + e / K];
+}
+
 int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local) {
     const int64_t K = ctx->K;
     std::vector<double> h((size_t)(K + 1) * 4);
@@ -2510,10 +2517,14 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
     if (comps)
         ASB_HIP(ctx, hipMemcpyAsync(comps, ctx->comps, (size_t)K * 3 * ctx->n_loc * sizeof(double), hipMemcpyDeviceToHost,
                                     ctx->stream));
-    std::vector<double> hw;
-    if (weigs) {
-        hw.resize((size_t)K * ctx->Fp);
-        ASB_HIP(ctx, hipMemcpyAsync(hw.data(), ctx->W, hw.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (weigs) {        // the reference's (F, K) order is produced on the device: one copy straight into the caller's array
+        int rc = asb_alloc(ctx, &ctx->w_fk, (size_t)ctx->F * K);
+        if (rc) return rc;
+        const long long total = (long long)ctx->F * K;
+        hipLaunchKernelGGL(k_weights_fk, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, ctx->stream,
+                           ctx->W, (long long)ctx->Fp, (long long)ctx->F, (long long)K, ctx->w_fk);
+        ASB_CHECK_LAUNCH(ctx);
+        ASB_HIP(ctx, hipMemcpyAsync(weigs, ctx->w_fk, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double r2 = sc[SC_NORMX2];
@@ -2523,8 +2534,5 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
         r2 -= h[k * 4 + 3];                       // |R_k|^2 = |R_{k-1}|^2 - |w_k|^2 |c_k|^2
         if (normR2_local) normR2_local[k] = r2;
     }
-    if (weigs)
-        for (int64_t f = 0; f < ctx->F; ++f)
-            for (int64_t k = 0; k < K; ++k) weigs[f * K + k] = hw[(size_t)k * ctx->Fp + f];
     return ASB_OK;
 }
