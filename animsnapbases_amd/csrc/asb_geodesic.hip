@@ -549,6 +549,7 @@ extern "C" int asb_geodesic_cache_add(asb_ctx* ctx, const int64_t* sources, int 
     }
     *slot0 = G->cached;
     G->cached += nsrc;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `sources` is the caller's: its upload must not outlive this call
     return ASB_OK;
 }
 extern "C" int asb_geodesic_cache_clear(asb_ctx* ctx) {
