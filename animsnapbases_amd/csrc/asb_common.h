@@ -120,6 +120,8 @@ struct asb_ctx {
     long long* ccnt = nullptr;
     int* hist = nullptr;
     PanelState* pstate = nullptr;
+    PanelState* pstate2 = nullptr;         // double panels: the first sub-panel's state, kept for its check after the pass
+    int double_panels = 0;                 // ASB_DOUBLE_PANELS=1 (experimental)
     int64_t n_panels = 0, n_refresh = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)

@@ -2419,6 +2419,114 @@ static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_ou
     return ASB_OK;
 }
 
+// ---- double panels (ASB_DOUBLE_PANELS=1, experimental): TWO sub-panels of up to 16 steps on the same candidate rows (the
+// panel kernel writes the deflated rows back), then ONE read of X for their up to 32 columns.  The second sub-panel's
+// steps are unproven almost by construction; they are checked like any unproven step, tile by tile: the first tile's
+// check and energy update, and only if all of it stands the second tile's against the updated energies.
+static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelState* st, int64_t* kept) {
+    const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
+    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram);
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
+                       ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0, st,
+                       ctx->scalar_dev);
+    hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)kb, st, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
+                       ctx->colpart, -1);
+    ctx->nblk = cgrid;
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, -1, kb, ctx->scal, st);
+    ASB_CHECK_LAUNCH(ctx);
+    if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin, st, sizeof(PanelState), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PanelState h;
+    memcpy(&h, ctx->host_pin, sizeof(h));
+    *kept = h.committed;
+    return ASB_OK;
+}
+
+static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
+    int rc;
+    *done_out = 0;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)3 * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)3 * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)48))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)1))) return rc;
+    for (int level = 1; level <= 2; ++level) {
+        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+        if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+    }
+    if ((rc = asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr))) return rc;
+    long long kb[2] = {k, k + ASB_PANEL_COLS};
+    int nc[2] = {0, 0}, proven[2] = {0, 0};
+    int64_t ran = 0;
+    const int stepsA = (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
+    ctx->run_writeback = 1;
+    ctx->run_spec_max = ctx->spec_panels ? ctx->spec_budget : 0;
+    rc = asb_panel_run(ctx, k, stepsA, 0, 0, &ran);
+    ctx->run_writeback = 0;
+    ctx->run_spec_max = 0;
+    if (rc) return rc;
+    if (ran == 0) return ASB_OK;                      // the caller's refresh / forced path
+    nc[0] = (int)ran;
+    proven[0] = (int)ctx->run_proven;
+    int ntile = 1;
+    if (ran == ASB_PANEL_COLS && ctx->run_coop_used && ctx->spec_panels && k + ASB_PANEL_COLS < k1) {
+        // the first sub-panel's state (winner energies, provable head) is needed again after the pass
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
+        const int stepsB = (int)((k1 - kb[1]) < ASB_PANEL_COLS ? (k1 - kb[1]) : ASB_PANEL_COLS);
+        int64_t ranB = 0;
+        ctx->run_spec_max = ASB_PANEL_COLS;
+        rc = asb_panel_run(ctx, kb[1], stepsB, 0, 0, &ranB);      // same candidates, rows as the first sub-panel left them
+        ctx->run_spec_max = 0;
+        if (rc) return rc;
+        ctx->n_panels--;                                 // statistics count reads of X
+        if (ranB > 0 && ctx->run_coop_used) {
+            nc[1] = (int)ranB;
+            proven[1] = (int)ctx->run_proven;
+            ntile = 2;
+        }
+    }
+    PanelState* st[2] = {ntile == 2 ? ctx->pstate2 : ctx->pstate, ctx->pstate};
+    // one read of X for both tiles
+    WideArgs wa{{0, 0, 0}, {0, 0, 0}};
+    for (int ct = 0; ct < ntile; ++ct) {
+        wide_build_tile(ctx, ct, kb[ct], nc[ct]);
+        wa.kb[ct] = kb[ct];
+        wa.nc[ct] = nc[ct];
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    const long long rows = 3 * ctx->n_loc;
+    size_t slot;
+    if ((rc = prof_begin(ctx, slot))) return rc;
+    if (ntile == 1)
+        hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    else
+        hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    if ((rc = prof_end(ctx, slot))) return rc;
+    ASB_CHECK_LAUNCH(ctx);
+    int64_t total = 0;
+    for (int ct = 0; ct < ntile; ++ct) {
+        int64_t kept = 0;
+        if ((rc = spec_tile_finish(ctx, ct, kb[ct], nc[ct], st[ct], &kept))) return rc;
+        ctx->n_spec_steps += nc[ct] - proven[ct];
+        ctx->n_spec_kept += kept > proven[ct] ? kept - proven[ct] : 0;
+        total += kept;
+        if (getenv("ASB_DEBUG_PANELS"))
+            fprintf(stderr, "[asb] double panel at k=%lld tile %d: %d proven + %lld of %d unproven steps kept\n", k, ct, proven[ct],
+                    (long long)(kept > proven[ct] ? kept - proven[ct] : 0), nc[ct] - proven[ct]);
+        if (kept < nc[ct]) break;                    // what follows was built on a rejected step
+    }
+    if (total > 0) ctx->k_done = k + total;
+    *done_out = total;
+    return ASB_OK;
+}
+
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
     long long k = k0;
@@ -2432,7 +2540,16 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
         ctx->band_target = bt < 2048 ? 2048 : (bt > 8192 ? 8192 : bt);
         ctx->band_cap = ctx->band_target * 4 / 3;
     }
+    const bool use_double = ctx->double_panels && !use_super && !global_all && ctx->panel_coop && ctx->Fp <= 2048 && ctx->spec_panels;
     while (k < k1) {
+        if (use_double && stalled == 0) {
+            int64_t done = 0;
+            if ((rc = double_panel(ctx, k, k1, &done))) return rc;
+            if (done > 0) { k += done; continue; }
+            stalled = 1;                                 // nothing stood: exact energies, then the plain path below
+            if ((rc = asb_panel_refresh(ctx, k, nullptr, nullptr))) return rc;
+            continue;
+        }
         if (use_super && stalled == 0) {
             int64_t done = 0;
             if ((rc = super_panel(ctx, k, k1, &done))) return rc;
