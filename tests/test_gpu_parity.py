@@ -327,6 +327,31 @@ def test_unproven_panel_steps_keep_the_reference_sequence(monkeypatch):
     assert relerr(outs[2][1], outs[1][1]) < 1e-11 and relerr(outs[2][2], outs[1][2]) < 1e-11
 
 
+def test_double_panels_keep_the_reference_sequence(monkeypatch):
+    """ASB_DOUBLE_PANELS=1 (experimental): two sub-panels on the same candidate rows, one 32-column read of X, the
+    unproven steps checked tile by tile -- fewer reads of X, same vertex sequence and basis as the oracle."""
+    rng = np.random.default_rng(72)
+    F, N, K = 144, 26000, 52
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    param = _param(vertPos_numComponents=K)
+    from animsnapbases_amd import posComponents, posSnapshots
+    pre = orc.prepare_snapshots(verts, "first", True)
+    d = orc.extract_k_components(pre["snapTensor"], K, "global", None, 0.1, 0.4)
+    panels = {}
+    for dbl in ("1", "0"):
+        monkeypatch.setenv("ASB_DOUBLE_PANELS", dbl)
+        snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
+        comp = posComponents(param, snaps)
+        comp.deflate_mode = "project"
+        comp.compute_components_store_singvalues()
+        assert comp.selected_vertices.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comp.comps, comp.weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-9 and relerr(weigs, d["weigs"]) < 1e-9
+        assert relerr(comp.measures_at_largeDeforVerts[:, 1:], d["measures"][:, 1:]) < 1e-8
+        panels[dbl] = snaps._engine.deflate_stats()["panels"]
+    assert panels["1"] < panels["0"], panels
+
+
 def test_project_mode_stepwise_panel_protocol(monkeypatch):
     """The multi-rank panel protocol (asb_panel_* steps, torch exchange buffers, assemble) driven on
     ONE GPU must reproduce the fused single-rank run bit for bit (the fused run without unproven steps, which the
