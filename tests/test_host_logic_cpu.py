@@ -71,3 +71,26 @@ def test_voronoi_masses_sum_to_area():
     m = U.voronoi_vertex_masses(V, T)
     area = 0.5 * np.linalg.norm(np.cross(V[T[:, 1]] - V[T[:, 0]], V[T[:, 2]] - V[T[:, 0]]), axis=1).sum()
     assert abs(m.sum() - area) < 1e-12 * area and (m > 0).all()
+
+
+def test_rank_diagnostic_from_gram_matrices(capsys):
+    """The printed rank check (utils/utils.py:60-74) driven by per-dimension Gram matrices must say what the
+    row-by-row version says: full rank from the Gram rule, anything doubtful decided on the host slice."""
+    rng = np.random.default_rng(3)
+    n, K = 400, 7
+    A = rng.normal(size=(n, K, 3))
+    A[:, 5, 1] = A[:, 2, 1] * 2.0                     # dimension 1: rank K - 1
+    G = np.stack([A[:, :, j].T @ A[:, :, j] for j in range(3)])
+    asked = []
+
+    def host_slice(j):
+        asked.append(j)
+        return A[:, :, j]
+
+    U.test_linear_dependency_grams(G, K, host_slice)
+    by_gram = capsys.readouterr().out.splitlines()
+    U.test_linear_dependency(A, 3, K)
+    by_rows = capsys.readouterr().out.splitlines()
+    assert by_gram == by_rows
+    assert by_gram[0] == ".. linear independent." and "rank: %d" % (K - 1) in by_gram[1]
+    assert asked == [1]                               # only the doubtful dimension went to the host
