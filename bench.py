@@ -198,7 +198,7 @@ def main():
                          "survey_step_bytes": 24.0 * N * F * (1 + K),
                          "survey_step_equivalent_GBps": 24.0 * N * F * (1 + K) / (dt / args.steps) / 1e9},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(F, N, K, args.cpu_budget)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:
