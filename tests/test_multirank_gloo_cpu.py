@@ -101,6 +101,14 @@ def test_two_rank_gloo_projection_mode(tmp_path, device_select):
     mp.spawn(_worker, args=(2, port, "global", str(tmp_path), "project", device_select), nprocs=2, join=True)
 
 
+def test_four_rank_gloo_projection_mode(tmp_path):
+    """The same protocol over four processes (uneven shards of 65 vertices: 17, 16, 16, 16): per-rank counts, the packed
+    rows + ids exchange and the min over ranks of the unproven-step checks with more than two participants."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(4, port, "global", str(tmp_path), "project", True), nprocs=4, join=True)
+
+
 def test_unproven_steps_protocol_keeps_the_sequence(monkeypatch, tmp_path):
     """The panel driver's unproven steps (run_spec -> project_spec -> min over ranks -> commit) on the CPU test double, one
     process: uniform noise with rest_shape='first' makes the provable panels short; the checked extra steps must save
