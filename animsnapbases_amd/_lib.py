@@ -64,6 +64,8 @@ PROTOTYPES = {
     "asb_panel_refresh": (c_int, [ctypes.c_void_p, c_i64, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_spec_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "asb_deflate_energy_passes": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
+    "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_deflate_block_argmax": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp]),
     "asb_deflate_force_next": (c_int, [ctypes.c_void_p, c_i64]),

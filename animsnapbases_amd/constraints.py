@@ -37,7 +37,8 @@ constProj_output_directory = ""
 class nonlinearSnapshots:
     """Constraint-projection snapshots: F frames of (e*p, 3) (nonlinear_snapshots.py:17-53)."""
 
-    def __init__(self, param, *, frames=None, test_frames=None, engine=None, comm=None, mass=None):
+    def __init__(self, param, *, frames=None, test_frames=None, engine=None, comm=None, mass=None, frames_device=None,
+                 keepalive=None):
         self.snapshots_file = ""
         self.rest_shape = ""
         self.dim = 0
@@ -54,6 +55,9 @@ class nonlinearSnapshots:
         self.test_snapTensor = None
         self.param = param
         self._frames, self._test_frames, self._preset_mass = frames, test_frames, mass
+        # (dev_ptr, F, rows): an (F, rows, 3) float64 tensor already in this rank's HBM -- this rank's shard of the
+        # constraint rows (or all of them); standardised in place like posSnapshots.from_device
+        self._frames_device, self._keepalive = frames_device, keepalive
         self._engine, self._comm = engine, comm if comm is not None else Comm()
         self._shards = None
 
@@ -85,14 +89,31 @@ class nonlinearSnapshots:
     @log_time(constProj_output_directory)
     def snapshots_prepare(self):
         """nonlinear_snapshots.py:74-96: read, optional sqrt-mass weighting, standardise -- on the GPU."""
-        X = self.read()
+        X = self.read() if self._frames_device is None else None
         if self._engine is None:
             dev, stream = 0, None
-            if self._comm.multi:
+            if self._comm.multi or self._frames_device is not None:
                 import torch
                 dev, stream = torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream
             self._engine = HipEngine(dev, stream)
         eng, comm = self._engine, self._comm
+        if self._frames_device is not None:
+            if self.param.constProj_massWeight:
+                raise NotImplementedError("mass weighting of device-resident constraint snapshots")
+            ptr_, F, rows = self._frames_device
+            counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * rows) if comm.multi else np.array([rows])
+            self._shards, v0 = [], 0
+            for n in counts.astype(np.int64):
+                self._shards.append((v0, int(n)))
+                v0 += int(n)
+            self.frames_rows = int(counts.sum())
+            self.frs = int(F)
+            self.num_constained_elements = self.frames_rows // self.constraintsSize
+            eng.adopt_device(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows)
+            if self.param.constProj_standarize:
+                self.standarize()
+            print('nonlinearSnapshots ready ... Volkwein (False), standarized (' + str(self.param.constProj_standarize) + ').')
+            return
         self.frames_rows = X.shape[1]
         massL = None
         if self.param.constProj_massWeight:

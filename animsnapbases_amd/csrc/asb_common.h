@@ -47,6 +47,12 @@ struct asb_ctx {
     double* X = nullptr;      // (3*n_loc, Fp)   prepared snapshots (snapTensor)
     double* mean = nullptr;   // (3*n_loc)
     bool have_mean = false;
+    // per-vertex energies |X_v|^2 of the PREPARED tensor, a by-product of the last sweep that wrote it (k_scale_energy) or
+    // of the first projection-mode begin after X changed; every writer of X clears e0_valid
+    double* E0 = nullptr;       // (n_loc)
+    double* e0_sc = nullptr;    // [|X|^2 of the shard, largest energy]
+    bool e0_valid = false;
+    int64_t n_energy_pass = 0;  // reads of X the last asb_deflate_begin spent on initial energies (statistics)
 
     // ---- reduction scratch ----
     int nblk_cap = 0;
@@ -64,6 +70,10 @@ struct asb_ctx {
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
     double* coop_w = nullptr;         // (2, grid, Fp) tentative weights
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
+    int e0_reuse = 1;                 // ASB_E0_REUSE=0 -> asb_project_begin always re-reads X for the initial energies
+    int correct_rows = 1;             // ASB_CORRECT_ROWS=0 -> the one-thread-per-vertex correction kernel (k_correct)
+    int coop_test_stall = 0;          // ASB_COOP_TEST_STALL=1 (tests): the first co-resident launch is made to time out
+    int64_t n_coop_fallbacks = 0;     // launches of k_panel_coop whose record exchange timed out (redone by the two-kernel loop)
     // super-panels (asb_project.hip): how the next asb_panel_run behaves / what it did
     int run_writeback = 0, run_theta_band = 0, run_coop_used = 0;
     int spec_panels = 1;              // ASB_SPEC_PANELS=0 -> provable steps only
@@ -111,6 +121,7 @@ struct asb_ctx {
     int64_t n_slots_host = 0;   // candidates in the assembled (multi-rank) buffer
     double* colpart = nullptr;   // (blocks, 16)
     double* gram = nullptr;      // (K, 16) w_j . w_panel
+    double* gram_s = nullptr;    // the same divided by |w_t|^2 of the panel's column t (k_correct_rows)
     double* ypart = nullptr;     // partial 16x16 tiles between sweeps of k_project_lds
     unsigned int* tile_counter = nullptr;
     double* Wq = nullptr;        // (Fp/16, 4, 16, 4) panel in MFMA lane order (k_project_l2)

@@ -288,6 +288,18 @@ extern "C" int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_ref
     return ASB_OK;
 }
 
+extern "C" int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes) {
+    if (!ctx || !n_passes) return ASB_ERR_ARG;
+    *n_passes = ctx->mode == ASB_DEFLATE_PROJECT ? ctx->n_energy_pass : 1;
+    return ASB_OK;
+}
+
+extern "C" int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n) {
+    if (!ctx || !n) return ASB_ERR_ARG;
+    *n = ctx->n_coop_fallbacks;
+    return ASB_OK;
+}
+
 extern "C" int asb_deflate_spec_stats(asb_ctx* ctx, int64_t* tried, int64_t* kept) {
     if (!ctx) return ASB_ERR_ARG;
     if (tried) *tried = ctx->n_spec_steps;

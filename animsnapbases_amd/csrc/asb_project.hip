@@ -169,6 +169,16 @@ __global__ __launch_bounds__(256) void k_range_init(const double* pmax, const lo
     }
 }
 
+// the same from the energies the standardisation sweep left behind (e0 = [|X|^2, largest energy])
+__global__ void k_range_restore(double* __restrict__ sc, const double* __restrict__ e0) {
+    sc[SC_EMAX] = e0[1];
+    sc[SC_LO] = 0.0;
+    sc[SC_HI] = e0[1];
+    sc[SC_ABOVE] = 0.0;
+    sc[SC_NORMX2] = e0[0];
+    sc[SC_E0MAX] = e0[1];
+}
+
 // level 1 (by_exponent): hist[b] = #{ e : biased exponent of e == b } -- exact, needs no range, and
 // covers the whole dynamic range of the energies (they fall by 1e8 on low-rank data);
 // level 2: linear bins inside the crossing binade [lo, hi).
@@ -386,7 +396,8 @@ __global__ __launch_bounds__(256) void k_best_energy(const double* pmax, const l
 // energies E[v] -= sum_t |w_t|^2 |c_t[v]|^2 and the per-block partial records.
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W, const double* __restrict__ Wt,
-                                                    int Fp, double* __restrict__ G) {
+                                                    int Fp, double* __restrict__ G, double* __restrict__ Gs = nullptr,
+                                                    const double* __restrict__ wn2 = nullptr) {
     __shared__ double sh[4 * 16];
     const double* wj = W + (long long)blockIdx.x * Fp;
     double acc[16];
@@ -399,7 +410,10 @@ __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W
         for (int t = 0; t < 16; ++t) acc[t] += a * wt[t];
     }
     block_sum<16>(acc, sh);
-    if (threadIdx.x < 16) G[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x < 16) {
+        G[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x];
+        if (Gs) Gs[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x] / wn2[threadIdx.x];      // (w_j . w_t) / |w_t|^2
+    }
 }
 
 // vmap != nullptr: only the vertices vmap[0 .. bstate->n_cand) (global ids; the band of a super-panel) are treated, E is
@@ -548,6 +562,123 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
         __syncthreads();
     }
     if (tid == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; psum[blockIdx.x] = sh_d[256]; }
+}
+
+// k_correct_rows: the same correction with ONE THREAD PER ROW (r = 3 v + d) instead of one per vertex: 16 accumulators
+// per thread instead of 48 (about 80 VGPRs against 432, six waves per SIMD against one), every load of an earlier
+// component is 512 contiguous bytes per wave, and the multipliers Gs[j][t] = (w_j . w_t) / |w_t|^2 are wave-uniform
+// (scalar loads).  A block is 192 threads = 64 whole vertices; the three rows of a vertex meet again through LDS, where
+// the first wave does the per-vertex part (energies, block records, or -- SPEC -- the check of the unproven steps).
+template <bool SPEC>
+__global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps, long long comp_stride, long long n_vert,
+                                                      int k0, int ncols, const double* __restrict__ Gs,
+                                                      const double* __restrict__ wn2, double* __restrict__ E,
+                                                      double* __restrict__ pmax, long long* __restrict__ pidx,
+                                                      double* __restrict__ psum, double* __restrict__ colpart,
+                                                      PanelState* __restrict__ spec, const double* __restrict__ sc) {
+    __shared__ double qs[16 * 192];
+    const int tid = threadIdx.x;
+    const long long n_rows = 3 * n_vert;
+    int viol = ASB_PANEL_COLS;
+    double bmax = -1.0, bsum = 0.0, csum[16];
+    long long bidx = 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) csum[t] = 0.0;
+    for (long long vb = (long long)blockIdx.x * 64; vb < n_vert; vb += (long long)gridDim.x * 64) {
+        const long long r = 3 * vb + tid;
+        const bool valid = r < n_rows;
+        double c[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) c[t] = (valid && t < ncols) ? comps[(long long)(k0 + t) * comp_stride + r] : 0.0;
+        int j = 0;
+        for (; j + 8 <= k0; j += 8) {          // eight earlier components in flight
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = valid ? comps[(long long)(j + u) * comp_stride + r] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double* g = Gs + (long long)(j + u) * 16;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) c[t] -= a[u] * g[t];
+            }
+        }
+        for (; j < k0; ++j) {
+            const double a = valid ? comps[(long long)j * comp_stride + r] : 0.0;
+            const double* g = Gs + (long long)j * 16;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) c[t] -= a * g[t];
+        }
+        // among the panel's own columns, in order (column t needs the corrected columns j < t)
+#pragma unroll
+        for (int t = 1; t < 16; ++t)
+            if (t < ncols) {
+                const double* g = Gs + (long long)k0 * 16 + t;
+#pragma unroll
+                for (int jj = 0; jj < t; ++jj) c[t] -= c[jj] * g[jj * 16];
+            }
+        __syncthreads();                       // the previous group's reads of qs are done
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (valid && t < ncols) comps[(long long)(k0 + t) * comp_stride + r] = c[t];
+            qs[t * 192 + tid] = c[t] * c[t];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const long long v = vb + tid;
+            if (v < n_vert) {
+                double e = E[v];
+                if (SPEC) {
+                    const bool outside = !(e > sc[SC_TAU]);           // the compaction took E > tau
+                    const double margin = spec->margin;
+                    const int proven = (int)spec->proven;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t < ncols) {
+                            if (outside && t >= proven && t < viol && !(spec->e_win[t] > e + margin)) viol = t;
+                            e -= ((qs[t * 192 + 3 * tid] + qs[t * 192 + 3 * tid + 1]) + qs[t * 192 + 3 * tid + 2]) * wn2[t];
+                        }
+                } else {
+                    double loss = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t < ncols) {
+                            const double q = ((qs[t * 192 + 3 * tid] + qs[t * 192 + 3 * tid + 1]) + qs[t * 192 + 3 * tid + 2]) * wn2[t];
+                            loss += q;
+                            csum[t] += q;
+                        }
+                    e -= loss;
+                    if (e < 0.0) e = 0.0;
+                    E[v] = e;
+                    bsum += e;
+                    if (am_better(e, v, bmax, bidx)) { bmax = e; bidx = v; }
+                }
+            }
+        }
+    }
+    if (tid >= 64) return;                     // the per-vertex records live in the first wave
+    if (SPEC) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ov = __shfl_xor(viol, o, 64);
+            viol = ov < viol ? ov : viol;
+        }
+        if (tid == 0 && viol < ASB_PANEL_COLS) atomicMin(reinterpret_cast<long long*>(&spec->spec_ok), (long long)viol);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) csum[t] = wave_sum(csum[t]);
+    bsum = wave_sum(bsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double om = __shfl_xor(bmax, o, 64);
+        const long long oi = __shfl_xor(bidx, o, 64);
+        if (am_better(om, oi, bmax, bidx)) { bmax = om; bidx = oi; }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) colpart[(long long)blockIdx.x * 16 + t] = csum[t];
+        pmax[blockIdx.x] = bmax; pidx[blockIdx.x] = bidx; psum[blockIdx.x] = bsum;
+    }
 }
 
 // second half of a panel with unproven steps: E -= sum over the columns that survived the check (t < spec_ok), block
@@ -1218,21 +1349,33 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
     launch_project(ctx, ncols, ctx->comps + (size_t)k0 * 3 * ctx->n_loc);      // HIP-event bracketed per kernel launch
     ASB_CHECK_LAUNCH(ctx);
     // rows j < k0: earlier panels' weights against this panel's; rows k0 .. k0+ncols-1: the panel's own Gram matrix
-    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(k0 + ncols)), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram);
-    long long cw = (ctx->n_loc + 255) / 256;
+    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(k0 + ncols)), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt, (int)ctx->Fp, ctx->gram,
+                       ctx->gram_s, ctx->wn2t);
+    const bool rows_kernel = ctx->correct_rows != 0;
+    long long cw = rows_kernel ? (ctx->n_loc + 63) / 64 : (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
     if (spec) {
-        hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
-                           ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0,
-                           ctx->pstate, ctx->scalar_dev);
+        if (rows_kernel)
+            hipLaunchKernelGGL(k_correct_rows<true>, dim3(cgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                               (long long)ctx->n_loc, (int)k0, ncols, ctx->gram_s, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                               ctx->psum, ctx->colpart, ctx->pstate, ctx->scalar_dev);
+        else
+            hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                               (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                               ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0,
+                               ctx->pstate, ctx->scalar_dev);
         ASB_CHECK_LAUNCH(ctx);
         if (check_only) return ASB_OK;
         return project_commit(ctx, k0, -1, kept);
     }
-    hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                       (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
-                       ctx->psum, ctx->colpart);
+    if (rows_kernel)
+        hipLaunchKernelGGL(k_correct_rows<false>, dim3(cgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram_s, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart, (PanelState*)nullptr, (const double*)nullptr);
+    else
+        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart);
     ASB_CHECK_LAUNCH(ctx);
     ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, ncols, k0, ctx->scal,
@@ -1464,12 +1607,23 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
     if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->gram, (size_t)K * ASB_PANEL_COLS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->gram_s, (size_t)K * ASB_PANEL_COLS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ctmp, (size_t)ASB_CBLOCKS * ctx->m_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ccnt, (size_t)ASB_CBLOCKS))) return rc;
     ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
-    // initial energies straight from X (read-only pass)
     StreamCfg c;
     if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    if (ctx->e0_valid && ctx->E0 && ctx->e0_reuse) {
+        // the energies of the prepared tensor came with the sweep that wrote it (asb_snapshots_scale) or with an earlier
+        // begin on the same tensor: X has not changed since, so nothing is read again
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->energy, ctx->E0, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_range_restore, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, ctx->e0_sc);
+        ASB_CHECK_LAUNCH(ctx);
+        ctx->nblk = 0;                 // no partial records yet: every consumer of them runs after a refresh
+        ctx->n_energy_pass = 0;
+        return ASB_OK;
+    }
+    // initial energies straight from X (read-only pass)
     const int grid = stream_grid(ctx, c, ctx->n_loc);
     StreamArgs a{ctx->X, nullptr, nullptr, nullptr, nullptr, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
                  (long long)ctx->n_loc, nullptr};
@@ -1479,6 +1633,12 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     hipLaunchKernelGGL(k_range_init, dim3(1), dim3(256), 0, ctx->stream, ctx->pmax, ctx->pidx, ctx->psum, ctx->nblk,
                        ctx->scalar_dev, 1);
     ASB_CHECK_LAUNCH(ctx);
+    ctx->n_energy_pass = 1;
+    if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)2))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->E0, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->e0_sc, ctx->scalar_dev + SC_NORMX2, 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->e0_valid = true;
     return ASB_OK;
 }
 
@@ -1952,7 +2112,8 @@ template <int NJ>
 __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const double* R0, long long m_cap, int F, int Fp,
                                                        double* __restrict__ W, double* __restrict__ scal, long long k0, int steps,
                                                        PanelState* __restrict__ panel, const long long* __restrict__ cand_idx,
-                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w, double* rows_out) {
+                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w, double* rows_out,
+                                                       int test_stall) {
     __shared__ double w_sh[NJ * 64];
     __shared__ double sh_e[4];
     __shared__ long long sh_i[4];
@@ -2046,7 +2207,9 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         if (wv == ow) {
             if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 10] = wall_clock64();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&myrec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag
+            // ... before the flag (test_stall, tests only: the last block never signals, so every block runs into the poll limit)
+            if (lane == 0 && !(test_stall && blockIdx.x == G - 1))
+                __hip_atomic_store(&myrec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 1] = wall_clock64();
         // ---- 2. + 3. poll every record until it is this step's, reduce to the same winner in every block
@@ -2060,9 +2223,16 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
             long long spins = 0;
             while (__hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1LL << 20) || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { dead = 1; break; }
+                if (++spins > (test_stall ? (1LL << 10) : (1LL << 20)) ||
+                    __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { dead = 1; break; }
             }
             if (dead) break;
+            // Ordering of the hand-off (MI355X guide, "valid forms"): the record's payload was stored with agent-scope
+            // (write-through, sc1) stores, every storing wave drained them (s_waitcnt 0) in front of the workgroup barrier
+            // that precedes the sequence-number store; here EVERY load of the payload is an agent-scope (sc1) load issued
+            // after the poll has matched -- loads of one wave return in order, and the compiler barrier keeps them from
+            // being hoisted above the poll loop.  No cache invalidate / write-back is needed in this form.
+            asm volatile("" ::: "memory");
             const double eb = coop_load(&r->e);
             const long long ib = __hip_atomic_load(&r->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (am_better(eb, ib, be, bi)) { be = eb; bi = ib; bb = b; }
@@ -2164,7 +2334,7 @@ static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bo
     // turns any surprise into an error instead of a hang.
     hipLaunchKernelGGL(k_panel_coop<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (long long)ctx->m_cap, (int)ctx->F,
                        (int)ctx->Fp, ctx->W, ctx->scal, k0, steps, ctx->pstate, ctx->cand_idx, ctx->coop_bar,
-                       (CoopRec*)ctx->coop_rec, ctx->coop_w, writeback ? ctx->candR : (double*)nullptr);
+                       (CoopRec*)ctx->coop_rec, ctx->coop_w, writeback ? ctx->candR : (double*)nullptr, ctx->coop_test_stall);
     ASB_CHECK_LAUNCH(ctx);
     *launched = true;
     return ASB_OK;
@@ -2226,7 +2396,21 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     ctx->run_proven = (h.proven < 0 || h.proven > h.committed) ? h.committed : h.proven;
     ctx->n_panels++;
     if (coop) {
-        if (flags[1]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "panel kernel: the grid barrier timed out (blocks not co-resident?)");
+        if (flags[1]) {
+            // The record exchange did not complete: the kernel's blocks were not all resident at once -- another stream,
+            // an RCCL kernel or a second context holds part of the GPU.  Every block has left through the abort flag (the
+            // stream is idle again); what the dead launch wrote (W / scal rows from k0 on, the panel state) is rewritten by
+            // the two-kernel loop, which needs no co-residency.  The context stays on that loop from now on.
+            if (ctx->run_writeback)     // super / double panels only (opt-in): the candidate rows were deflated in place
+                ASB_FAIL(ctx, ASB_ERR_NUMERIC, "panel kernel: the record exchange timed out while the rows were updated in place");
+            ctx->panel_coop = 0;
+            ctx->coop_test_stall = 0;
+            ctx->n_coop_fallbacks++;
+            ctx->n_panels--;
+            rc = asb_panel_run(ctx, k0, steps, global_all, assembled, committed);
+            ctx->run_coop_used = 0;
+            return rc;
+        }
         if (flags[2]) {               // more candidates than resident waves: this panel runs through the two-kernel loop
             const int save = ctx->panel_coop;
             ctx->panel_coop = 0;

@@ -106,6 +106,55 @@ __global__ __launch_bounds__(256) void k_scale(double* __restrict__ X, long long
     }
 }
 
+// k_scale_energy: row *= a AND the per-vertex energies of the scaled tensor in the same sweep (one wave per vertex: its
+// three rows are 3 Fp contiguous doubles; the zero padding stays zero).  E0[v] = sum of the scaled squares; per-block
+// (sum, max) partials for |X|^2 and the largest energy -- what the projection path would otherwise re-read all of X for.
+__global__ __launch_bounds__(256) void k_scale_energy(double* __restrict__ X, long long n_vert, int Fp, double a,
+                                                      double* __restrict__ E0, double* __restrict__ psum,
+                                                      double* __restrict__ pmax) {
+    __shared__ double sh[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n2 = 3 * Fp / 2;
+    double bsum = 0.0, bmax = 0.0;
+    for (long long v = (long long)blockIdx.x * 4 + wid; v < n_vert; v += (long long)gridDim.x * 4) {
+        double2* p = reinterpret_cast<double2*>(X + v * 3 * Fp);
+        double e0 = 0.0, e1 = 0.0;
+        for (int i = lane; i < n2; i += 64) {
+            double2 q = p[i];
+            q.x *= a;
+            q.y *= a;
+            p[i] = q;
+            e0 += q.x * q.x;
+            e1 += q.y * q.y;
+        }
+        const double e = wave_sum(e0 + e1);
+        if (lane == 0) E0[v] = e;
+        bsum += e;
+        bmax = fmax(bmax, e);
+    }
+    if (lane == 0) { sh[wid] = bsum; sh[4 + wid] = bmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        psum[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        pmax[blockIdx.x] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_e0_finish(const double* __restrict__ psum, const double* __restrict__ pmax, int n,
+                                                   double* __restrict__ out) {
+    __shared__ double sh[8];
+    double s = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s += psum[i]; m = fmax(m, pmax[i]); }
+    s = wave_sum(s);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        out[1] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, int n, double* __restrict__ out) {
     __shared__ double sh[4];
     double v[1] = {0.0};
@@ -143,6 +192,9 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if (const char* pk = getenv("ASB_PROJECT_KERNEL")) ctx->project_kernel = atoi(pk);
     if (const char* pv = getenv("ASB_L2_VARIANT")) ctx->l2_variant = atoi(pv);
     if (const char* pc = getenv("ASB_PANEL_COOP")) ctx->panel_coop = atoi(pc);
+    if (const char* ts = getenv("ASB_COOP_TEST_STALL")) ctx->coop_test_stall = atoi(ts);
+    if (const char* er = getenv("ASB_E0_REUSE")) ctx->e0_reuse = atoi(er);
+    if (const char* cr = getenv("ASB_CORRECT_ROWS")) ctx->correct_rows = atoi(cr);
     if (const char* sp = getenv("ASB_SUPER_PANELS")) ctx->super_panels = atoi(sp);
     if (const char* sp = getenv("ASB_SPEC_PANELS")) ctx->spec_panels = atoi(sp);
     if (const char* gc = getenv("ASB_GATHER_CPT")) ctx->gather_cpt = atoi(gc);
@@ -218,6 +270,7 @@ static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_
     ctx->v0 = v0;
     ctx->n_loc = n_loc;
     ctx->have_mean = false;
+    ctx->e0_valid = false;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->X, (size_t)n_loc * 3 * ctx->Fp))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->mean, (size_t)n_loc * 3))) return rc;
@@ -301,6 +354,7 @@ extern "C" int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, 
                        (int)ctx->F, (int)ctx->Fp, rest_shape, subtract, ctx->mean, ctx->psum);
     ASB_CHECK_LAUNCH(ctx);
     ctx->have_mean = true;
+    if (subtract) ctx->e0_valid = false;
     double tmp;
     return finish_sum(ctx, grid, local_sum ? local_sum : &tmp);
 }
@@ -316,11 +370,19 @@ extern "C" int asb_snapshots_sqdev(asb_ctx* ctx, double mu, double* local_sqdev)
 
 extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     if (!ctx || !ctx->X) return ASB_ERR_ARG;
-    const long long n2 = ctx->n_loc * 3 * ctx->Fp / 2;
-    long long want = (n2 + 255) / 256;
+    // the scaling sweep also leaves the per-vertex energies of the scaled tensor (E0), |X|^2 and the largest energy:
+    // asb_project_begin then needs no pass over X of its own
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)2))) return rc;
+    long long want = (ctx->n_loc + 3) / 4;
     const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
-    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, n2, a);
+    hipLaunchKernelGGL(k_scale_energy, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc, (int)ctx->Fp, a,
+                       ctx->E0, ctx->psum, ctx->pmax);
     ASB_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_e0_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->psum, ctx->pmax, grid, ctx->e0_sc);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->e0_valid = true;
     return ASB_OK;
 }
 

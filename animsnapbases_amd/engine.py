@@ -259,7 +259,12 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
         c, d = ctypes.c_int64(), ctypes.c_int64()
         self._ck(self.lib.asb_deflate_spec_stats(self.h, ctypes.byref(c), ctypes.byref(d)))
-        return dict(panels=a.value, refreshes=b.value, unproven_tried=c.value, unproven_kept=d.value)
+        e = ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_energy_passes(self.h, ctypes.byref(e)))
+        f = ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_coop_fallbacks(self.h, ctypes.byref(f)))
+        return dict(panels=a.value, refreshes=b.value, unproven_tried=c.value, unproven_kept=d.value, energy_passes=e.value,
+                    coop_fallbacks=f.value)
 
     def download_residual(self):
         out = np.empty((self.F, self.n_loc, 3))

@@ -5,17 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config #4, the one the north-star target is quoted on): synthetic
-random snapshot tensor 100 000 vertices x 2 000 frames (float64, 4.8 GB), greedy-deflation
-"PCA" with K = 128 components, global support, vertex rows sharded over the ranks.
-One "step" = one complete ``extract_k_components`` over the resident tensor (F snapshots).
-metric = snapshots/sec = F * steps / wall.  Inputs are resident in HBM before the timed
-region (generated on the device); outputs that the reference holds in RAM (weights,
-singular values, residual norms, selected vertices) are copied back inside the timed
-region, the (K, N, 3) basis stays device-resident until read (DESIGN.md gives the
-PCIe-inclusive figure).
+Headline workload (BASELINE.json config #4, the one the north-star target is quoted on): synthetic random snapshot
+tensor 100 000 vertices x 2 000 frames (float64, 4.8 GB), greedy-deflation "PCA" with K = 128 components, global
+support, vertex rows sharded over the ranks.  One "step" = one complete ``extract_k_components`` over the resident
+tensor (F snapshots).  metric = snapshots/sec = F * steps / wall.  Inputs are resident in HBM before the timed region
+(generated on the device); what the reference holds in RAM afterwards (weights, singular values, residual norms,
+selected vertices) is copied back inside the timed region; the (K, N, 3) basis stays device-resident until it is read
+-- ``end_to_end`` adds the preparation (layout change + standardisation, ``prepare_ms``) and that download.
 
-Prints ONE JSON line (rank 0) with the ``roofline`` and ``cpu_baseline`` objects.
+Prints ONE JSON line (rank 0).  Besides the contract's keys:
+  roofline      dominant kernel (HIP events around every launch of it on the engine's stream) AND the step-level
+                figure: (reads of X per step) x 24 N F bytes / ms_per_step against 8 TB/s;
+  cpu_baseline  the NumPy oracle (a port of the reference's CPU path) on a bounded sample, median of 3;
+  end_to_end    prepare_ms + ms_per_step + basis_download_ms;
+  other_configs BASELINE.json configs 2, 3 and 5 at their full size (one GPU), each with its own time, roofline and CPU
+                baseline (N = 1 only; ``--no-other-configs`` skips them).
 """
 import argparse
 import contextlib
@@ -32,33 +36,203 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor spec; the guide lists no f64 row; tools/probe_mfma_f64: 70 measured)
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")      # offline rocprofv3 --pmc passes of THIS build
 
 
-def cpu_baseline(F, N, K, budget_s=20.0):
-    """Times the NumPy oracle (a port of the reference's CPU path) on a bounded sample of the
-    same workload and scales it to the full job: per-component cost is linear in N (every
-    operation is a streaming pass over the F x N x 3 residual)."""
-    from oracle import asb_oracle as orc
-
+def _cpu_info():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_s = max(256, min(N, N // 5))
-    k_s = 2
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, model
+
+
+def _median3(fn):
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def cpu_baseline_c4(F, N, K, budget_s=18.0):
+    """NumPy oracle on a bounded sample of config 4, scaled: the per-component cost is linear in N (every operation is a
+    streaming pass over the F x N x 3 residual) and the loop is linear in K.  Median of 3 runs of the sample."""
+    from oracle import asb_oracle as orc
+    cores, model = _cpu_info()
+    n_s = max(256, min(N, N // 10))
     rng = np.random.default_rng(7)
     X = rng.uniform(-1, 1, size=(F, n_s, 3))
     X = orc.prepare_snapshots(X, "first", True)["snapTensor"]
     t0 = time.perf_counter()
     orc.extract_k_components(X, 1)                 # warm-up (BLAS threads, page faults)
     t_one = time.perf_counter() - t0
-    k_s = int(max(2, min(K, budget_s / max(t_one, 1e-3))))
+    k_s = int(max(2, min(K, budget_s / 3.0 / max(t_one, 1e-3))))
+    med, ts = _median3(lambda: orc.extract_k_components(X, k_s))
+    per_comp_full = med / k_s * (N / n_s)
+    return dict(value=F / (per_comp_full * K), unit="snapshots/s", cores=cores, kind="port", cpu_model=model,
+                runs_s=[round(t, 3) for t in ts],
+                sample="NumPy oracle (oracle/asb_oracle.py, OpenBLAS threads = all %d host cores) on %d of %d vertices x %d "
+                       "frames, %d of %d components; median of 3 runs (%.2f s); scaled linearly in N and K"
+                       % (cores, n_s, N, F, k_s, K, med))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs 2, 3, 5 (one GPU, full size)
+# ---------------------------------------------------------------------------------------------------------------------
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _timed(fn, sync):
+    sync()
     t0 = time.perf_counter()
-    orc.extract_k_components(X, k_s)
-    dt = time.perf_counter() - t0
-    per_comp_full = dt / k_s * (N / n_s)
-    value = F / (per_comp_full * K)
-    return dict(value=value, unit="snapshots/s", cores=cores, kind="port",
-                sample="NumPy oracle (oracle/asb_oracle.py, OpenBLAS threads = all %d host cores) on %d of %d "
-                       "vertices x %d frames, %d of %d components, %.1f s measured; scaled linearly in N and K"
-                       % (cores, n_s, N, F, k_s, K, dt))
+    r = _quiet(fn)
+    sync()
+    return (time.perf_counter() - t0) * 1e3, r
+
+
+def _pos_param(K, support, kind="PCA"):
+    return types.SimpleNamespace(vertPos_bases_type=kind, vertPos_numComponents=K, q_support=support,
+                                 store_vertPos_PCA_sing_val=False, vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25,
+                                 q_standarize=True, q_massWeight=False, q_orthogonal=False, vertPos_output_directory=".",
+                                 name="bench", splocs_max_itrs=20, splocs_admm_num_itrs=10, splocs_lambda=2.0, splocs_rho=10.0,
+                                 vertPos_rest_shape="first")
+
+
+def _fixture_mesh(name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    return g["rest"], g["tris"].astype(np.int64), g
+
+
+def other_config_pos(tag, fixture, support, kind, cpu=True):
+    """configs 2 / 3: the real rest mesh (from the committed fixture), seeded synthetic frames of SURVEY.md 8(d)."""
+    from animsnapbases_amd import posComponents, posSnapshots
+    from oracle import asb_oracle as orc
+    rest, tris, g = _fixture_mesh(fixture)
+    F, K = int(g["F"]), int(g["param_vertPos_numComponents"])
+    N = rest.shape[0]
+    verts = orc.synth_snapshots(rest, F, rank=int(g["rank"]), noise=float(g["noise"]), seed=int(g["seed"]), kind=str(g["kind"]))
+    holder = {}
+
+    def prep():
+        holder["snaps"] = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False)
+    t_prep, _ = _timed(prep, lambda: None)
+    snaps = holder["snaps"]
+    comp = posComponents(_pos_param(K, support, kind), snaps)
+    sync = snaps._engine.sync
+    if kind == "PCA":
+        _timed(comp.compute_components_store_singvalues, sync)       # warm-up
+    if snaps.compute_geodesic_distance is not None:
+        snaps.compute_geodesic_distance._cache.clear()                # the timed call computes its distance fields itself
+    ms, _ = _timed(comp.compute_components_store_singvalues, sync)
+    assert comp.selected_vertices.tolist() == g["idx"].tolist()       # sanity of what was timed (parity: tests/)
+    c = 1 if support == "global" else 2
+    alg = 24.0 * N * F * (1 + c * K)
+    if kind == "SPLOCS":
+        its, admm = 20, 10
+        alg += its * (48.0 * N * F + 8.0 * 3 * N * K * (2 + 4 * admm))
+    out = {"workload": "%s: %s (%d verts) x %d frames, %s K=%d support=%s%s" %
+                       (tag, str(g["mesh"]), N, F, kind, K, support, ", 20 outer x 10 ADMM" if kind == "SPLOCS" else ""),
+           "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "prepare_ms": t_prep,
+           "roofline": {"bound": "hbm", "level": "call", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
+                        "note": "SURVEY 8(d) algorithmic bytes of the whole call / its wall time; the %.0f MB tensor is "
+                                "Infinity-Cache resident, so this is a nominal HBM figure" % (24.0 * N * F / 1e6)}}
+    if cpu:
+        cores, model = _cpu_info()
+        geo = orc.Geodesics(verts[0], tris) if support == "local" else None
+        pre = orc.prepare_snapshots(verts, "first", True)
+        if kind == "PCA":
+            med, ts = _median3(lambda: orc.extract_k_components(pre["snapTensor"], K, support, geo, 0.1, 0.25))
+            out["cpu_baseline"] = dict(value=F / med, unit="snapshots/s", cores=cores, kind="port", cpu_model=model,
+                                       runs_s=[round(t, 3) for t in ts], sample="NumPy oracle, the full workload, median of 3")
+        else:
+            ks = 4          # bounded: 4 of the 64 components, 1 of the 20 outer iterations; both loops are linear in K
+
+            def sample():
+                d = orc.extract_k_components(pre["snapTensor"], ks, support, geo, 0.1, 0.25)
+                t1 = time.perf_counter()
+                orc.splocs_glob_optimization(pre["snapTensor"], d["comps"], d["weigs"], d["R"], geo, 0.1, 0.25, 1, 10, 2.0, 10.0)
+                sample.t_splocs.append(time.perf_counter() - t1)
+            sample.t_splocs = []
+            med, ts = _median3(sample)
+            t_s = float(np.median(sample.t_splocs))
+            full = (med - t_s) * (K / ks) + t_s * (K / ks) * 20
+            out["cpu_baseline"] = dict(value=F / full, unit="snapshots/s", cores=cores, kind="port", cpu_model=model,
+                                       runs_s=[round(t, 3) for t in ts],
+                                       sample="NumPy oracle on %d of %d components and 1 of 20 SPLOCS outer iterations at full N, F "
+                                              "(median of 3: %.2f s, of which SPLOCS %.2f s); scaled linearly in K and iterations"
+                                              % (ks, K, med, t_s))
+    return out
+
+
+def other_config_c5(dev, cpu=True, ep=50000, F=4000, K=256):
+    """config 5: constraint-projection snapshots 50 000 x 3 rows x 4 000 frames, POD (pod_vectorized) K = 256 + DEIM."""
+    import torch
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    r = 40
+    coef = torch.randn((F, r), dtype=torch.float64, device=dev, generator=gen) * \
+        (0.85 ** torch.arange(r, dtype=torch.float64, device=dev))[None]
+    modes = torch.randn((r, ep * 3), dtype=torch.float64, device=dev, generator=gen)
+    Xd = 0.1 + coef @ modes                                            # synthetic INPUT only (low rank + noise, SURVEY 8d)
+    Xd += 1e-5 * torch.randn((F, ep * 3), dtype=torch.float64, device=dev, generator=gen)
+    del coef, modes
+    torch.cuda.synchronize()
+    param = types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=F, constProj_p_size=1,
+                                  constProj_massWeight=False, constProj_standarize=True, constProj_orthogonal=False,
+                                  constProj_basis_type="pod_vectorized", deim_desired_num_components=K,
+                                  constProj_store_sing_val=False, constProj_output_directory=".", name="c5", constProj_name="v")
+    ns = nonlinearSnapshots(param, frames_device=(Xd.data_ptr(), F, ep), keepalive=Xd)
+    ns.config()
+    t_prep, _ = _timed(ns.snapshots_prepare, torch.cuda.synchronize)
+    del Xd
+    torch.cuda.empty_cache()
+    sync = ns._engine.sync
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    t_pod, _ = _timed(cc.compute_components_store_singvalues, sync)
+    t_post, _ = _timed(cc.post_process_components, sync)
+    t_deim, _ = _timed(cc.deim, sync)
+    assert len(set(cc.geom_Pt.tolist())) == K
+    M = 3 * ep
+    flops = 2.0 * M * F * F + 2.0 * M * F * K
+    out = {"workload": "config5: %d x 3 constraint rows x %d frames, pod_vectorized K=%d + DEIM, 1 GPU" % (ep, F, K),
+           "ms": t_pod + t_deim, "snapshots_per_s": F / ((t_pod + t_deim) * 1e-3), "prepare_ms": t_prep,
+           "pod_ms": t_pod, "post_process_ms": t_post, "deim_ms": t_deim,
+           "roofline": {"bound": "mfma", "level": "call", "achieved": flops / (t_pod * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flops / (t_pod * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops": flops,
+                        "note": "SURVEY 8(d): 2 M F^2 + 2 M F K f64 flop / POD wall time against the FP64 matrix peak"}}
+    del cc, ns
+    torch.cuda.empty_cache()
+    if cpu:
+        from oracle import asb_oracle as orc
+        import scipy.linalg as sla
+        cores, model = _cpu_info()
+        rng = np.random.default_rng(5)
+        ts_, ms_ = [], (6000, 12000)
+        for m in ms_:                    # two bounded samples, linear fit t = a + b M (the F^3 part does not scale with M)
+            A = rng.normal(size=(m, 40)) @ rng.normal(size=(40, F)) + 1e-5 * rng.normal(size=(m, F))
+            med, _ = _median3(lambda: sla.svd(A, full_matrices=False))
+            ts_.append(med)
+        b = (ts_[1] - ts_[0]) / (ms_[1] - ms_[0])
+        a = ts_[0] - b * ms_[0]
+        full = a + b * M
+        out["cpu_baseline"] = dict(value=F / full, unit="snapshots/s", cores=cores, kind="port", cpu_model=model,
+                                   sample="scipy.linalg.svd (the oracle's pod_vectorized call) on %d x %d and %d x %d samples, "
+                                          "median of 3 each (%.2f s, %.2f s); linear fit in the row count extrapolated to %d rows "
+                                          "(POD only; DEIM not included)" % (ms_[0], F, ms_[1], F, ts_[0], ts_[1], M))
+    return out
 
 
 def main():
@@ -70,7 +244,8 @@ def main():
     ap.add_argument("--frames", type=int, default=2000)
     ap.add_argument("--comps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=18.0)
     args = ap.parse_args()
 
     # native libraries (RCCL prints a version banner) write to fd 1: keep the real stdout for the ONE JSON line
@@ -108,16 +283,16 @@ def main():
     torch.cuda.synchronize()
 
     quiet = io.StringIO()
+    t0 = time.perf_counter()
     with contextlib.redirect_stdout(quiet):
         snaps = posSnapshots.from_device(Xd.data_ptr(), F, n_loc, rest_shape="first", standarize=True, comm=comm,
                                          keepalive=Xd)
+    snaps._engine.sync()
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t0) * 1e3           # layout change + rest shape + standardisation of the resident tensor
     del Xd
     torch.cuda.empty_cache()
-    param = types.SimpleNamespace(vertPos_bases_type="PCA", vertPos_numComponents=K, q_support="global",
-                                  store_vertPos_PCA_sing_val=False, vertPos_smooth_min_dist=0.1,
-                                  vertPos_smooth_max_dist=0.25, q_standarize=True, q_massWeight=False,
-                                  q_orthogonal=False, vertPos_output_directory=".", name="bench")
-    comp = posComponents(param, snaps)
+    comp = posComponents(_pos_param(K, "global"), snaps)
     eng = snaps._engine
 
     def step():
@@ -150,56 +325,90 @@ def main():
     # sanity of the result that was just timed (not a parity test: see tests/)
     assert len(set(comp.selected_vertices.tolist())) == K
     assert np.isfinite(comp.measures_at_largeDeforVerts).all()
+    stats = eng.deflate_stats()
+    # the (K, N, 3) basis back in host memory, as the reference leaves it (rank 0's share; pageable destination)
+    t0 = time.perf_counter()
+    basis = comp.comps if world == 1 else eng.results(want_comps=True, want_weigs=False)["comps"]
+    download_ms = (time.perf_counter() - t0) * 1e3
+    basis_bytes = basis.nbytes
+    del basis
 
     if rank == 0:
+        ms_step = dt / args.steps * 1e3
         value = F * args.steps / dt
-        # dominant kernel: one streaming pass over this rank's shard -- k_project_mfma (projection mode:
-        # one launch per PANEL of up to 16 components) or k_stream (residual mode: one per component).
-        # algorithmic bytes per launch = 24 * n_loc * F (c = 1: one read of the shard)
-        stats = eng.deflate_stats()
-        # HBM traffic from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected
-        # as the microarch guide prescribes; tools/summarise_pmc.py -> profiles/*_pmc_traffic.json).  Per pass over
-        # the shard: k_project_lds takes ceil(F/1008) sweep launches per pass.
-        traffic = None
-        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))["kernels"]
-            kname = {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
-            if getattr(eng, "mode", 0) == 1 and kname in pm and (N, F, world) == (100000, 2000, 1) and \
-                    os.environ.get("ASB_SUPER_PANELS", "0") != "1" and os.environ.get("ASB_L2_VARIANT", "4") == "4":
-                traffic = pm[kname]["hbm_bytes"]
-        except Exception:
-            traffic = None
         mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
-        nsweep = -(-((F + 15) // 16) // 63) if (getattr(eng, "mode", 0) == 1 and pk == 2) else 1   # k_project_lds: sweeps per pass
+        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
+        nsweep = -(-((F + 15) // 16) // 63) if (mode == "project" and pk == 2) else 1   # k_project_lds: sweeps per pass
+        # dominant kernel: one streaming pass over this rank's shard per launch; algorithmic bytes per launch = 24 n_loc F
+        # (c = 1: one read of the shard)
         alg_bytes = 24.0 * n_loc * F / nsweep
         avg_ms = kern_ms / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
+        # HBM traffic of that kernel from the PMC counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+        # this build at this shape (tools/summarise_pmc.py), an OFFLINE measurement committed under profiles/ -- counters
+        # cannot be read from inside the run
+        traffic, traffic_src = None, None
+        kname = {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
+        try:
+            pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+            if mode == "project" and kname in pm["kernels"] and (N, F, world) == (100000, 2000, 1) and \
+                    os.environ.get("ASB_L2_VARIANT", "4") == "4":
+                traffic = pm["kernels"][kname]["hbm_bytes"]
+                traffic_src = PMC_PROFILE + " (offline rocprofv3 --pmc passes of this build and shape, not this run)"
+        except Exception:
+            pass
+        # step level: X is read once per panel pass (+ once for the initial energies when they are not carried over from
+        # the standardisation sweep); 24 N F bytes each
+        reads = launches / max(args.steps, 1) / nsweep + stats.get("energy_passes", 1)      # both per step
+        step_bytes = reads * 24.0 * N * F
+        step_gbs = step_bytes / (ms_step * 1e-3) / 1e9 / world
         out = {
             "metric": "snapshots/sec (SVD+SPLOCS) for n_verts x n_frames; basis Frobenius err vs ref",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config4: synthetic U[-1,1) %d verts x %d frames, greedy-deflation PCA K=%d, "
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": (("k_project_wide<NT,G,1..3> (super-panels: up to 48 columns per read of X)"
-                                     if os.environ.get("ASB_SUPER_PANELS", "0") == "1" and mode == "project" else
-                                     {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma")) +
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": ({2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
                                     " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
-                         "algorithm": mode, "panels_per_step": stats["panels"], "refreshes": stats["refreshes"],
-                         "launches": launches,
+                         "algorithm": mode, "panels_per_step": stats["panels"],
+                         "refreshes": stats["refreshes"], "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         # SURVEY.md 8(d) prices a whole step at 24 N F (1 + K) bytes (one read of X per component);
-                         # the panel algorithm reads X once per PANEL, so the step beats that figure's own roofline
-                         "survey_step_bytes": 24.0 * N * F * (1 + K),
-                         "survey_step_equivalent_GBps": 24.0 * N * F * (1 + K) / (dt / args.steps) / 1e9},
+                         # the whole step against the same peak: what THIS algorithm has to read (one read of X per
+                         # panel pass [+ initial energies]) / ms_per_step, per GPU
+                         "step": {"reads_of_X": reads, "bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                                  "dominant_kernel_share": (kern_ms / args.steps) / ms_step if launches else None},
+                         # SURVEY.md 8(d) priced a step at 24 N F (1 + K) bytes (one read of X per component); the panel
+                         # algorithm commits up to 16 components per read, so that figure is not a roofline for it
+                         "survey_step_bytes": 24.0 * N * F * (1 + K)},
+            "end_to_end": {"prepare_ms": prepare_ms, "step_ms": ms_step, "basis_download_ms": download_ms,
+                           "basis_bytes": basis_bytes, "total_ms": prepare_ms + ms_step + download_ms,
+                           "snapshots_per_s": F / ((prepare_ms + ms_step + download_ms) * 1e-3),
+                           "note": "input already in HBM (F,N,3); prepare = vertex-major layout change + rest shape + "
+                                   "standardisation; download = the (K,N,3) basis into pageable host memory"},
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait for it)
-            out["cpu_baseline"] = cpu_baseline(F, N, K, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline_c4(F, N, K, args.cpu_budget)
+    if world == 1 and not args.no_other_configs and (N, F, K) == (100000, 2000, 128):
+        del comp, snaps, eng
+        torch.cuda.empty_cache()
+        cpu = not args.no_cpu_baseline
+        oc = {}
+        for tag, fn in (("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
+                        ("c2_local", lambda: other_config_pos("config2 (local support)", "c2_bunny_pca_local", "local", "PCA", cpu)),
+                        ("c3", lambda: other_config_pos("config3", "c3_armadillo_splocs", "local", "SPLOCS", cpu)),
+                        ("c5", lambda: other_config_c5(dev, cpu))):
+            try:
+                oc[tag] = fn()
+            except Exception as e:                        # the headline line must still be printed
+                oc[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        out["other_configs"] = oc
+    if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:
         dist.barrier()

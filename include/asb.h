@@ -189,6 +189,14 @@ int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_refresh);
  * selected sequence stays that of the reference loop (posComponents.py:75-77).  tried / kept: such steps in the last
  * run.  ASB_SPEC_PANELS=0 switches them off. */
 int asb_deflate_spec_stats(asb_ctx* ctx, int64_t* tried, int64_t* kept);
+/* reads of the snapshot tensor that the last asb_deflate_begin spent on the initial per-vertex energies ((R**2).sum of
+ * posComponents.py:78-80 at k = 0): 0 when they came with the standardisation sweep (asb_snapshots_scale) or with an
+ * earlier begin on the same, unchanged tensor; 1 otherwise.  ASB_E0_REUSE=0 always recomputes them. */
+int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes);
+/* The panel's inner loop normally runs as ONE launch of co-resident blocks that exchange records through memory
+ * (k_panel_coop).  If that exchange times out -- the blocks were not all resident because something else shares the GPU --
+ * the panel is redone by the two-kernel loop and the context stays on it; *n = how often that happened (lifetime). */
+int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
 /* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
 int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 

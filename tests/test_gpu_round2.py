@@ -1,0 +1,101 @@
+"""GPU (-m gpu): what round 2 added to the projection path --
+  * initial energies carried over from the standardisation sweep (asb_snapshots_scale / k_scale_energy) instead of a
+    read of X per call: same sequence and basis as recomputing them (ASB_E0_REUSE=0), zero energy passes reported;
+  * the one-thread-per-row correction kernel (k_correct_rows) against the per-vertex one (ASB_CORRECT_ROWS=0);
+  * k_panel_coop's record exchange timing out (forced: ASB_COOP_TEST_STALL=1) -> the panel is redone by the two-kernel
+    loop, the context stays on it, results unchanged.
+All against the NumPy oracle (posComponents.py:67-122), index sequence bit-exact."""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import align_signs, relerr
+from oracle import asb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _param(K):
+    return types.SimpleNamespace(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                                 q_support="global", vertPos_numComponents=K, store_vertPos_PCA_sing_val=False,
+                                 vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25, vertPos_rest_shape="first",
+                                 name="t", vertPos_output_directory=".")
+
+
+def _run(verts, K, standarize=True, calls=1):
+    from animsnapbases_amd import posComponents, posSnapshots
+    snaps = posSnapshots.from_arrays(verts, None, "first", standarize=standarize, massWeight=False)
+    comp = posComponents(_param(K), snaps)
+    comp.deflate_mode = "project"
+    stats = []
+    for _ in range(calls):
+        comp.compute_components_store_singvalues()
+        stats.append(snaps._engine.deflate_stats())
+    return comp, stats
+
+
+def _check(comp, d, tol=1e-9):
+    assert comp.selected_vertices.tolist() == d["idx"].tolist()
+    comps, weigs = align_signs(comp.comps, comp.weigs, d["comps"])
+    assert relerr(comps, d["comps"]) < tol and relerr(weigs, d["weigs"]) < tol
+    assert relerr(comp.measures_at_largeDeforVerts[:, 1:], d["measures"][:, 1:]) < 1e-7
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lowrank"])
+def test_initial_energies_from_the_standardisation_sweep(kind, monkeypatch):
+    rng = np.random.default_rng(5)
+    F, N, K = 130, 9000, 40
+    if kind == "uniform":
+        verts = rng.uniform(-1, 1, size=(F, N, 3))
+    else:
+        verts = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=12, seed=5)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    comp, stats = _run(verts, K, calls=2)
+    assert [s["energy_passes"] for s in stats] == [0, 0]          # the energies came with asb_snapshots_scale
+    _check(comp, d)
+    monkeypatch.setenv("ASB_E0_REUSE", "0")
+    comp0, stats0 = _run(verts, K, calls=2)
+    assert [s["energy_passes"] for s in stats0] == [1, 1]
+    _check(comp0, d)
+    assert relerr(comp.comps, comp0.comps) < 1e-12 and relerr(comp.weigs, comp0.weigs) < 1e-12
+    # not standardised: nothing scaled the tensor, so the first call reads X once and later calls reuse that
+    monkeypatch.delenv("ASB_E0_REUSE")
+    compn, statsn = _run(verts, K, standarize=False, calls=3)
+    assert [s["energy_passes"] for s in statsn] == [1, 0, 0]
+    dn = orc.extract_k_components(orc.prepare_snapshots(verts, "first", False)["snapTensor"], K)
+    _check(compn, dn)
+
+
+def test_row_correction_kernel_matches_the_vertex_one(monkeypatch):
+    """Many panels (K = 70 on flat random data: the correction against up to 60 earlier components matters) with and
+    without unproven steps; ragged vertex count (not a multiple of 64)."""
+    rng = np.random.default_rng(9)
+    F, N, K = 90, 20011, 70
+    verts = rng.uniform(-1, 1, size=(F, N, 3)) + 0.3 * rng.normal(size=(F, 1, 3))
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    outs = {}
+    for rows in ("1", "0"):
+        for spec in ("1", "0"):
+            monkeypatch.setenv("ASB_CORRECT_ROWS", rows)
+            monkeypatch.setenv("ASB_SPEC_PANELS", spec)
+            comp, _ = _run(verts, K)
+            _check(comp, d)
+            outs[(rows, spec)] = (comp.comps.copy(), comp.weigs.copy())
+    for spec in ("1", "0"):
+        assert relerr(outs[("1", spec)][0], outs[("0", spec)][0]) < 1e-12
+
+
+def test_panel_kernel_timeout_falls_back_to_the_two_kernel_loop(monkeypatch):
+    rng = np.random.default_rng(13)
+    F, N, K = 100, 12000, 36
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    monkeypatch.setenv("ASB_COOP_TEST_STALL", "1")
+    comp, stats = _run(verts, K, calls=2)
+    assert stats[0]["coop_fallbacks"] == 1 and stats[1]["coop_fallbacks"] == 1      # once; then the context stays off it
+    _check(comp, d)
+    monkeypatch.delenv("ASB_COOP_TEST_STALL")
+    ref, st = _run(verts, K)
+    assert st[0]["coop_fallbacks"] == 0
+    assert relerr(comp.comps, ref.comps) < 1e-11
