@@ -64,6 +64,13 @@ PROTOTYPES = {
     "asb_panel_refresh": (c_int, [ctypes.c_void_p, c_i64, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "asb_deflate_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_deflate_spec_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "asb_sym_eig_topk": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),
+    "asb_pod_basis_dev": (c_int, [ctypes.c_void_p, c_i64]),
+    "asb_pod_rotate": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_dp]),
+    "asb_qr_apply_joint": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "asb_test_tridiag_eig": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),
+    "asb_test_jacobi_rows": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),
+    "asb_test_chol_tinv": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp]),
     "asb_deflate_energy_passes": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),

@@ -8,28 +8,27 @@ row layout as the position path; its Gram matrix A^T A is accumulated with f64 M
 the row shard (partial Gram matrices all-reduced over ranks with RCCL), the K leading
 left singular vectors are formed by the deflation's projection kernel, QR per dimension is
 CholeskyQR2, and each DEIM step's residual GEMV + arg-max runs on the shard.
-Host work, by design: the F x F symmetric eigen-solve (LAPACK ``eigh``) and DEIM's k x k
+The F x F symmetric eigen-problem, the K x K Cholesky factors and the small SVD of the Rayleigh-Ritz
+step run on the device too (csrc/asb_eig.hip, csrc/asb_smalldense.hip).  Host work: DEIM's k x k
 interpolation solves (an O(k^2) bordered-inverse update whose residual is checked every step;
 ``numpy.linalg.lstsq``, the routine the reference calls at constraintsComponents.py:829, is
-the fallback).
+the fallback); LAPACK ``eigh`` on the Gram matrix only with ``ASB_POD_EIG=host``.
 
 Other basis types of the reference (``pod`` per-(p,d) torch SVD, ``pca_blocks``,
 ``pca_blocks_with_St``, geometric / block DEIM, polyscope views) are out of scope
  and raise ``NotImplementedError``.
 """
 import csv
-from concurrent.futures import ThreadPoolExecutor
 import os
 import sys
 
 import numpy as np
-from scipy.linalg import eigh_tridiagonal
 
 from . import _lib
 from ._panels import deflate_panels_multirank
 from .distributed import Comm
 from .engine import HipEngine
-from .utils import log_time, qr_factor, summed_grams, testSparsity, test_linear_dependency, test_linear_dependency_grams
+from .utils import log_time, summed_grams, testSparsity, test_linear_dependency, test_linear_dependency_grams
 
 constProj_output_directory = ""
 
@@ -337,28 +336,21 @@ class constraintsComponents:  # Components == bases
             eng.pod_gram(Gbuf.data_ptr(), to_host=False)
             comm.allreduce_tensor(Gbuf)                      # partial Gram matrices: RCCL all-reduce
         on_dev = os.environ.get("ASB_POD_EIG", getattr(self, "pod_eig", "device")) == "device"
-        if on_dev and (Gbuf is None or Gbuf.is_cuda):
-            # F x F eigen-problem: Householder tridiagonalisation + back-transformation on the device (asb_eig.hip,
-            # ordered reductions -> identical on every rank), LAPACK MRRR on the tridiagonal matrix in between
+        dev_vectors = False
+        if on_dev and F >= 3 and (Gbuf is None or Gbuf.is_cuda):
+            # F x F eigen-problem entirely on the device: Householder tridiagonalisation (asb_eig.hip), bisection + inverse
+            # iteration on the tridiagonal matrix (asb_smalldense.hip), back-transformation; ordered reductions only, so
+            # every rank gets identical values and vectors from its copy of the all-reduced Gram matrix
             if Gbuf is None:
                 eng.pod_gram(to_host=False)
-            gp = Gbuf.data_ptr() if Gbuf is not None else None
-            d, e = eng.sym_tridiag(F, gp)
-            if F > 2:
-                # the full spectrum (only the CSV / `singular_values` need it) is computed by a second LAPACK call
-                # in a worker thread while the K leading vectors are found and back-transformed
-                with ThreadPoolExecutor(1) as pool:
-                    all_vals = pool.submit(eigh_tridiagonal, d, e, eigvals_only=True, lapack_driver='sterf')
-                    _, Z = eigh_tridiagonal(d, e, select='i', select_range=(F - Kv, F - 1), lapack_driver='stemr')
-                    V = eng.sym_backtransform(F, Z[:, ::-1], gp)
-                    lam = all_vals.result()[::-1]
-            else:
-                lam, V = np.linalg.eigh(np.diag(d) + np.diag(e, 1) + np.diag(e, -1))
-                lam, V = lam[::-1], V[:, ::-1][:, :Kv]
-        else:
+            lam, n_bad = eng.sym_eig_topk(F, Kv, Gbuf.data_ptr() if Gbuf is not None else None)
+            if n_bad:
+                print("[asb] POD: %d of %d inverse iterations missed the growth criterion" % (n_bad, Kv))
+            dev_vectors, V = True, None
+        else:       # ASB_POD_EIG=host (explicit) or F < 3: LAPACK on the F x F Gram matrix
             G = Gbuf.cpu().numpy().reshape(F, F) if Gbuf is not None else eng.pod_gram()
             G = 0.5 * (G + G.T)
-            lam, V = np.linalg.eigh(G)                       # host LAPACK on F x F; ascending
+            lam, V = np.linalg.eigh(G)                       # ascending
             lam, V = lam[::-1], V[:, ::-1]
         S = np.sqrt(np.maximum(lam, 0.0))
         self.singular_values = S
@@ -369,34 +361,37 @@ class constraintsComponents:  # Components == bases
                                   "Gram-matrix route resolves (1e-8); ask for fewer components (the snapshot matrix has "
                                   "numerical rank %d)" % (K, K, S[K - 1] / S[0] if S[0] > 0 else 0.0,
                                                           int(np.sum(S > 3e-8 * S[0]))))
-        # Gram-route accuracy of left vector k is eps (sigma_0 / sigma_k)^2.  When the weakest requested component makes
-        # that worse than ~1e-9, refine by Rayleigh-Ritz on A itself: K + p Gram vectors -> orthonormal Q (CholeskyQR2
-        # over all 3 ep entries) -> B = Q^T A (one more pass over A) -> SVD of the small B -> basis = Q U_B.
-        refine = S[0] > 3e3 * S[K - 1] and getattr(self, "pod_refine", True)
+        # Gram-route accuracy of left vector k is eps (sigma_0 / sigma_k)^2, and the device's inverse iteration gives the
+        # vectors of close eigenvalues only as a span.  Rayleigh-Ritz on A itself repairs both: K + p Gram vectors ->
+        # orthonormal Q (CholeskyQR2 with the joint Gram matrix over all 3 ep entries, blocked Cholesky on the device) ->
+        # B = Q^T A (one more pass over A) -> left vectors / singular values of the small B by one-sided Jacobi on the
+        # device -> basis = Q U_B.  Always on with the device eigen-solver; with host LAPACK vectors only when the
+        # weakest requested component makes the Gram route worse than ~1e-9.
+        refine = (dev_vectors or S[0] > 3e3 * S[K - 1]) and getattr(self, "pod_refine", True)
         if refine:
             Kx = int(min(Kv, np.sum(S > 3e-8 * S[0])))
-            eng.pod_basis(np.ascontiguousarray(V[:, :Kx]), S[:Kx])
-            for _ in range(2):
-                G3 = summed_grams(eng, comm, Kx)
-                T = qr_factor(np.broadcast_to(G3.sum(axis=0), (3, Kx, Kx)).copy())       # one factor for all three slices
-                eng.components_transform(T)
-            if comm.multi:
-                Bbuf = comm.new_buffer(Kx * F, eng.device_exchange)
-                eng.pod_project(Bbuf.data_ptr(), to_host=False)
-                comm.allreduce_tensor(Bbuf)
-                B = Bbuf.cpu().numpy().reshape(Kx, F)
+            if dev_vectors:
+                eng.pod_basis_dev(Kx)
             else:
-                B = eng.pod_project()
-            # left singular vectors of the wide B (Kx x F) from the small triangular factor of B^T = Q_b R_b:
-            # B = R_b^T Q_b^T, so they are those of R_b^T (Kx x Kx) -- a few ms instead of 0.6 s for gesdd on B itself
-            Rb = np.linalg.qr(B.T, mode="r")
-            Ub, Sb, _ = np.linalg.svd(Rb.T)
-            eng.components_transform(np.broadcast_to(Ub, (3, Kx, Kx)).copy())
+                eng.pod_basis(np.ascontiguousarray(V[:, :Kx]), S[:Kx])
+            for _ in range(2):
+                Gq = comm.new_buffer(3 * Kx * Kx, eng.device_exchange) if comm.multi else None
+                eng.orth_gram(Gq.data_ptr() if Gq is not None else None)
+                if Gq is not None:
+                    comm.allreduce_tensor(Gq)
+                eng.qr_apply_joint(Gq.data_ptr() if Gq is not None else None)       # one factor for all three slices
+            Bbuf = comm.new_buffer(Kx * F, eng.device_exchange) if comm.multi else None
+            eng.pod_project(Bbuf.data_ptr() if Bbuf is not None else None, to_host=False)
+            if Bbuf is not None:
+                comm.allreduce_tensor(Bbuf)
+            Sb = eng.pod_rotate(Bbuf.data_ptr() if Bbuf is not None else None)
             S = S.copy()
             S[:Kx] = Sb
             self.singular_values = S
             if Kx > K:                                  # drop the oversampling vectors again
                 eng.components_truncate(K)
+        elif dev_vectors:
+            eng.pod_basis_dev(K)
         else:
             eng.pod_basis(np.ascontiguousarray(V[:, :K]), S[:K])
         if writer is not None:
@@ -420,15 +415,12 @@ class constraintsComponents:  # Components == bases
             eng.snapshots_affine(1.0 / ns.pre_scale_factor, True, None)        # also restore the snapshots (:424-428)
             ns._snapTensor = None
         if p.constProj_orthogonal:
-            for _ in range(2):                                                 # CholeskyQR2
-                if self.numComp <= 128:                                        # one-block Cholesky on the device
-                    Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.multi else None
-                    eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
-                    if Gbuf is not None:
-                        comm.allreduce_tensor(Gbuf)
-                    eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
-                else:                                    # larger K: K x K Cholesky on the host, products on the device
-                    eng.components_transform(qr_factor(summed_grams(eng, comm, self.numComp)))
+            for _ in range(2):                                                 # CholeskyQR2, any K, on the device
+                Gbuf = comm.new_buffer(3 * self.numComp * self.numComp, eng.device_exchange) if comm.multi else None
+                eng.orth_gram(Gbuf.data_ptr() if Gbuf is not None else None)
+                if Gbuf is not None:
+                    comm.allreduce_tensor(Gbuf)
+                eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
         if p.constProj_massWeight:
             assert ns.frames_rows == ns.invMassL.shape[0]
             eng.components_post(False, 1.0, ns.invMassL[v0:v0 + n_loc])

@@ -155,6 +155,14 @@ struct asb_ctx {
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
     double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
     int64_t td_n = 0;
+    // asb_smalldense.hip: tridiagonal eigen-solver, one-sided Jacobi, blocked Cholesky
+    double* tri_work = nullptr;
+    unsigned char* tri_swp = nullptr;
+    double *jac_q = nullptr, *jac_sig = nullptr, *jac_a = nullptr;
+    int* jac_where = nullptr;
+    double* chol_w = nullptr;
+    double *eig_lam = nullptr, *eig_v = nullptr;  // asb_sym_eig_topk: eigenvalues (n, descending), leading vectors (n x k)
+    int64_t eig_n = 0, eig_k = 0;
 
     // ---- profiling of the dominant streaming kernel ----
     bool prof = false;
@@ -180,6 +188,13 @@ static inline int asb_gemm_tn(asb_ctx* ctx, const double* A, long long lda, cons
 int asb_transpose(asb_ctx* ctx, const double* in, long long rows, long long cols, double* out);   // (rows x cols) -> (cols x rows)
 // eigen-decomposition of a symmetric n x n matrix (n <= 128) on the device: lam (n) descending, V (n x n) columns
 int asb_sym_eig(asb_ctx* ctx, const double* A_dev, int n, double* lam_dev, double* V_dev);
+// asb_smalldense.hip
+int asb_tri_eig_dev(asb_ctx* ctx, const double* d, const double* e, int n, int k, double* lam_desc, double* Z, int* n_bad);
+int asb_jacobi_rows_dev(asb_ctx* ctx, double* A, int nv, int m, long long lda, double* Q_sorted, int q_transposed,
+                        double* sig_sorted, int* sweeps_out);
+int asb_sym_eig_large(asb_ctx* ctx, const double* A_dev, int n, double* lam_dev, double* V_dev);
+int asb_chol_tinv_dev(asb_ctx* ctx, const double* G, int K, double* Tt, int* status_dev);
+int asb_components_transform_dev(asb_ctx* ctx, const double* T_dev, int same_T);      // asb_linalg.hip
 int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local);
 
 #define ASB_FAIL(ctx, code, ...)                                   \

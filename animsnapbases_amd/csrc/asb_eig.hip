@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void k_symmetrize(double* __restrict__ A, int 
     }
 }
 
-extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host, double* e_host) {
-    if (!ctx || !d_host || !e_host || n64 < 1) return ASB_ERR_ARG;
+// device part of asb_sym_tridiag: d, e stay in ctx->td_work (d at 6 n, e at 7 n); host copies when the pointers are given
+static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host, double* e_host) {
+    if (!ctx || n64 < 1) return ASB_ERR_ARG;
     double* A = A_dev ? A_dev : ctx->pod_g;
     if (!A) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_sym_tridiag: no matrix (run asb_pod_gram first or pass A_dev)");
     if (n64 > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: n = %lld too large", (long long)n64);
@@ -179,17 +180,13 @@ extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double*
     double* e = d + n;
     ASB_HIP(ctx, hipMemsetAsync(ctx->td_work, 0, (size_t)8 * n * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_symmetrize, dim3(2048), dim3(256), 0, ctx->stream, A, n);
-    if (n == 1) {
-        ASB_HIP(ctx, hipMemcpyAsync(d_host, A, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (n <= 2) {
+        if (!d_host || !e_host) ASB_FAIL(ctx, ASB_ERR_ARG, "the device eigen-solver needs n >= 3 (n = %d)", n);
+        double h[4] = {0, 0, 0, 0};
+        ASB_HIP(ctx, hipMemcpyAsync(h, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->td_n = n;
-        return ASB_OK;
-    }
-    if (n == 2) {
-        double h[4];
-        ASB_HIP(ctx, hipMemcpyAsync(h, A, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        d_host[0] = h[0]; d_host[1] = h[3]; e_host[0] = h[2];
+        d_host[0] = h[0];
+        if (n == 2) { d_host[1] = h[3]; e_host[0] = h[2]; }
         ctx->td_n = n;
         return ASB_OK;
     }
@@ -211,10 +208,62 @@ extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double*
         }
     }
     ASB_CHECK_LAUNCH(ctx);
-    ASB_HIP(ctx, hipMemcpyAsync(d_host, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipMemcpyAsync(e_host, e, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->td_n = n;
+    if (d_host && e_host) {
+        ASB_HIP(ctx, hipMemcpyAsync(d_host, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(e_host, e, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ASB_OK;
+}
+
+extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host, double* e_host) {
+    if (!ctx || !d_host || !e_host || n64 < 1) return ASB_ERR_ARG;
+    return sym_tridiag(ctx, A_dev, n64, d_host, e_host);
+}
+
+// Z (device, n x k row-major) -> V = Q Z (device, n x k) with the reflectors asb_sym_tridiag left in A
+static int sym_backtransform_dev(asb_ctx* ctx, const double* A, int n, const double* Z, int k, double* V) {
+    const double* tau = ctx->td_work + (size_t)5 * n;
+    int wpb = (int)((size_t)(160 * 1024 - 1024) / ((size_t)n * sizeof(double)));
+    if (wpb < 1) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_backtransform: n = %d does not fit one LDS column", n);
+    if (wpb > 4) wpb = 4;
+    const size_t lds = (size_t)wpb * n * sizeof(double);
+    if (lds > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_td_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_td_back, dim3((k + wpb - 1) / wpb), dim3(256), lds, ctx->stream, A, tau, n, Z, k, V, wpb);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+// The whole symmetric eigen-problem on the device (n >= 3): Householder tridiagonalisation, bisection + inverse iteration
+// on the tridiagonal matrix (asb_smalldense.hip), back-transformation.  A_dev (NULL: the Gram matrix of asb_pod_gram) is
+// overwritten.  lam_host (n): ALL eigenvalues, descending.  The k leading eigenvectors stay on the device (n x k,
+// row-major) for asb_pod_basis_dev; V_host (optional, n x k) receives a copy.  *n_bad (optional): vectors whose inverse
+// iteration missed its growth criterion (0 in every case seen; they are still normalised iterates).
+extern "C" int asb_sym_eig_topk(asb_ctx* ctx, double* A_dev, int64_t n64, int64_t k64, double* lam_host, double* V_host,
+                                int64_t* n_bad) {
+    if (!ctx || !lam_host || n64 < 3 || k64 < 1 || k64 > n64) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = sym_tridiag(ctx, A_dev, n64, nullptr, nullptr))) return rc;
+    const int n = (int)n64, k = (int)k64;
+    const double* A = A_dev ? A_dev : ctx->pod_g;
+    if ((rc = asb_alloc(ctx, &ctx->td_z, (size_t)2 * n * k))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->eig_lam, (size_t)n))) return rc;
+    double* Z = ctx->td_z;
+    double* V = Z + (size_t)n * k;
+    const double* d = ctx->td_work + (size_t)6 * n;
+    const double* e = ctx->td_work + (size_t)7 * n;
+    int bad = 0;
+    if ((rc = asb_tri_eig_dev(ctx, d, e, n, k, ctx->eig_lam, Z, &bad))) return rc;
+    if ((rc = sym_backtransform_dev(ctx, A, n, Z, k, V))) return rc;
+    ctx->eig_v = V;
+    ctx->eig_n = n;
+    ctx->eig_k = k;
+    ASB_HIP(ctx, hipMemcpyAsync(lam_host, ctx->eig_lam, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (V_host) ASB_HIP(ctx, hipMemcpyAsync(V_host, V, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_bad) *n_bad = bad;
     return ASB_OK;
 }
 
@@ -230,15 +279,7 @@ extern "C" int asb_sym_backtransform(asb_ctx* ctx, const double* A_dev, int64_t 
     double* Z = ctx->td_z;
     double* V = Z + (size_t)n * k;
     ASB_HIP(ctx, hipMemcpyAsync(Z, Z_host, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    const double* tau = ctx->td_work + (size_t)5 * n;
-    int wpb = (int)((size_t)(160 * 1024 - 1024) / ((size_t)n * sizeof(double)));
-    if (wpb < 1) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_backtransform: n = %d does not fit one LDS column", n);
-    if (wpb > 4) wpb = 4;
-    const size_t lds = (size_t)wpb * n * sizeof(double);
-    if (lds > 48 * 1024)
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_td_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_td_back, dim3((k + wpb - 1) / wpb), dim3(256), lds, ctx->stream, A, tau, n, Z, k, V, wpb);
-    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = sym_backtransform_dev(ctx, A, n, Z, k, V))) return rc;
     ASB_HIP(ctx, hipMemcpyAsync(V_host, V, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;

@@ -344,7 +344,13 @@ __global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ 
 }
 
 int asb_sym_eig(asb_ctx* ctx, const double* A_dev, int n, double* lam_dev, double* V_dev) {
-    if (n < 1 || n > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "device eigen-solver supports n <= 128 (n = %d)", n);
+    if (n < 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_sym_eig: n = %d", n);
+    if (n > 128) {      // beyond one block's LDS: one-sided Jacobi on the rows, one launch per round (positive semi-definite input)
+        int rc0;
+        if ((rc0 = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc0;
+        ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+        return asb_sym_eig_large(ctx, A_dev, n, lam_dev, V_dev);
+    }
     const int ne = n + (n & 1);
     const size_t lds = ((size_t)ne * ne + ne) * sizeof(double) + (size_t)ne * sizeof(int) + 64;
     static size_t attr = 0;
@@ -403,11 +409,10 @@ extern "C" int asb_orth_gram(asb_ctx* ctx, double* G_dev) {
 extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_out) {
     if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
     const int64_t K = ctx->K, n = ctx->n_loc;
-    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_orth_apply: the one-block eigen-solver takes K <= 128 (K = %lld); "
-                          "use asb_orth_gram_get + asb_components_transform", (long long)K);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->olam, (size_t)3 * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->osing, (size_t)3 * K))) return rc;
     if (G_dev) ASB_HIP(ctx, hipMemcpyAsync(ctx->og, G_dev, (size_t)3 * K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -417,7 +422,7 @@ extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_ou
         double* Gl = ctx->og + (size_t)l * K * K;
         double* Vl = ctx->ovec + (size_t)l * K * K;
         if ((rc = asb_sym_eig(ctx, Gl, (int)K, ctx->olam + l * K, Vl))) return rc;
-        hipLaunchKernelGGL(k_scale_eigvecs, dim3(1), dim3(256), 0, ctx->stream, Vl, ctx->olam + l * K, (int)K,
+        hipLaunchKernelGGL(k_scale_eigvecs, dim3(1), dim3(1024), 0, ctx->stream, Vl, ctx->olam + l * K, (int)K,
                            Nmax * 2.220446049250313e-16, Gl, ctx->osing + l * K, ctx->la_status);
         ASB_CHECK_LAUNCH(ctx);
         int st[4];
@@ -472,18 +477,26 @@ extern "C" int asb_orth_gram_get(asb_ctx* ctx, double* G_host) {
 // comps[:, :, l] <- T_l^T-combination of the components: new_j = sum_i comps_i T[l][i][j]  (T host, (3, K, K) row-major).
 // The K x K factor of an orthogonalisation whose small dense step ran on the host (K > 128: orth = V S^-1 of the Gram
 // matrix's eigen-decomposition, qr = L^-T of its Cholesky factor); needs asb_orth_gram to have been called.
-extern "C" int asb_components_transform(asb_ctx* ctx, const double* T_host) {
-    if (!ctx || !ctx->comps || !ctx->oct || !T_host) return ASB_ERR_ARG;
+// device form: T_dev (K x K) for all three slices (same_T) or (3, K, K); no synchronisation
+int asb_components_transform_dev(asb_ctx* ctx, const double* T_dev, int same_T) {
     const int64_t K = ctx->K, n = ctx->n_loc;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
-    ASB_HIP(ctx, hipMemcpyAsync(ctx->ovec, T_host, (size_t)3 * K * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     for (int l = 0; l < 3; ++l)
-        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, ctx->ovec + (size_t)l * K * K, K, K, (int)n, (int)K, ctx->comps2 + l, 3,
-                                3 * n)))
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, T_dev + (same_T ? 0 : (size_t)l * K * K), K, K, (int)n, (int)K,
+                                ctx->comps2 + l, 3, 3 * n)))
             return rc;
     ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+
+extern "C" int asb_components_transform(asb_ctx* ctx, const double* T_host) {
+    if (!ctx || !ctx->comps || !T_host) return ASB_ERR_ARG;
+    const int64_t K = ctx->K;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->ovec, T_host, (size_t)3 * K * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = asb_components_transform_dev(ctx, ctx->ovec, 0))) return rc;
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }

@@ -139,32 +139,93 @@ __global__ __launch_bounds__(256) void k_chol_tinv(const double* __restrict__ G,
     }
 }
 
-// one CholeskyQR pass per dimension with the (all-reduced) Gram matrices of asb_orth_gram:
-// comps[:,:,l] <- (A_l L^-T)^T.  Call twice (Gram, apply, Gram, apply) for CholeskyQR2.
-extern "C" int asb_qr_apply(asb_ctx* ctx, const double* G_dev) {
+// sum of the three per-dimension Gram matrices (the joint Gram of the (3 n) x K basis) into slice 0
+__global__ __launch_bounds__(256) void k_sum3(double* __restrict__ G, long long kk) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < kk; e += (long long)gridDim.x * 256)
+        G[e] = (G[e] + G[kk + e]) + G[2 * kk + e];
+}
+
+// one CholeskyQR pass with the (all-reduced) Gram matrices of asb_orth_gram: comps[:,:,l] <- (A_l L_l^-T)^T per dimension
+// (joint = 0: `qr(comps[:,:,l].T, mode='economic')[0].T`, constraintsComponents.py:431-435), or with ONE factor of the summed
+// Gram matrix for all three slices (joint = 1: orthonormal (3 n)-vectors, the Rayleigh-Ritz basis of the POD refinement).
+// K <= 128: Cholesky + inverse in one block's LDS; larger K: blocked (asb_smalldense.hip).  Call twice for CholeskyQR2.
+static int qr_apply(asb_ctx* ctx, const double* G_dev, int joint) {
     if (!ctx || !ctx->comps || !ctx->oct) return ASB_ERR_ARG;
     const int64_t K = ctx->K, n = ctx->n_loc;
-    if (K > 128) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_qr_apply: the one-block Cholesky takes K <= 128 (K = %lld); "
-                          "use asb_orth_gram_get + asb_components_transform", (long long)K);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * 3 * n))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
     if (G_dev) ASB_HIP(ctx, hipMemcpyAsync(ctx->og, G_dev, (size_t)3 * K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+    if (joint) hipLaunchKernelGGL(k_sum3, dim3(256), dim3(256), 0, ctx->stream, ctx->og, (long long)K * K);
     const size_t lds = (size_t)K * K * sizeof(double);
-    if (lds > 48 * 1024) ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_chol_tinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int l = 0; l < 3; ++l) {
+    if (K <= 128 && lds > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_chol_tinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int l = 0; l < (joint ? 1 : 3); ++l) {
         double* Tt = ctx->ovec + (size_t)l * K * K;
-        hipLaunchKernelGGL(k_chol_tinv, dim3(1), dim3(256), lds, ctx->stream, ctx->og + (size_t)l * K * K, (int)K, Tt, ctx->la_status);
-        ASB_CHECK_LAUNCH(ctx);
-        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, Tt, K, K, (int)n, (int)K, ctx->comps2 + l, 3, 3 * n))) return rc;
+        if (K <= 128) {
+            hipLaunchKernelGGL(k_chol_tinv, dim3(1), dim3(256), lds, ctx->stream, ctx->og + (size_t)l * K * K, (int)K, Tt, ctx->la_status);
+            ASB_CHECK_LAUNCH(ctx);
+        } else if ((rc = asb_chol_tinv_dev(ctx, ctx->og + (size_t)l * K * K, (int)K, Tt, ctx->la_status))) {
+            return rc;
+        }
     }
+    for (int l = 0; l < 3; ++l)
+        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, ctx->ovec + (joint ? 0 : (size_t)l * K * K), K, K, (int)n, (int)K,
+                                ctx->comps2 + l, 3, 3 * n)))
+            return rc;
     int st[4];
     ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (st[0]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "QR: a coordinate slice of the basis is rank deficient");
     ASB_HIP(ctx, hipMemcpyAsync(ctx->comps, ctx->comps2, (size_t)K * 3 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ASB_OK;
+}
+extern "C" int asb_qr_apply(asb_ctx* ctx, const double* G_dev) { return qr_apply(ctx, G_dev, 0); }
+extern "C" int asb_qr_apply_joint(asb_ctx* ctx, const double* G_dev) { return qr_apply(ctx, G_dev, 1); }
+
+// sigma[i] = sqrt(max(lam[i], 0))
+__global__ __launch_bounds__(256) void k_sqrt_pos(const double* __restrict__ lam, long long n, double* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = sqrt(fmax(lam[i], 0.0));
+}
+
+// comps[i] = X . V[:, i] / sigma[i] for i < K from the eigen-pairs asb_sym_eig_topk left on the device (no host copy)
+extern "C" int asb_pod_basis_dev(asb_ctx* ctx, int64_t K) {
+    if (!ctx || !ctx->X || K < 1) return ASB_ERR_ARG;
+    if (!ctx->eig_v || ctx->eig_n != ctx->F || K > ctx->eig_k)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_basis_dev: asb_sym_eig_topk has not left %lld vectors of an F = %lld problem", (long long)K,
+                 (long long)ctx->F);
+    const int64_t n3 = 3 * ctx->n_loc;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_s, (size_t)K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+    ctx->K = K;
+    hipLaunchKernelGGL(k_sqrt_pos, dim3(4), dim3(256), 0, ctx->stream, ctx->eig_lam, (long long)K, ctx->pod_s);
+    ASB_CHECK_LAUNCH(ctx);
+    for (int64_t k0 = 0; k0 < K; k0 += 16) {
+        const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
+        if ((rc = asb_project_columns(ctx, ctx->eig_v, ctx->eig_k, k0, nc, ctx->comps + (size_t)k0 * n3, ctx->pod_s))) return rc;
+    }
+    return ASB_OK;
+}
+
+// Rayleigh-Ritz rotation: the (all-reduced) K x F matrix B = Q^T A (B_dev, or the one asb_pod_project left in the context;
+// overwritten) -> its singular values S_host (K, descending) and left vectors U_B by one-sided Jacobi on its rows, then
+// basis <- Q U_B.  The device counterpart of the small SVD the reference gets from gesdd on A itself (:307).
+extern "C" int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host) {
+    if (!ctx || !ctx->comps || !S_host) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, F = ctx->F;
+    double* B = B_dev ? B_dev : ctx->pod_v;
+    if (!B) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_rotate: no B (run asb_pod_project first or pass B_dev)");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->ovec, (size_t)3 * K * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->olam, (size_t)3 * K))) return rc;
+    if ((rc = asb_jacobi_rows_dev(ctx, B, (int)K, (int)F, F, ctx->ovec, 1, ctx->olam, nullptr))) return rc;
+    if ((rc = asb_components_transform_dev(ctx, ctx->ovec, 1))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(S_host, ctx->olam, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }
 

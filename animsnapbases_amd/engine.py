@@ -405,6 +405,52 @@ class HipEngine(object):
                                                 int(Z.shape[1]), ptr(V)))
         return V
 
+    def sym_eig_topk(self, n, k, A_dev_ptr=None, want_vectors=False):
+        """All eigenvalues (descending) of the n x n symmetric device matrix (default: the POD Gram matrix) and its k
+        leading eigenvectors, entirely on the device; the vectors stay there for ``pod_basis_dev``."""
+        lam = np.empty(n)
+        V = np.empty((n, k)) if want_vectors else None
+        bad = ctypes.c_int64()
+        self._ck(self.lib.asb_sym_eig_topk(self.h, ctypes.c_void_p(A_dev_ptr) if A_dev_ptr else None, int(n), int(k), ptr(lam),
+                                           ptr(V), ctypes.byref(bad)))
+        return (lam, V, bad.value) if want_vectors else (lam, bad.value)
+
+    def pod_basis_dev(self, K):
+        self._ck(self.lib.asb_pod_basis_dev(self.h, int(K)))
+        self.K = int(K)
+
+    def pod_rotate(self, B_dev_ptr=None):
+        S = np.empty(self.K)
+        self._ck(self.lib.asb_pod_rotate(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, ptr(S)))
+        return S
+
+    def qr_apply_joint(self, G_dev_ptr=None):
+        self._ck(self.lib.asb_qr_apply_joint(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
+
+    # host-array probes of the small dense device solvers (tests)
+    def test_tridiag_eig(self, d, e, k):
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        n = d.shape[0]
+        lam, Z, bad = np.empty(n), np.empty((n, max(k, 1))), ctypes.c_int64()
+        self._ck(self.lib.asb_test_tridiag_eig(self.h, ptr(d), ptr(e) if n > 1 else ptr(np.zeros(1)), n, int(k), ptr(lam),
+                                               ptr(Z), ctypes.byref(bad)))
+        return lam, Z[:, :k], bad.value
+
+    def test_jacobi_rows(self, A, want_u=True):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        nv, m = A.shape
+        U = np.empty((nv, nv)) if want_u else None
+        sig, sw = np.empty(nv), ctypes.c_int64()
+        self._ck(self.lib.asb_test_jacobi_rows(self.h, ptr(A), nv, m, ptr(U), ptr(sig), ctypes.byref(sw)))
+        return U, sig, sw.value
+
+    def test_chol_tinv(self, G):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        Tt = np.empty_like(G)
+        self._ck(self.lib.asb_test_chol_tinv(self.h, ptr(G), G.shape[0], ptr(Tt)))
+        return Tt
+
     def snapshots_affine(self, inv_scale, add_mean, rowscale_loc=None):
         if rowscale_loc is not None:
             rowscale_loc = np.ascontiguousarray(rowscale_loc, dtype=np.float64)

@@ -306,16 +306,13 @@ class posComponents:  # Components == bases
         loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None)
         if self.param.q_orthogonal:
             K = self.numComp
-            if K <= 128:                # Gram -> one-block Jacobi eigen-solver -> U = A V S^-1, all on the device
-                Gbuf = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
-                gp = Gbuf.data_ptr() if Gbuf is not None else None
-                eng.orth_gram(gp)
-                if Gbuf is not None:
-                    comm.allreduce_tensor(Gbuf)
-                self.ortho_sing_vals = eng.orth_apply(gp)
-            else:                       # larger K: the K x K eigen-problem on the host, the N x K products on the device
-                T, self.ortho_sing_vals = _u.orth_factor(_u.summed_grams(eng, comm, K), snaps.nVerts)
-                eng.components_transform(T)
+            # Gram -> K x K Jacobi eigen-solver -> U = A V S^-1, all on the device (any K)
+            Gbuf = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
+            gp = Gbuf.data_ptr() if Gbuf is not None else None
+            eng.orth_gram(gp)
+            if Gbuf is not None:
+                comm.allreduce_tensor(Gbuf)
+            self.ortho_sing_vals = eng.orth_apply(gp)
             # the Gram route leaves U^T U = I + O(eps cond^2): one Newton-Schulz step with the Gram of U removes it
             Gbuf = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
             gp = Gbuf.data_ptr() if Gbuf is not None else None

@@ -76,7 +76,7 @@ def read_components_bin(path):
     return np.ascontiguousarray(body.reshape(3, K, N).transpose(1, 2, 0))
 
 
-# ------------------------------------------------------------------ K x K steps of the orthogonalisations (K > 128)
+# ------------------------------------------------------------------ K x K Gram matrices of the basis (rank diagnostic)
 def summed_grams(eng, comm, K):
     """The three per-dimension K x K Gram matrices of the device-resident basis, summed over the ranks, on the host."""
     if comm.multi:
@@ -88,35 +88,6 @@ def summed_grams(eng, comm, K):
         eng.orth_gram(None)
         G = eng.orth_gram_get()
     return 0.5 * (G + G.transpose(0, 2, 1))
-
-
-def orth_factor(G, n_rows):
-    """T_l = V S^-1 of G_l = V S^2 V^T (descending): A_l T_l are the left singular vectors scipy's orth returns
-    (up to sign); raises when a slice is rank deficient by orth's own tolerance.  Returns (T (3,K,K), S (3,K))."""
-    K = G.shape[1]
-    T, S = np.empty_like(G), np.empty((3, K))
-    for l in range(3):
-        lam, V = np.linalg.eigh(G[l])
-        lam, V = lam[::-1], V[:, ::-1]
-        s = np.sqrt(np.maximum(lam, 0.0))
-        if not s[-1] > max(n_rows, K) * np.finfo(float).eps * s[0]:
-            raise ArithmeticError("orthogonalisation: the basis is rank deficient in dimension %d "
-                                  "(scipy.linalg.orth would drop vectors)" % l)
-        T[l], S[l] = V / s[None, :], s
-    return T, S
-
-
-def qr_factor(G):
-    """T_l = L^-T with G_l = L L^T: A_l T_l is the Q of the economic QR of A_l (CholeskyQR; column signs positive)."""
-    from scipy.linalg import cholesky, solve_triangular
-    T = np.empty_like(G)
-    for l in range(3):
-        try:
-            L = cholesky(G[l], lower=True)
-        except np.linalg.LinAlgError:
-            raise ArithmeticError("QR: a coordinate slice of the basis is rank deficient")
-        T[l] = solve_triangular(L, np.eye(G.shape[1]), lower=True).T
-    return T
 
 
 # ------------------------------------------------------------------ printed checks

@@ -210,7 +210,8 @@ int asb_components_post(asb_ctx* ctx, int unscale, double pre_scale_factor,
                         const double* invMassL_loc, double* comps_out);
 
 /* :284-287 `comps[:,:,l] = orth(comps[:,:,l].T).T` (scipy's SVD-based orth) per dimension,
- * as Gram (MFMA) -> K x K Jacobi eigen-solve -> U = A V S^-1, all on the device (K <= 128).
+ * as Gram (MFMA) -> K x K Jacobi eigen-solve -> U = A V S^-1, all on the device (K <= 128: parallel Jacobi in one
+ * block's LDS; larger K: one-sided Jacobi on the rows of the Gram matrix, csrc/asb_smalldense.hip).
  * asb_orth_gram: this shard's three K x K Gram matrices into G_dev (3*K*K doubles, caller's
  * device buffer to be all-reduced over ranks) or into the context when NULL.
  * asb_orth_apply: finishes with the (summed) Gram matrices; sing_out (host, 3*K, optional).
@@ -289,11 +290,28 @@ int asb_components_truncate(asb_ctx* ctx, int64_t K);
  * asb_sym_backtransform: V = Q Z for k eigenvectors Z of T (host, n x k row-major) -> V_host (n x k). */
 int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n, double* d_host, double* e_host);
 int asb_sym_backtransform(asb_ctx* ctx, const double* A_dev, int64_t n, const double* Z_host, int64_t k, double* V_host);
+/* The same eigen-problem with NOTHING on the host (n >= 3): tridiagonalisation, then all eigenvalues of T by bisection
+ * on Sturm counts and its k leading eigenvectors by inverse iteration (csrc/asb_smalldense.hip), then the
+ * back-transformation.  lam_host (n): all eigenvalues, descending; the k vectors stay on the device for
+ * asb_pod_basis_dev (V_host, optional n x k row-major, receives a copy); *n_bad (optional): inverse iterations that missed
+ * their growth criterion.  Vectors of eigenvalues closer than ~eps |T| / 1e-5 are accurate as a SPAN, not one by one
+ * (no re-orthogonalisation inside clusters): the POD follows with a Rayleigh-Ritz step on the snapshot matrix. */
+int asb_sym_eig_topk(asb_ctx* ctx, double* A_dev, int64_t n, int64_t k, double* lam_host, double* V_host, int64_t* n_bad);
+/* asb_pod_basis from the eigen-pairs asb_sym_eig_topk left on the device: comps[i] = A V[:, i] / sqrt(lam[i]), i < K */
+int asb_pod_basis_dev(asb_ctx* ctx, int64_t K);
+/* Rayleigh-Ritz rotation on the device: singular values (S_host, K, descending) and left vectors U_B of the (all-reduced)
+ * K x F matrix B = Q^T A (B_dev, or the context's from asb_pod_project; overwritten) by one-sided Jacobi on its rows;
+ * basis <- Q U_B.  Replaces the small host SVD between asb_pod_project and asb_components_transform. */
+int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host);
+/* asb_qr_apply with ONE Cholesky factor of the sum of the three Gram matrices for all three slices: the basis becomes
+ * orthonormal as (3 n)-vectors (the Q of the Rayleigh-Ritz step).  Any K. */
+int asb_qr_apply_joint(asb_ctx* ctx, const double* G_dev);
 /* :421-428 / :440-443 the reference also restores the snapshot tensor:
  * X <- (X * inv_scale + mean) * rowscale[v]   (rowscale host n_loc or NULL) */
 int asb_snapshots_affine(asb_ctx* ctx, double inv_scale, int add_mean, const double* rowscale);
 /* :430-433 `qr(comps[:,:,l].T, mode='economic')[0].T`: one CholeskyQR pass per dimension with the
- * Gram matrices of asb_orth_gram (NULL: the context's).  Call gram/apply twice (CholeskyQR2). K <= 128. */
+ * Gram matrices of asb_orth_gram (NULL: the context's).  Call gram/apply twice (CholeskyQR2).  K <= 128: one block's
+ * LDS; larger K (the reference's configurations use 200 ... 1000): blocked Cholesky + inverse, csrc/asb_smalldense.hip. */
 int asb_qr_apply(asb_ctx* ctx, const double* G_dev);
 /* deim, :797-860, device half: residual r = V[:, :k] coef - v_k per dimension and its arg-max over this
  * shard (global row index).  coef: host (3, k), NULL for k = 0.  The k x k interpolation solves stay with
@@ -330,6 +348,14 @@ int asb_splocs_objective(asb_ctx* ctx, const double* P_dev, const double* M_dev,
 int asb_splocs_results(asb_ctx* ctx, double* C_out, double* W_out);
 
 /* ------------------------------------------------ host-side probes ----------- */
+/* the small dense solvers of csrc/asb_smalldense.hip on host arrays (tests):
+ * tridiagonal (d, e) -> all eigenvalues descending + k leading unit eigenvectors Z (n x k row-major);
+ * one-sided Jacobi on the rows of A (nv x m): singular values descending, left vectors as COLUMNS of U (nv x nv, optional);
+ * Tt[c][i] = (L^-1)[i][c] of the Cholesky factor G = L L^T (any K). */
+int asb_test_tridiag_eig(asb_ctx* ctx, const double* d, const double* e, int64_t n, int64_t k, double* lam_desc, double* Z,
+                         int64_t* n_bad);
+int asb_test_jacobi_rows(asb_ctx* ctx, const double* A, int64_t nv, int64_t m, double* U, double* sig, int64_t* sweeps);
+int asb_test_chol_tinv(asb_ctx* ctx, const double* G, int64_t K, double* Tt);
 /* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
  * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */
 void asb_test_eig3(const double* a6, double* out4);
