@@ -422,7 +422,7 @@ extern "C" int asb_orth_apply(asb_ctx* ctx, const double* G_dev, double* sing_ou
         double* Gl = ctx->og + (size_t)l * K * K;
         double* Vl = ctx->ovec + (size_t)l * K * K;
         if ((rc = asb_sym_eig(ctx, Gl, (int)K, ctx->olam + l * K, Vl))) return rc;
-        hipLaunchKernelGGL(k_scale_eigvecs, dim3(1), dim3(1024), 0, ctx->stream, Vl, ctx->olam + l * K, (int)K,
+        hipLaunchKernelGGL(k_scale_eigvecs, dim3(1), dim3(256), 0, ctx->stream, Vl, ctx->olam + l * K, (int)K,
                            Nmax * 2.220446049250313e-16, Gl, ctx->osing + l * K, ctx->la_status);
         ASB_CHECK_LAUNCH(ctx);
         int st[4];

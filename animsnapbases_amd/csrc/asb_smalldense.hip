@@ -235,7 +235,8 @@ int asb_tri_eig_dev(asb_ctx* ctx, const double* d, const double* e, int n, int k
 // Pair (i, j): alpha = |a_i|^2, beta = |a_j|^2, gamma = a_i . a_j; if |gamma| > tol sqrt(alpha beta) the plane rotation
 // that makes the two rows orthogonal is applied to rows i, j of A and of Q (accumulated left factor, Q A_0 = A).
 __global__ __launch_bounds__(256) void k_jacobi_round(double* __restrict__ A, int m, long long lda, double* __restrict__ Q, int nq,
-                                                      int n2, int r, int nv, double tol, unsigned* __restrict__ n_rot) {
+                                                      int n2, int r, int nv, double tol, const double* __restrict__ fro2,
+                                                      unsigned* __restrict__ n_rot) {
     __shared__ double sh[12];
     const int p = blockIdx.x, np = n2 - 1;
     int i = (p == 0) ? (r % np) : ((r + p) % np);
@@ -251,7 +252,10 @@ __global__ __launch_bounds__(256) void k_jacobi_round(double* __restrict__ A, in
     }
     block_sum<3>(v, sh);
     const double al = v[0], be = v[1], ga = v[2];
-    if (!(al > 0.0) || !(be > 0.0) || !(fabs(ga) > tol * sqrt(al) * sqrt(be))) return;
+    // rows at rounding level of the whole matrix (rank deficiency: more rows than columns, dependent rows) carry no
+    // direction of their own: they are left alone, or the sweep over mutually "correlated" noise never ends
+    const double floor2 = 1e-28 * fro2[0];
+    if (!(al > floor2) || !(be > floor2) || !(fabs(ga) > tol * sqrt(al) * sqrt(be))) return;
     const double zeta = (be - al) / (2.0 * ga);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
@@ -270,6 +274,14 @@ __global__ __launch_bounds__(256) void k_jacobi_round(double* __restrict__ A, in
         }
     }
     if (threadIdx.x == 0) atomicAdd(n_rot, 1u);
+}
+
+__global__ __launch_bounds__(256) void k_sumsq(const double* __restrict__ sig, int nv, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < nv; i += 256) v[0] += sig[i] * sig[i];
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) out[0] = v[0];
 }
 
 __global__ __launch_bounds__(256) void k_row_norms(const double* __restrict__ A, int m, long long lda, double* __restrict__ sig) {
@@ -317,12 +329,15 @@ int asb_jacobi_rows_dev(asb_ctx* ctx, double* A, int nv, int m, long long lda, d
     if (nv < 1 || m < 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_jacobi_rows_dev: %d x %d", nv, m);
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->jac_q, (size_t)nv * nv))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->jac_sig, (size_t)nv))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->jac_sig, (size_t)nv + 1))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->jac_where, (size_t)nv + 4))) return rc;
     unsigned* n_rot = reinterpret_cast<unsigned*>(ctx->jac_where + nv);
     if (Q_sorted) hipLaunchKernelGGL(k_identity, dim3(256), dim3(256), 0, ctx->stream, ctx->jac_q, nv);
     const int n2 = nv + (nv & 1);
     const double tol = 4.0 * ASB_EPS;
+    double* fro2 = ctx->jac_sig + nv;            // |A|_F^2 of the input (rotations preserve it)
+    hipLaunchKernelGGL(k_row_norms, dim3(nv), dim3(256), 0, ctx->stream, A, m, lda, ctx->jac_sig);
+    hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(256), 0, ctx->stream, ctx->jac_sig, nv, fro2);
     int sweep = 0;
     bool converged = nv == 1;
     if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
@@ -330,7 +345,7 @@ int asb_jacobi_rows_dev(asb_ctx* ctx, double* A, int nv, int m, long long lda, d
         ASB_HIP(ctx, hipMemsetAsync(n_rot, 0, sizeof(unsigned), ctx->stream));
         for (int r = 0; r < n2 - 1; ++r)
             hipLaunchKernelGGL(k_jacobi_round, dim3(n2 / 2), dim3(256), 0, ctx->stream, A, m, lda, Q_sorted ? ctx->jac_q : (double*)nullptr,
-                               nv, n2, r, nv, tol, n_rot);
+                               nv, n2, r, nv, tol, fro2, n_rot);
         ASB_CHECK_LAUNCH(ctx);
         ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin + 384, n_rot, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -49,7 +49,7 @@ def test_tridiagonal_bisection_and_inverse_iteration(eng, n, rank, noise, k):
     # the well separated ones also vector by vector, the rest as a span (what the POD's Rayleigh-Ritz step needs)
     _, Zr = eigh_tridiagonal(d, e)
     Zr = Zr[:, ::-1]
-    sep = min(rank, k) - 2
+    sep = min(int(np.sum(0.8 ** np.arange(rank) > 30 * noise)), k - 1)      # leading values clear of the noise floor
     for j in range(sep):
         gap = min(lam[j - 1] - lam[j] if j else np.inf, lam[j] - lam[j + 1])
         err = min(np.linalg.norm(Z[:, j] - Zr[:, j]), np.linalg.norm(Z[:, j] + Zr[:, j]))
