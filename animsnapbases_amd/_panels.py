@@ -40,6 +40,7 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             pass
     _, rows_loc, idx_loc, top_loc, top_all = bufs
     packed_ok = hasattr(eng, "panel_assemble_packed")
+    spec_word = torch.zeros(1, dtype=torch.float64, device=dev) if (hasattr(eng, "panel_project_spec_dev") and dev.type != "cpu") else None
     global_all = n_rows <= cap
     spec_budget = 16 if (hasattr(eng, "panel_run_spec") and os.environ.get("ASB_SPEC_PANELS", "1") != "0") else 0
     k, stalled, forced_next = 0, 0, -1
@@ -93,8 +94,13 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             else:
                 done = proven = eng.panel_run(k, steps, take_all)
             if done > proven:                             # the tail is unproven: the pass decides how much of it stands
-                mine = eng.panel_project_spec(k, done, proven)
-                done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
+                if spec_word is not None:                 # count stays on the device: min over ranks, ONE read
+                    eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
+                    comm.allreduce_min_tensor(spec_word)
+                    done = int(spec_word.item())
+                else:
+                    mine = eng.panel_project_spec(k, done, proven)
+                    done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
                 eng.panel_commit(k, done)
                 gain = done - proven
                 # a kept step saves 1/16 of a panel, a rejected one costs one step of the panel kernel: back off only

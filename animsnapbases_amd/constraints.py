@@ -439,10 +439,21 @@ class constraintsComponents:  # Components == bases
         eng, comm = ns._engine, ns._comm
         p_size = ns.constraintsSize
         K = self.numComp
-        if self._comps_on_device and hasattr(eng, "orth_gram_get"):      # the rank diagnostic (:801) from the device's K x K Gram matrices
-            test_linear_dependency_grams(summed_grams(eng, comm, K), K, lambda j: self.comps[:, :, j].T)
-        else:
-            test_linear_dependency(self.comps.swapaxes(0, 1), 3, K)
+        self._rank_diagnostic(K)
+        if not comm.multi and self._comps_on_device and hasattr(eng, "deim_run") and \
+                os.environ.get("ASB_DEIM", getattr(self, "deim_backend", "device")) == "device":
+            # single rank: the whole loop on the device (bordered inverse of the k x k systems carried there, verified
+            # per step); one host synchronisation.  A failed verification falls through to the lstsq loop below.
+            Pt_d, maxabs, bad = eng.deim_run()
+            if not bad:
+                for k in range(K):
+                    if k > 0 and maxabs[k] <= 1e-8:             # np.allclose(r, 0) of :837
+                        print("ERROR!: zero residual!!")
+                        return
+                    print(k, int(Pt_d[k]) // p_size)
+                self._set_interpolation(list(Pt_d), [int(i) // p_size for i in Pt_d], list(range(1, K + 1)), list(Pt_d))
+                print("Regular Deim interpolation, used", self.geom_alpha.shape[0], "constrained elements")
+                return
         rows = np.zeros((K, K, 3))          # rows[m, j, i] = V[Pt[m], j, i]
         Pt, e_points, e_range = [], [], []
         # The reference solves the growing k x k system from scratch with lstsq at every step (O(K^4) in all).
@@ -487,7 +498,7 @@ class constraintsComponents:  # Components == bases
             if comm.multi:
                 idx = int(comm.global_argmax(np.array([idx]), np.array([val]))[0])
                 val = float(comm.allreduce_max(val)[0])
-            if k > 0 and not val > 0.0:
+            if k > 0 and not val > 1e-16:                # (all |r| <= 1e-8, np.allclose(r, 0) of :837, implies this)
                 print("ERROR!: zero residual!!")
                 return
             row = eng.deim_row(idx)
@@ -503,11 +514,142 @@ class constraintsComponents:  # Components == bases
             Pt.append(idx)
             e_points.append(alpha)
             e_range.append(k + 1)
+        self._set_interpolation(Pt, e_points, e_range, Pt)
+        print("Regular Deim interpolation, used", self.geom_alpha.shape[0], "constrained elements")
+
+    def _set_interpolation(self, Pt, e_points, e_range, idxs=None):
         self.geom_Pt = np.array(Pt)
         self.geom_alpha = np.array(e_points)
+        if idxs is not None:
+            self.geom_ep_idxs = np.array(set(int(i) for i in idxs))      # (0-d object array, as the reference builds it :853)
         self.geom_alpha_ranges = np.array(e_range)
         self.geom_interpol_verts = np.array(self.geom_interpol_verts)
-        print("Regular Deim interpolation, used", self.geom_alpha.shape[0], "constrained elements")
+
+    def _rank_diagnostic(self, expected):
+        """test_linear_dependency(bases, 3, expected) of :801 / :630 / :742 -- from the device's Gram matrices when the
+        basis lives there."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        if self._comps_on_device and hasattr(eng, "orth_gram_get"):
+            test_linear_dependency_grams(summed_grams(eng, comm, expected), expected, lambda j: self.comps[:, :, j].T)
+        else:
+            test_linear_dependency(self.comps.swapaxes(0, 1), 3, expected)
+
+    def _block_interpolation(self, group, unique):
+        """Shared loop of deim_blocksForm (:733-795, group = 1: arg-max over rows) and of
+        geom_block_form_utilizing_differential_operator in the constraint space (:619-731, group = p: arg-max over
+        constraints, no constraint twice).  Step k: lstsq of V[Pt, :kp, i] against the block's p vectors (the reference's
+        call, host; k p x k p), residual + arg-max on the device."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        if comm.multi:
+            raise NotImplementedError("block interpolation runs on one rank")
+        p = int(ns.constraintsSize)
+        K = self.numComp
+        Kp = K * p
+        v0, n_loc = ns._shards[comm.rank]
+        if not self._comps_on_device:
+            eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))
+            self._comps_on_device = True
+        if eng.K != Kp:
+            raise ValueError("the basis has %d vectors, %d blocks of %d expected" % (eng.K, K, p))
+        self._rank_diagnostic(Kp)
+        rows = np.zeros((0, Kp, 3))          # rows[m, j, i] = V[Pt[m], j, i]
+        Pt, e_points, e_range, idxs = [], [], [], []
+        for k in range(K):
+            coef = None
+            if k > 0:
+                kp = k * p
+                coef = np.empty((3, kp, p))
+                for i in range(3):
+                    coef[i] = np.linalg.lstsq(rows[:, :kp, i], rows[:, kp:kp + p, i], rcond=None)[0]      # (:764-765)
+            idx, val, amax = eng.deim_block_step(k, p, coef, group)
+            if k > 0 and amax <= 1e-8:                       # np.allclose(r, 0) (:768 / :677)
+                print("ERROR!: zero residual!!")
+                return False
+            alpha = idx // p if group == 1 else idx
+            if unique:
+                assert alpha not in e_points
+            idxs.append(idx)
+            e_points.append(alpha)
+            print(k, alpha)
+            new = np.stack([eng.deim_row(alpha * p + m) for m in range(p)])
+            rows = np.concatenate([rows, new], axis=0)
+            Pt.extend(alpha * p + m for m in range(p))
+            e_range.append(k + 1)
+        self._set_interpolation(Pt, e_points, e_range, idxs if group == 1 else None)
+        return True
+
+    def deim_blocksForm(self):
+        """constraintsComponents.py:733-795."""
+        if self._block_interpolation(1, False):
+            print("Regular Deim interpolation, used", self.geom_alpha.shape[0], "constrained elements")
+
+    @log_time(constProj_output_directory)
+    def geom_block_form_utilizing_differential_operator(self, error_in_pos_space=False):
+        """constraintsComponents.py:619-731 with the error measured in the constraint-projection space.  The position-space
+        variant multiplies the residual by the libigl-built operator S^T and walks mesh adjacency (utils/support.py:210-370):
+        out of scope of this build (SURVEY.md section 2 #3/#4)."""
+        if error_in_pos_space:
+            raise NotImplementedError("error_in_pos_space=True needs the differential operator S^T and the element adjacency "
+                                      "helpers of the reference (libigl; out of scope)")
+        if self._block_interpolation(int(self.nonlinearSnapshots.constraintsSize), True):
+            print("Computing interpolation elements utilizing differential operator, used", self.geom_alpha.shape[0],
+                  "constrained elements")
+
+    def geom_constructed(self, r, case, interpol="geom"):
+        """constraintsComponents.py:489-521: reconstruction of the train / test frames from the r leading basis blocks and
+        the interpolation points: per dimension the normal equations of V_r[Pt] (r p x r p, host LU as the reference), the
+        (e p x r p) by (r p x F) product on the device."""
+        from scipy.linalg import lu_factor, lu_solve
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        if comm.multi:
+            raise NotImplementedError("geom_constructed runs on one rank")
+        kind = getattr(self.param, "constProj_bases_interpolation_type", "")
+        p = int(ns.constraintsSize) if kind in ("geom", "deim_block_form") else 1
+        if case == "train":
+            frames = ns.snapTensor
+        elif case == "test":
+            frames = ns.test_snapTensor
+        else:
+            raise ValueError("unknown frames to reconstruct.")
+        F = frames.shape[0]
+        if getattr(self.param, "constProj_snapshots_type", "") == "verts_bending":
+            Pt = self.geom_Pt[:self.geom_alpha_ranges[r - 1]]
+        else:
+            Pt = self.geom_alpha[:self.geom_alpha_ranges[r - 1]]
+        Pt = np.asarray(Pt, dtype=np.int64)
+        rp = r * p
+        if not self._comps_on_device:
+            v0, n_loc = ns._shards[comm.rank]
+            eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))
+            self._comps_on_device = True
+        VPt = np.stack([eng.deim_row(int(g)) for g in Pt])[:, :rp, :]            # (|Pt|, rp, 3)
+        coef = np.empty((3, rp, F))
+        for l in range(3):
+            u, piv = lu_factor(VPt[:, :, l].T @ VPt[:, :, l])
+            coef[l] = lu_solve((u, piv), VPt[:, :, l].T @ np.ascontiguousarray(frames[:, Pt, l]).T)
+        return eng.components_expand(coef)
+
+    @log_time(constProj_output_directory)
+    def store_components_gradually_to_files(self, start, end, step, fileType):
+        """constraintsComponents.py:572-594; fileType '.bin' or '.npy'."""
+        from .utils import store_components, store_interpol_points_vector
+        print('Storing bases ...', end='', flush=True)
+        ns = self.nonlinearSnapshots
+        numframes = ns.frs
+        numverts = ns.num_constained_elements * ns.constraintsSize
+        out = getattr(self.param, "constProj_output_directory", "")
+        basesFile = os.path.join(out, self.fileNameBases)
+        pointsFile = os.path.join(out, self.fileName_geom_points)
+        vertsFile = os.path.join(out, "corrVerts")
+        p = ns.constraintsSize
+        for k in range(start, end + 1, step):
+            store_components(basesFile, numframes, k * p, numverts, 3, self.comps[:k * p, :, :], fileType, 'Kp')
+            store_interpol_points_vector(pointsFile, ns.frs, k, self.geom_alpha[:self.geom_alpha_ranges[k - 1]], fileType)
+            store_interpol_points_vector(vertsFile, ns.frs, k, self.geom_interpol_verts[:k], fileType)
+        print('done.')
 
     @log_time(constProj_output_directory)
     def store_components_n_interpol_points(self):

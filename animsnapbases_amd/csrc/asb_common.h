@@ -161,6 +161,8 @@ struct asb_ctx {
     double *jac_q = nullptr, *jac_sig = nullptr, *jac_a = nullptr;
     int* jac_where = nullptr;
     double* chol_w = nullptr;
+    double* deim_m = nullptr;         // asb_deim_run: Mx, Minv, coef, partials
+    long long* deim_pt = nullptr;
     double *eig_lam = nullptr, *eig_v = nullptr;  // asb_sym_eig_topk: eigenvalues (n, descending), leading vectors (n x k)
     int64_t eig_n = 0, eig_k = 0;
 

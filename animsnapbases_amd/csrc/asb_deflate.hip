@@ -124,9 +124,18 @@ __global__ __launch_bounds__(256) void k_block_argmax(const double* __restrict__
     if (threadIdx.x == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; }
 }
 
+static int energy_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out);
 extern "C" int asb_deflate_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out) {
     if (!ctx || !ctx->R || !ctx->energy || !block_out || p < 1) return ASB_ERR_ARG;
     if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_block_argmax needs the residual mode");
+    return energy_block_argmax(ctx, p, block_out, val_out);
+}
+// the same on whatever per-row energies the context holds (asb_deim_block_residual)
+extern "C" int asb_energy_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out) {
+    if (!ctx || !ctx->energy || !block_out || p < 1) return ASB_ERR_ARG;
+    return energy_block_argmax(ctx, p, block_out, val_out);
+}
+static int energy_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out) {
     if (ctx->v0 % p || ctx->n_loc % p)
         ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_block_argmax: the shard [%lld, +%lld) does not hold whole blocks of %d rows",
                  (long long)ctx->v0, (long long)ctx->n_loc, p);

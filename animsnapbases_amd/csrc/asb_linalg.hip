@@ -501,6 +501,28 @@ extern "C" int asb_components_transform(asb_ctx* ctx, const double* T_host) {
     return ASB_OK;
 }
 
+// out (host, F x n_loc x 3): out[f][e][l] = sum_{j < r} comps[j][e][l] coef[l][j][f] -- the reconstruction product of
+// geom_constructed (constraintsComponents.py:517-519: V_r[:, :, l] @ x for every frame) as one MFMA product per dimension
+extern "C" int asb_components_expand(asb_ctx* ctx, const double* coef_host, int64_t r, int64_t Fo, double* out_host) {
+    if (!ctx || !ctx->comps || !coef_host || !out_host || r < 1 || r > ctx->K || Fo < 1) return ASB_ERR_ARG;
+    const int64_t n = ctx->n_loc;
+    double *dc = nullptr, *dout = nullptr;
+    ASB_HIP(ctx, hipMalloc((void**)&dc, (size_t)3 * r * Fo * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&dout, (size_t)Fo * 3 * n * sizeof(double));
+    int rc = ASB_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(dc, coef_host, (size_t)3 * r * Fo * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    for (int l = 0; l < 3 && e == hipSuccess && rc == ASB_OK; ++l)
+        rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, dc + (size_t)l * r * Fo, Fo, r, (int)n, (int)Fo, dout + l, 3, 3 * n);
+    if (e == hipSuccess && rc == ASB_OK)
+        e = hipMemcpyAsync(out_host, dout, (size_t)Fo * 3 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dc);
+    if (dout) (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_components_expand: %s", hipGetErrorString(e));
+    return ASB_OK;
+}
+
 // keeps the first K components of the device-resident basis (rows are contiguous: nothing moves)
 extern "C" int asb_components_truncate(asb_ctx* ctx, int64_t K) {
     if (!ctx || !ctx->comps || K < 1 || K > ctx->K) return ASB_ERR_ARG;

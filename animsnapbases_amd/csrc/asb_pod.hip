@@ -236,10 +236,13 @@ extern "C" int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host) {
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict__ comps, long long n_vert, int k,
                                                        const double* __restrict__ coef, long long v0,
-                                                       double* __restrict__ pmax, long long* __restrict__ pidx) {
+                                                       double* __restrict__ pmax, long long* __restrict__ pidx,
+                                                       double* __restrict__ pabs = nullptr) {
     extern __shared__ double cf[];          // 3 * k
     __shared__ double sh_d[256];
     __shared__ long long sh_i[256];
+    __shared__ double sh_a[4];
+    double amax = 0.0;
     for (int q = threadIdx.x; q < 3 * k; q += blockDim.x) cf[q] = coef[q];
     __syncthreads();
     const long long stride = 3 * n_vert;
@@ -255,6 +258,11 @@ __global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict_
         r0 -= q[0]; r1 -= q[1]; r2 -= q[2];
         const double en = r0 * r0 + r1 * r1 + r2 * r2;
         if (am_better(en, e, be, bi)) { be = en; bi = e; }
+        amax = fmax(amax, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
+    }
+    if (pabs) {
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) sh_a[threadIdx.x >> 6] = amax;
     }
     sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi;
     __syncthreads();
@@ -265,7 +273,231 @@ __global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict_
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = v0 + sh_i[0]; }
+    if (threadIdx.x == 0) {
+        pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = v0 + sh_i[0];
+        if (pabs) pabs[blockIdx.x] = fmax(fmax(sh_a[0], sh_a[1]), fmax(sh_a[2], sh_a[3]));
+    }
+}
+
+// ---- the whole DEIM loop on the device (one rank holds every row) -------------------------------------------------------
+// State: Mx (3, K, K) with Mx[i][m][j] = V[Pt[m], j, i] (row m = the m-th interpolation point, all K columns), Minv (3, K, K)
+// whose leading k x k block is (Mx[i][:k, :k])^-1, carried along by the bordering (Schur complement) update -- what the
+// reference recomputes from scratch with lstsq at every step (:829).
+// k_deim_solve (one block per dimension): grows the inverse by last step's point / vector, then coef[i] = Minv b with
+// b = Mx[i][:k, k]; the solve is verified (|M x - b| against rounding level), a failure raises flags[0] and the caller
+// repeats the loop with the reference's lstsq on the host.
+__global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ Mx, double* __restrict__ Minv, int K, int k,
+                                                    double* __restrict__ coef, int* __restrict__ flags) {
+    extern __shared__ double sh[];               // u (K), w (K), x (K), red (8)
+    double* u = sh;
+    double* w = u + K;
+    double* x = w + K;
+    double* red = x + K;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const double* M = Mx + (size_t)i * K * K;
+    double* A = Minv + (size_t)i * K * K;
+    const int n = k - 1;                         // size of the inverse carried over
+    if (k == 1) {
+        if (tid == 0) {
+            const double m00 = M[0];
+            if (m00 == 0.0 || !(m00 == m00)) flags[0] = 1;
+            A[0] = 1.0 / m00;
+        }
+    } else {
+        // u = A bcol, w = crow A   (bcol[m] = M[m][n], crow[j] = M[n][j])
+        for (int r = tid; r < n; r += 256) {
+            double su = 0.0, sw = 0.0;
+            for (int q = 0; q < n; ++q) {
+                su += A[(size_t)r * K + q] * M[(size_t)q * K + n];
+                sw += M[(size_t)n * K + q] * A[(size_t)q * K + r];
+            }
+            u[r] = su;
+            w[r] = sw;
+        }
+        __syncthreads();
+        double part[1] = {0.0};
+        for (int q = tid; q < n; q += 256) part[0] += M[(size_t)n * K + q] * u[q];
+        block_sum<1>(part, red);
+        const double sch = M[(size_t)n * K + n] - part[0];
+        if (sch == 0.0 || !(sch == sch) || fabs(sch) > 1.7e308) {
+            if (tid == 0) flags[0] = 1;
+            return;
+        }
+        const double is = 1.0 / sch;
+        for (int e = tid; e < n * n; e += 256) {
+            const int r = e / n, c = e % n;
+            A[(size_t)r * K + c] += u[r] * w[c] * is;
+        }
+        for (int r = tid; r < n; r += 256) {
+            A[(size_t)r * K + n] = -u[r] * is;
+            A[(size_t)n * K + r] = -w[r] * is;
+        }
+        if (tid == 0) A[(size_t)n * K + n] = is;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // x = A[:k, :k] b,  b[m] = M[m][k]
+    double nb2 = 0.0, nx2 = 0.0, nm2 = 0.0;
+    for (int r = tid; r < k; r += 256) {
+        double sx = 0.0;
+        for (int q = 0; q < k; ++q) {
+            sx += A[(size_t)r * K + q] * M[(size_t)q * K + k];
+            const double m = M[(size_t)r * K + q];
+            nm2 += m * m;
+        }
+        x[r] = sx;
+        coef[(size_t)i * k + r] = sx;
+        nx2 += sx * sx;
+        const double b = M[(size_t)r * K + k];
+        nb2 += b * b;
+    }
+    __syncthreads();
+    double res2 = 0.0;
+    for (int r = tid; r < k; r += 256) {
+        double sr = -M[(size_t)r * K + k];
+        for (int q = 0; q < k; ++q) sr += M[(size_t)r * K + q] * x[q];
+        res2 += sr * sr;
+    }
+    double v[4] = {nb2, nx2, nm2, res2};
+    block_sum<4>(v, red);
+    if (tid == 0) {
+        const double lim = 1e-10 * (sqrt(v[0]) + sqrt(v[2]) * sqrt(v[1]));
+        if (!(sqrt(v[3]) <= lim)) flags[0] = 1;
+    }
+}
+
+// reduces the residual kernel's partials to the step's point: Pt[k], its largest |r| entry, and row k of Mx
+__global__ __launch_bounds__(256) void k_deim_pick(const double* __restrict__ pmax, const long long* __restrict__ pidx,
+                                                   const double* __restrict__ pabs, int nblk, const double* __restrict__ comps,
+                                                   long long n_vert, int K, int k, long long* __restrict__ Pt,
+                                                   double* __restrict__ maxabs, double* __restrict__ Mx) {
+    __shared__ double sh_d[256];
+    __shared__ long long sh_i[256];
+    __shared__ double sh_a[256];
+    double be = -1.0, am = 0.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        if (am_better(pmax[b], pidx[b], be, bi)) { be = pmax[b]; bi = pidx[b]; }
+        am = fmax(am, pabs[b]);
+    }
+    sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi; sh_a[threadIdx.x] = am;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            if (am_better(sh_d[threadIdx.x + o], sh_i[threadIdx.x + o], sh_d[threadIdx.x], sh_i[threadIdx.x])) {
+                sh_d[threadIdx.x] = sh_d[threadIdx.x + o];
+                sh_i[threadIdx.x] = sh_i[threadIdx.x + o];
+            }
+            sh_a[threadIdx.x] = fmax(sh_a[threadIdx.x], sh_a[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    const long long idx = sh_i[0];
+    if (threadIdx.x == 0) { Pt[k] = idx; maxabs[k] = sh_a[0]; }
+    for (int q = threadIdx.x; q < 3 * K; q += 256) {
+        const int i = q / K, j = q % K;
+        Mx[(size_t)i * K * K + (size_t)k * K + j] = comps[(long long)j * 3 * n_vert + 3 * idx + i];
+    }
+}
+
+// deim (:797-860) for a basis whose every row is on this device: Pt_out (K) the interpolation rows in order, maxabs_out (K)
+// the largest |residual| entry of each step (the reference stops with "zero residual" when np.allclose(r, 0), i.e. when it
+// is <= 1e-8), *solve_failed != 0 when a bordered solve missed its check (the caller then uses lstsq on the host).  One
+// host synchronisation for the whole loop.
+extern "C" int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, int* solve_failed) {
+    if (!ctx || !ctx->comps || !Pt_out || !maxabs_out || !solve_failed) return ASB_ERR_ARG;
+    if (ctx->n_loc != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deim_run needs all rows on one rank");
+    const int K = (int)ctx->K;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->deim_m, (size_t)6 * K * K + 4 * (size_t)K + 2048 * 2))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->deim_pt, (size_t)K + 2048))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
+    double* Mx = ctx->deim_m;
+    double* Minv = Mx + (size_t)3 * K * K;
+    double* coef = Minv + (size_t)3 * K * K;          // 3 K
+    double* maxabs = coef + (size_t)3 * K;            // K
+    double* pmax = maxabs + K;                        // 2048
+    double* pabs = pmax + 2048;                       // 2048
+    long long* Pt = ctx->deim_pt;
+    long long* pidx = Pt + K;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+    long long want = (ctx->n_loc + 255) / 256;
+    const int grid = (int)(want < 1024 ? want : 1024);
+    const size_t lds_solve = ((size_t)3 * K + 16) * sizeof(double);
+    for (int k = 0; k < K; ++k) {
+        if (k > 0) {
+            hipLaunchKernelGGL(k_deim_solve, dim3(3), dim3(256), lds_solve, ctx->stream, Mx, Minv, K, k, coef, ctx->la_status);
+        }
+        hipLaunchKernelGGL(k_deim_residual, dim3(grid), dim3(256), (size_t)(3 * k + 1) * sizeof(double), ctx->stream, ctx->comps,
+                           (long long)ctx->n_loc, k, coef, (long long)ctx->v0, pmax, pidx, pabs);
+        hipLaunchKernelGGL(k_deim_pick, dim3(1), dim3(256), 0, ctx->stream, pmax, pidx, pabs, grid, ctx->comps, (long long)ctx->n_loc,
+                           K, k, Pt, maxabs, Mx);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    int st[4];
+    ASB_HIP(ctx, hipMemcpyAsync(Pt_out, Pt, (size_t)K * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(maxabs_out, maxabs, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *solve_failed = st[0];
+    return ASB_OK;
+}
+
+// ---- block DEIM (deim_blocksForm :733-795, geom_block_form_utilizing_differential_operator :619-731 in the constraint
+// space): step k works on the p basis vectors of block k.  r[row][m][i] = sum_{j < k p} coef[i][j][m] V[row][j][i] -
+// V[row][k p + m][i]; the per-row energies sum_{m, i} r^2 go to ctx->energy, the caller takes the arg-max over rows
+// (group = 1) or over constraints of p rows (group = p) with asb_deflate_block_argmax.  coef host (3, k p, p), NULL at k = 0.
+__global__ __launch_bounds__(256) void k_deim_block_residual(const double* __restrict__ comps, long long n_rows, int kp, int p,
+                                                             const double* __restrict__ coef, double* __restrict__ energy,
+                                                             double* __restrict__ pabs) {
+    __shared__ double sh_a[4];
+    const long long stride = 3 * n_rows;
+    double amax = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_rows; e += (long long)gridDim.x * 256) {
+        double en = 0.0;
+        for (int m = 0; m < p; ++m) {
+            double r[3] = {0.0, 0.0, 0.0};
+            for (int j = 0; j < kp; ++j) {
+                const double* q = comps + (long long)j * stride + 3 * e;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r[i] += coef[((size_t)i * kp + j) * p + m] * q[i];
+            }
+            const double* q = comps + (long long)(kp + m) * stride + 3 * e;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                r[i] -= q[i];
+                en += r[i] * r[i];
+                amax = fmax(amax, fabs(r[i]));
+            }
+        }
+        energy[e] = en;
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) sh_a[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) pabs[blockIdx.x] = fmax(fmax(sh_a[0], sh_a[1]), fmax(sh_a[2], sh_a[3]));
+}
+
+extern "C" int asb_deim_block_residual(asb_ctx* ctx, int64_t k, int p, const double* coef, double* maxabs_out) {
+    if (!ctx || !ctx->comps || k < 0 || p < 1 || (k + 1) * p > ctx->K || !maxabs_out) return ASB_ERR_ARG;
+    if (k > 0 && !coef) return ASB_ERR_ARG;
+    const int kp = (int)(k * p);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_coef, (size_t)3 * ctx->K * p + 8))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->energy, (size_t)ctx->n_loc))) return rc;
+    if (k > 0) ASB_HIP(ctx, hipMemcpyAsync(ctx->pod_coef, coef, (size_t)3 * kp * p * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    long long want = (ctx->n_loc + 255) / 256;
+    const int grid = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(k_deim_block_residual, dim3(grid), dim3(256), 0, ctx->stream, ctx->comps, (long long)ctx->n_loc, kp, p,
+                       ctx->pod_coef, ctx->energy, ctx->pmax);
+    ASB_CHECK_LAUNCH(ctx);
+    std::vector<double> h(grid);
+    ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->pmax, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double am = 0.0;
+    for (int b = 0; b < grid; ++b) am = h[b] > am ? h[b] : am;
+    *maxabs_out = am;
+    return ASB_OK;
 }
 
 // shard arg-max of the DEIM residual of basis vector k given the interpolation coefficients

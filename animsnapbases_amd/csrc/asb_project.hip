@@ -2484,6 +2484,23 @@ extern "C" int asb_panel_project_spec(asb_ctx* ctx, int64_t k0, int ncols, int p
     *first_rejected = h.spec_ok < ncols ? h.spec_ok : ncols;
     return ASB_OK;
 }
+// the same without a host read-back: the count goes into the caller's DEVICE word (a float64, to be min-all-reduced over
+// the ranks and read once) -- one host synchronisation per panel less in the multi-rank driver
+__global__ void k_spec_count(const PanelState* __restrict__ st, int ncols, double* __restrict__ out) {
+    out[0] = (double)(st->spec_ok < ncols ? st->spec_ok : ncols);
+}
+extern "C" int asb_panel_project_spec_dev(asb_ctx* ctx, int64_t k0, int ncols, int proven, double* first_rejected_dev) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !first_rejected_dev) return ASB_ERR_ARG;
+    if (ncols < 1 || ncols > ASB_PANEL_COLS || k0 < 0 || k0 + ncols > ctx->K || proven < 0 || proven >= ncols)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_project_spec_dev: bad range");
+    int rc = project_pass(ctx, k0, ncols, proven, nullptr, true);
+    if (rc) return rc;
+    ctx->n_spec_steps += ncols - proven;
+    ctx->run_proven = proven;
+    hipLaunchKernelGGL(k_spec_count, dim3(1), dim3(1), 0, ctx->stream, ctx->pstate, ncols, first_rejected_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
 // energies / column sums of the first `kept` columns of that pass (0: nothing stood, the energies stay as they were)
 extern "C" int asb_panel_commit(asb_ctx* ctx, int64_t k0, int kept) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;

@@ -48,6 +48,7 @@ class Comm(object):
         self.multi = self.world > 1 or bool(force_collectives and self.dist is not None)
         self._torch = None
         self._dev = None
+        self._bufs = {}
         if self.multi:
             import torch
 
@@ -63,32 +64,44 @@ class Comm(object):
         return self.shards(N)[self.rank]
 
     # ------------------------------------------------------------ collectives
+    # Small host-side values (scalars of the standardisation, the K residual norms, a panel's counters): ONE exchange
+    # tensor per (kind, length) lives on the exchange device for the life of the communicator, the value is written into
+    # it, reduced / gathered in place with all_reduce / all_gather_into_tensor, and read back once -- no per-call tensor
+    # construction, no Python lists of per-rank tensors.
+    def _scratch(self, key, n, dtype):
+        buf = self._bufs.get((key, n))
+        if buf is None:
+            buf = self._torch.empty(n, dtype=dtype, device=self._dev)
+            self._bufs[(key, n)] = buf
+        return buf
+
+    def _reduce(self, values, op):
+        a = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        if not self.multi:
+            return a.copy()
+        t = self._scratch("red", a.size, self._torch.float64)
+        t.copy_(self._torch.from_numpy(np.ascontiguousarray(a).reshape(-1)), non_blocking=False)
+        self.dist.all_reduce(t, op=op, group=self.group)
+        return t.cpu().numpy().reshape(a.shape)
+
     def allreduce_sum(self, values):
         """Sum of a small float64 vector over ranks (returned as ndarray)."""
-        a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
-        if not self.multi:
-            return a
-        t = self._torch.from_numpy(a).to(self._dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        return self._reduce(values, self.dist.ReduceOp.SUM if self.multi else None)
 
     def allreduce_max(self, values):
-        a = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
-        if not self.multi:
-            return a
-        t = self._torch.from_numpy(a).to(self._dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return t.cpu().numpy()
+        return self._reduce(values, self.dist.ReduceOp.MAX if self.multi else None)
 
     def all_gather_ints(self, values):
         """(world, len(values)) int64 array of every rank's small integer vector."""
-        a = np.atleast_1d(np.asarray(values, dtype=np.int64)).copy()
+        a = np.atleast_1d(np.asarray(values, dtype=np.int64))
         if not self.multi:
-            return a[None]
-        t = self._torch.from_numpy(a).to(self._dev)
-        out = self._torch.empty(self.world * a.shape[0], dtype=self._torch.int64, device=self._dev)
+            return a[None].copy()
+        n = a.shape[0]
+        t = self._scratch("gi_in", n, self._torch.int64)
+        out = self._scratch("gi_out", self.world * n, self._torch.int64)
+        t.copy_(self._torch.from_numpy(np.ascontiguousarray(a)))
         self.dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.cpu().numpy().reshape(self.world, a.shape[0])
+        return out.cpu().numpy().reshape(self.world, n)
 
     def _need_torch(self):
         if self._torch is None:
@@ -107,6 +120,11 @@ class Comm(object):
             out.copy_(inp)
             return
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def allreduce_min_tensor(self, t):
+        """In-place MIN over ranks of a (device) tensor; the caller reads it."""
+        if self.multi:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
 
     def new_records(self, xlen, on_device):
         """(rec, recs): one exchange record and the gathered (world, xlen) buffer."""
@@ -139,35 +157,42 @@ class Comm(object):
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def global_argmax(self, idx, val):
-        """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties."""
+        """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties (NumPy's first-max rule
+        across the contiguous shards)."""
         if not self.multi:
             return idx
-        torch = self._torch
-        loc = torch.from_numpy(np.stack([val, idx.astype(np.float64)])).to(self._dev)
-        outs = [torch.empty_like(loc) for _ in range(self.world)]
-        self.dist.all_gather(outs, loc, group=self.group)
-        allv = np.stack([o.cpu().numpy() for o in outs])          # (world, 2, K)
-        best = np.empty(idx.shape[0], dtype=np.int64)
-        for k in range(idx.shape[0]):
-            order = sorted(range(self.world), key=lambda r: (-allv[r, 0, k], allv[r, 1, k]))
-            best[k] = int(allv[order[0], 1, k])
-        return best
+        n = idx.shape[0]
+        loc = self._scratch("am_in", 2 * n, self._torch.float64)
+        out = self._scratch("am_out", 2 * n * self.world, self._torch.float64)
+        loc.copy_(self._torch.from_numpy(np.concatenate([np.asarray(val, dtype=np.float64), idx.astype(np.float64)])))
+        self.dist.all_gather_into_tensor(out, loc, group=self.group)
+        allv = out.view(self.world, 2, n)
+        vals, ids = allv[:, 0, :], allv[:, 1, :]
+        top = vals.max(dim=0).values
+        cand = self._torch.where(vals == top[None, :], ids, self._torch.full_like(ids, float("inf")))
+        return cand.min(dim=0).values.to(self._torch.int64).cpu().numpy()
 
     def all_gather_rows(self, local, N, axis):
-        """Concatenates per-rank blocks along ``axis`` (block sizes follow ``partition``)."""
+        """Concatenates per-rank blocks along ``axis`` (block sizes follow ``partition``): one padded exchange tensor,
+        one all_gather_into_tensor, one copy back."""
         if not self.multi:
             return local
         torch = self._torch
         shards = self.shards(N)
         nmax = max(n for _, n in shards)
         loc = np.moveaxis(np.ascontiguousarray(local), axis, 0)
-        pad = np.zeros((nmax,) + loc.shape[1:], dtype=loc.dtype)
-        pad[:loc.shape[0]] = loc
-        t = torch.from_numpy(pad).to(self._dev)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t, group=self.group)
-        parts = [o.cpu().numpy()[:n] for o, (_, n) in zip(outs, shards)]
-        return np.moveaxis(np.concatenate(parts, axis=0), 0, axis)
+        rest = loc.shape[1:]
+        per = int(np.prod(rest, dtype=np.int64)) if rest else 1
+        piece = torch.zeros(nmax * per, dtype=torch.float64, device=self._dev)
+        piece[:loc.shape[0] * per].copy_(torch.from_numpy(np.ascontiguousarray(loc, dtype=np.float64).reshape(-1)))
+        out = torch.empty(self.world * nmax * per, dtype=torch.float64, device=self._dev)
+        self.dist.all_gather_into_tensor(out, piece, group=self.group)
+        full = out.cpu().numpy().reshape((self.world, nmax) + rest)
+        parts = [full[r, :n] for r, (_, n) in enumerate(shards)]
+        res = np.concatenate(parts, axis=0)
+        if local.dtype != np.float64:
+            res = res.astype(local.dtype)
+        return np.moveaxis(res, 0, axis)
 
     def barrier(self):
         if self.multi:

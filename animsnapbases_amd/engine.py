@@ -246,6 +246,9 @@ class HipEngine(object):
         self._ck(self.lib.asb_panel_project_spec(self.h, int(k0), int(ncols), int(proven), ctypes.byref(r)))
         return r.value
 
+    def panel_project_spec_dev(self, k0, ncols, proven, out_dev_ptr):
+        self._ck(self.lib.asb_panel_project_spec_dev(self.h, int(k0), int(ncols), int(proven), ctypes.c_void_p(out_dev_ptr)))
+
     def panel_commit(self, k0, kept):
         self._ck(self.lib.asb_panel_commit(self.h, int(k0), int(kept)))
 
@@ -467,6 +470,23 @@ class HipEngine(object):
         self._ck(self.lib.asb_deim_step(self.h, int(k), ptr(coef), ctypes.byref(i), ctypes.byref(v)))
         return i.value, v.value
 
+    def deim_run(self):
+        """The whole DEIM loop on the device (single rank): (Pt (K,), maxabs (K,), solve_failed)."""
+        Pt, ma, bad = np.empty(self.K, dtype=np.int64), np.empty(self.K), ctypes.c_int()
+        self._ck(self.lib.asb_deim_run(self.h, Pt.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ptr(ma), ctypes.byref(bad)))
+        return Pt, ma, bad.value
+
+    def deim_block_step(self, k, p, coef, group):
+        """Residual of basis block k (p vectors) and its arg-max over rows (group = 1) or constraints (group = p):
+        (index, energy, largest |r|)."""
+        if coef is not None:
+            coef = np.ascontiguousarray(coef, dtype=np.float64)
+            assert coef.shape == (3, k * p, p)
+        am, idx, val = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_deim_block_residual(self.h, int(k), int(p), ptr(coef), ctypes.byref(am)))
+        self._ck(self.lib.asb_energy_block_argmax(self.h, int(group), ctypes.byref(idx), ctypes.byref(val)))
+        return idx.value, val.value, am.value
+
     def deim_row(self, gidx):
         row = np.empty((self.K, 3))
         rc = self.lib.asb_deim_row(self.h, int(gidx), ptr(row))
@@ -478,6 +498,13 @@ class HipEngine(object):
     def results_comps(self):
         out = np.empty((self.K, self.n_loc, 3))
         self._ck(self.lib.asb_components_download(self.h, ptr(out)))
+        return out
+
+    def components_expand(self, coef):
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        assert coef.ndim == 3 and coef.shape[0] == 3
+        out = np.empty((coef.shape[2], self.n_loc, 3))
+        self._ck(self.lib.asb_components_expand(self.h, ptr(coef), coef.shape[1], coef.shape[2], ptr(out)))
         return out
 
     def components_truncate(self, K):

@@ -67,6 +67,19 @@ def store_components(fileName, F, K, N, dim, basesTensor, extension='.bin', colN
         np.save(fileName + str(F) + 'K' + str(K), basesTensor)
 
 
+def store_interpol_points_vector(fileName, F, K, points, extension='.bin', colName='K'):
+    """utils/utils.py:77-98: ``<i n><i 1>`` + n doubles, or ``.npy``."""
+    points = np.asarray(points)
+    assert K <= points.shape[0]
+    print("Storing ", points.shape[0], "interpolation points")
+    if extension == '.bin':
+        with open(fileName + 'F' + str(F) + colName + str(K) + "_points" + str(points.shape[0]) + extension, 'wb') as doc0:
+            doc0.write(struct.pack("<ii", points.shape[0], 1))
+            doc0.write(np.asarray(points, dtype="<f8").tobytes())
+    if extension == '.npy':
+        np.save(fileName + str(F) + 'K' + str(K) + "_points" + str(points.shape[0]), points)
+
+
 def read_components_bin(path):
     """Inverse of ``store_components`` ('.bin'): returns (K, N, 3)."""
     with open(path, "rb") as fh:

@@ -178,6 +178,9 @@ int asb_panel_run_spec(asb_ctx* ctx, int64_t k0, int steps, int global_all, int 
                        int64_t* proven);
 int asb_panel_project_spec(asb_ctx* ctx, int64_t k0, int ncols, int proven, int64_t* first_rejected);
 int asb_panel_commit(asb_ctx* ctx, int64_t k0, int kept);
+/* asb_panel_project_spec without the host read-back: the count is written (as a float64) to the caller's device word,
+ * which the multi-rank driver min-all-reduces and reads once (one host synchronisation per panel instead of two). */
+int asb_panel_project_spec_dev(asb_ctx* ctx, int64_t k0, int ncols, int proven, double* first_rejected_dev);
 /* fallback: exact energies of every vertex of the shard; optional first arg-max */
 int asb_panel_refresh(asb_ctx* ctx, int64_t k, double* best_energy, int64_t* best_gidx);
 
@@ -228,6 +231,10 @@ int asb_orth_refine(asb_ctx* ctx, const double* G_dev);
  * T_l = V S^-1 (orth, :284-287) or L^-T (qr, constraintsComponents.py:431-435). */
 int asb_orth_gram_get(asb_ctx* ctx, double* G_host);
 int asb_components_transform(asb_ctx* ctx, const double* T_host);
+/* geom_constructed, constraintsComponents.py:489-521, the large product: out (host, F x n_loc x 3),
+ * out[f][e][l] = sum_{j < r} comps[j][e][l] coef[l][j][f] with coef host (3, r, F) (the interpolation coefficients of
+ * every frame, solved by the caller from the r p x r p normal equations as the reference does) */
+int asb_components_expand(asb_ctx* ctx, const double* coef_host, int64_t r, int64_t F, double* out_host);
 /* the device-resident basis (K, n_loc, 3) to the host */
 int asb_components_download(asb_ctx* ctx, double* comps_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
@@ -317,6 +324,18 @@ int asb_qr_apply(asb_ctx* ctx, const double* G_dev);
  * shard (global row index).  coef: host (3, k), NULL for k = 0.  The k x k interpolation solves stay with
  * the caller (numpy lstsq, as in the reference :829), fed by asb_deim_row. */
 int asb_deim_step(asb_ctx* ctx, int64_t k, const double* coef, int64_t* idx_out, double* val_out);
+/* deim (:797-860) entirely on the device, for a basis whose rows are all on this rank: Pt_out (K) = the interpolation rows in
+ * order; maxabs_out (K) = the largest |residual| entry of each step (the reference stops with "zero residual" when
+ * np.allclose(r, 0), i.e. <= 1e-8); the k x k systems are solved through a bordered inverse carried on the device and
+ * verified -- *solve_failed != 0 means a check failed and the caller should fall back to asb_deim_step + lstsq (:829). */
+int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, int* solve_failed);
+/* deim_blocksForm (:733-795) / geom_block_form_utilizing_differential_operator (:619-731, error in the constraint space):
+ * residual of block k (p basis vectors) with the interpolation coefficients coef (host, 3 x (k p) x p; NULL at k = 0);
+ * per-row energies into the context (arg-max over rows / constraints: asb_deflate_block_argmax with group 1 / p);
+ * *maxabs_out = largest |r| entry (np.allclose(r, 0) test of :771). */
+int asb_deim_block_residual(asb_ctx* ctx, int64_t k, int p, const double* coef, double* maxabs_out);
+/* first maximum over this shard of the sums of p consecutive per-row energies held by the context (global block index) */
+int asb_energy_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out);
 /* V[gidx, :, :] -> row_out (K, 3); returns 1 (and writes nothing) when another rank owns gidx */
 int asb_deim_row(asb_ctx* ctx, int64_t gidx, double* row_out);
 

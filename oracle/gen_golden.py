@@ -244,6 +244,86 @@ def run_reference_blocks(ref, frames, K, p, standarize=True):
                 blocks=np.asarray(cc.largeDeforBlocks, dtype=np.int64), numComp=np.array(cc.numComp))
 
 
+def _blocksdeim(work):
+    """Block interpolation on a 'pca_blocks' basis (p = 3): deim_blocksForm (:733-795), geom_block_form_utilizing_
+    differential_operator in the constraint space (:619-731), geom_constructed (:489-521) and the files of
+    store_components_gradually_to_files (:572-594).  Input: the frames of tests/golden/pca_blocks_p3.npz."""
+    import snapbases.constraintsComponents as ccmod
+    g = np.load(os.path.join(OUT, "pca_blocks_p3.npz"))
+    frames, K, p = g["frames"], int(g["K"]), int(g["p"])
+    ref = import_reference.cache
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    out = {}
+    for kind in ("deim_block_form", "geom"):
+        param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=False,
+                                      deim_desired_num_components=K, constProj_output_directory=work,
+                                      constProj_bases_interpolation_type=kind, constProj_snapshots_type="tris_strain")
+        ns = object.__new__(nonlinearSnapshots)
+        ns.param, ns.rest_shape, ns.dim, ns.frs, ns.constraintsSize = param, "first", 3, frames.shape[0], p
+        ns.num_constained_elements = frames.shape[1] // p
+        ns.snapTensor = frames.astype(float).copy()
+        ns.mean, ns.pre_scale_factor, ns.massL, ns.invMassL = None, 1, None, None
+        ns.standarize()
+        cc = object.__new__(constraintsComponents)
+        cc.param, cc.nonlinearSnapshots, cc.numComp, cc.comps = param, ns, 0, None
+        cc.support, cc.storeSingVal, cc.geom_interpol_verts = "global", False, []
+        with contextlib.redirect_stdout(io.StringIO()):
+            cc.compute_nonlinearity_bases_blocks(None)
+            if kind == "deim_block_form":
+                cc.deim_blocksForm()
+            else:
+                cc.geom_block_form_utilizing_differential_operator(False)
+        out[kind + "_Pt"] = np.asarray(cc.geom_Pt, dtype=np.int64)
+        out[kind + "_alpha"] = np.asarray(cc.geom_alpha, dtype=np.int64)
+        out[kind + "_ranges"] = np.asarray(cc.geom_alpha_ranges, dtype=np.int64)
+        # (geom_constructed with p > 1 indexes the ROWS of the basis with constraint numbers, :505: r rows for r p
+        # unknowns, a singular normal matrix -- not a parity target; it is pinned with p = 1 in _recon below)
+        if kind == "geom":
+            out["comps"] = cc.comps.copy()
+            out["snapTensor"] = ns.snapTensor.copy()
+            ccmod.constProj_output_directory = work
+            cc.fileNameBases, cc.fileName_geom_points = "p_nl_", "p_nl_interpol_points_"
+            cc.geom_interpol_verts = np.arange(10, 10 + K)
+            with contextlib.redirect_stdout(io.StringIO()):
+                cc.store_components_gradually_to_files(1, K, 2, ".bin")
+            names = sorted(f for f in os.listdir(work) if f.endswith(".bin") and (f.startswith("p_nl_") or f.startswith("corrVerts")))
+            out["files"] = np.array(names)
+            out["files_sha256"] = np.array([hashlib.sha256(open(os.path.join(work, f), "rb").read()).hexdigest() for f in names])
+    np.savez_compressed(os.path.join(OUT, "block_deim_p3.npz"), frames=frames, K=np.array(K), p=np.array(p), **out)
+    print("wrote block_deim_p3", out["deim_block_form_alpha"].tolist(), out["geom_alpha"].tolist(), list(out["files"]))
+
+
+def _recon(work):
+    """geom_constructed (:489-521) after deim on the POD basis of tests/golden/pod_deim_small.npz (p = 1), train and test frames."""
+    g = np.load(os.path.join(OUT, "pod_deim_small.npz"))
+    frames, K = g["frames"], int(g["K"])
+    ref = import_reference.cache
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=False,
+                                  deim_desired_num_components=K, constProj_output_directory=work,
+                                  constProj_bases_interpolation_type="deim", constProj_snapshots_type="tris_strain")
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param, ns.rest_shape, ns.dim, ns.frs, ns.constraintsSize = param, "first", 3, frames.shape[0], 1
+    ns.num_constained_elements = frames.shape[1]
+    ns.snapTensor = frames.astype(float).copy()
+    ns.mean, ns.pre_scale_factor, ns.massL, ns.invMassL = None, 1, None, None
+    ns.standarize()
+    rng = np.random.default_rng(77)
+    ns.test_snapTensor = ns.snapTensor[::3] + 1e-3 * rng.normal(size=ns.snapTensor[::3].shape)
+    cc = object.__new__(constraintsComponents)
+    cc.param, cc.nonlinearSnapshots, cc.numComp, cc.comps, cc.geom_interpol_verts = param, ns, 0, None, []
+    out = dict(test_snapTensor=ns.test_snapTensor.copy())
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_pod_for_vectorized_nonlinear_snapshots_tensor(None)
+        cc.deim()
+    out["Pt"] = np.asarray(cc.geom_Pt, dtype=np.int64)
+    for r in (3, K):
+        out["train_r%d" % r] = cc.geom_constructed(r, "train")
+        out["test_r%d" % r] = cc.geom_constructed(r, "test")
+    np.savez_compressed(os.path.join(OUT, "pod_deim_recon.npz"), K=np.array(K), **out)
+    print("wrote pod_deim_recon", out["Pt"].tolist())
+
+
 def _blocks(work):
     rng = np.random.default_rng(21)
     e, F, K = 40, 20, 5
@@ -363,6 +443,10 @@ def main():
                                        if k != "vertPos_output_directory"},
                                     **res)
                 print("wrote", name, "idx", res["idx"].tolist())
+            if only is not None and "blocksdeim" in only:
+                return _blocksdeim(work)
+            if only is not None and "recon" in only:
+                return _recon(work)
             if only is not None and "blocks" in only:
                 return _blocks(work)
             if only is not None and "ingest" not in only:
@@ -381,6 +465,8 @@ def main():
                                     p=np.array(1), orthogonal=np.array(orth), **res)
                 print("wrote", nm, "Pt", res["Pt"].tolist())
             _blocks(work)
+            _blocksdeim(work)
+            _recon(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

@@ -1,0 +1,102 @@
+"""GPU (-m gpu): the interpolation-point variants of constraintsComponents against the unmodified
+reference (oracle/gen_golden.py `blocksdeim`, `recon`):
+  deim_blocksForm (:733-795), geom_block_form_utilizing_differential_operator in the constraint space (:619-731),
+  geom_constructed (:489-521, p = 1: with p > 1 the reference's normal matrix is singular by construction),
+  store_components_gradually_to_files (:572-594, byte-identical files), and deim (:797-860) run entirely on the device."""
+import hashlib
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import asb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _cparam(K, tmp, kind, basis, p):
+    return types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=0, constProj_p_size=p,
+                                 constProj_massWeight=False, constProj_standarize=True, constProj_orthogonal=False,
+                                 constProj_basis_type=basis, deim_desired_num_components=K,
+                                 constProj_store_sing_val=False, constProj_output_directory=str(tmp), name="t", constProj_name="v",
+                                 constProj_bases_interpolation_type=kind, constProj_snapshots_type="tris_strain")
+
+
+def _build(frames, K, tmp, kind, basis, p, test_frames=None):
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    param = _cparam(K, tmp, kind, basis, p)
+    ns = nonlinearSnapshots(param, frames=frames, test_frames=test_frames)
+    ns.config()
+    ns.snapshots_prepare()
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.compute_components_store_singvalues()
+    return ns, cc
+
+
+@pytest.mark.parametrize("kind", ["deim_block_form", "geom"])
+def test_block_interpolation_vs_reference_golden(kind, tmp_path, capsys):
+    g = load_golden("block_deim_p3")
+    K, p = int(g["K"]), int(g["p"])
+    ns, cc = _build(g["frames"], K, tmp_path, kind, "pca_blocks", p)
+    if kind == "deim_block_form":
+        cc.deim_blocksForm()
+    else:
+        cc.geom_block_form_utilizing_differential_operator(False)
+        with pytest.raises(NotImplementedError):
+            cc.geom_block_form_utilizing_differential_operator(True)
+    assert cc.geom_Pt.tolist() == g[kind + "_Pt"].tolist()
+    assert cc.geom_alpha.tolist() == g[kind + "_alpha"].tolist()
+    assert cc.geom_alpha_ranges.tolist() == g[kind + "_ranges"].tolist()
+    out = capsys.readouterr().out.splitlines()
+    steps = [ln for ln in out if ln.split() and ln.split()[0].isdigit() and len(ln.split()) == 2]
+    assert [int(ln.split()[1]) for ln in steps[-K:]] == g[kind + "_alpha"].tolist()      # the reference's `print(k, alpha)`
+    if kind == "geom":
+        # the files of store_components_gradually_to_files for the reference's own basis: byte-identical
+        cc.comps = g["comps"]
+        cc.geom_interpol_verts = np.arange(10, 10 + K)
+        cc.store_components_gradually_to_files(1, K, 2, ".bin")
+        names = sorted(f for f in os.listdir(tmp_path) if f.endswith(".bin"))
+        assert names == [str(x) for x in g["files"]]
+        sha = [hashlib.sha256(open(os.path.join(tmp_path, f), "rb").read()).hexdigest() for f in names]
+        assert sha == [str(x) for x in g["files_sha256"]]
+
+
+def test_deim_on_the_device_and_geom_constructed_vs_reference_golden(tmp_path, monkeypatch):
+    g = load_golden("pod_deim_small")
+    rec = load_golden("pod_deim_recon")
+    K = int(g["K"])
+
+    def no_lstsq(*a, **k):
+        raise AssertionError("host lstsq inside the device DEIM loop")
+    ns, cc = _build(g["frames"], K, tmp_path, "deim", "pod_vectorized", 1)
+    ns.test_snapTensor = rec["test_snapTensor"]
+    with monkeypatch.context() as mp:
+        mp.setattr(np.linalg, "lstsq", no_lstsq)
+        cc.deim()
+    assert cc.geom_Pt.tolist() == g["Pt"].tolist() == rec["Pt"].tolist()
+    assert cc.geom_alpha.tolist() == g["alpha"].tolist() and cc.geom_alpha_ranges.tolist() == g["alpha_ranges"].tolist()
+    for r in (3, K):
+        assert relerr(cc.geom_constructed(r, "train"), rec["train_r%d" % r]) < 1e-8
+        assert relerr(cc.geom_constructed(r, "test"), rec["test_r%d" % r]) < 1e-8
+    with pytest.raises(ValueError):
+        cc.geom_constructed(3, "validation")
+
+
+@pytest.mark.parametrize("ep,F,K", [(900, 70, 40), (5000, 300, 130)])
+def test_device_deim_equals_the_lstsq_loop_and_the_oracle(ep, F, K, tmp_path, monkeypatch):
+    rng = np.random.default_rng(ep)
+    modes = rng.normal(size=(K + 20, ep, 3))
+    coef = rng.normal(size=(F, K + 20)) * (0.93 ** np.arange(K + 20))[None]
+    frames = 0.2 + np.tensordot(coef, modes, (1, 0)) + 1e-7 * rng.normal(size=(F, ep, 3))
+    ns, cc = _build(frames, K, tmp_path, "deim", "pod_vectorized", 1)
+    cc.post_process_components()
+    cc.deim()
+    dev = cc.geom_Pt.copy()
+    monkeypatch.setenv("ASB_DEIM", "host")
+    cc.deim()
+    assert dev.tolist() == cc.geom_Pt.tolist()
+    assert len(set(dev.tolist())) == K
+    assert dev.tolist() == orc.deim(cc.comps, 1)["Pt"].tolist()

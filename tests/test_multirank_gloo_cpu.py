@@ -148,3 +148,42 @@ def test_unproven_steps_protocol_keeps_the_sequence(monkeypatch, tmp_path):
         stats[spec] = snaps._engine.deflate_stats_project()
     assert stats["0"]["unproven_tried"] == 0
     assert stats["1"]["unproven_kept"] > 0 and stats["1"]["panels"] < stats["0"]["panels"], stats
+
+
+def _comm_worker(rank, world, port):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from animsnapbases_amd import Comm, partition
+        comm = Comm()
+        for rep in range(2):            # the second round reuses the cached exchange tensors
+            a = np.arange(5, dtype=np.float64) * (rank + 1) + rep
+            assert np.array_equal(comm.allreduce_sum(a), np.arange(5) * sum(range(1, world + 1)) + world * rep)
+            assert np.array_equal(comm.allreduce_max(a), np.arange(5) * world + rep)
+            assert comm.allreduce_sum(3.5).shape == (1,)
+            got = comm.all_gather_ints([rank, 10 * rank + rep, -7])
+            assert got.shape == (world, 3) and got.dtype == np.int64
+            assert got.tolist() == [[r, 10 * r + rep, -7] for r in range(world)]
+        # arg-max over ranks: larger value wins, equal values -> the lowest index (NumPy's first maximum)
+        val = np.array([1.0 + rank, 5.0, 2.0 - rank, 0.0])
+        idx = np.array([100 + rank, 50 - rank, 7 + rank, 9 * (world - rank)], dtype=np.int64)
+        best = comm.global_argmax(idx, val)
+        assert best.tolist() == [100 + world - 1, 50 - (world - 1), 7, 9], best
+        # uneven blocks along either axis come back in rank order on every rank
+        N = 4 * world + 1
+        v0, n = partition(N, world)[rank]
+        full = np.arange(3 * N * 2, dtype=np.float64).reshape(3, N, 2)
+        assert np.array_equal(comm.all_gather_rows(full[:, v0:v0 + n], N, axis=1), full)
+        assert np.array_equal(comm.all_gather_rows(full[0, v0:v0 + n], N, axis=0), full[0])
+        assert len(comm._bufs) <= 8              # exchange tensors are cached, not rebuilt per call
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_collectives_gloo(world):
+    """The small-value collectives of Comm (cached exchange tensors, all_reduce / all_gather_into_tensor only)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_comm_worker, args=(world, _free_port()), nprocs=world, join=True)

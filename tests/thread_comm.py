@@ -66,6 +66,16 @@ class ThreadComm(object):
         self._sync()
         self.hub.bar.wait()
 
+    def allreduce_min_tensor(self, t):
+        self._sync()
+        parts = self.hub.exchange(self.rank, t.clone())
+        m = parts[0]
+        for q in parts[1:]:
+            m = self._torch.minimum(m, q)
+        t.copy_(m)
+        self._sync()
+        self.hub.bar.wait()
+
     def all_gather_into(self, out, inp):
         self._sync()
         parts = self.hub.exchange(self.rank, inp.clone())
