@@ -31,6 +31,8 @@ PROTOTYPES = {
     "asb_prof_get": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
     "asb_snapshots_upload": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_i64, c_i64, c_dp]),
     "asb_snapshots_adopt_dev": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp, c_i64, c_i64]),
+    "asb_snapshots_upload_rest": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_i64, c_i64, c_dp, c_int, c_int, c_dp]),
+    "asb_snapshots_adopt_dev_rest": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp, c_i64, c_i64, c_int, c_int, c_dp]),
     "asb_snapshots_center": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(c_dbl)]),
     "asb_snapshots_sqdev": (c_int, [ctypes.c_void_p, c_dbl, ctypes.POINTER(c_dbl)]),
     "asb_snapshots_scale": (c_int, [ctypes.c_void_p, c_dbl]),

@@ -108,9 +108,14 @@ class nonlinearSnapshots:
             self.frames_rows = int(counts.sum())
             self.frs = int(F)
             self.num_constained_elements = self.frames_rows // self.constraintsSize
-            eng.adopt_device(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows)
+            fused = None
+            if self.rest_shape in ("first", "average") and self.param.constProj_standarize:
+                fused = eng.adopt_device_rest(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows,
+                                              0 if self.rest_shape == "first" else 1, True)
+            else:
+                eng.adopt_device(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows)
             if self.param.constProj_standarize:
-                self.standarize()
+                self.standarize(_fused=fused)
             print('nonlinearSnapshots ready ... Volkwein (False), standarized (' + str(self.param.constProj_standarize) + ').')
             return
         self.frames_rows = X.shape[1]
@@ -124,9 +129,13 @@ class nonlinearSnapshots:
         if min(n for _, n in self._shards) == 0:
             raise ValueError("%d constraint rows cannot be sharded over %d ranks: every rank needs at least one row"
                              % (X.shape[1], comm.world))
-        eng.upload(X, v0, n_loc, massL)
+        fused = None
+        if self.param.constProj_standarize and self.rest_shape in ("first", "average") and hasattr(eng, "upload_rest"):
+            fused = eng.upload_rest(X, v0, n_loc, massL, 0 if self.rest_shape == "first" else 1, True)
+        else:
+            eng.upload(X, v0, n_loc, massL)
         if self.param.constProj_standarize:
-            self.standarize()
+            self.standarize(_fused=fused)
         print('nonlinearSnapshots ready ... Volkwein (' + str(self.param.constProj_massWeight) + '), standarized (' +
               str(self.param.constProj_standarize) + ').')
 
@@ -166,17 +175,27 @@ class nonlinearSnapshots:
         self.massL = np.sqrt(self.mass)
         self.invMassL = 1.0 / self.massL
 
-    def standarize(self):
-        """nonlinear_snapshots.py:268-288."""
+    def standarize(self, _fused=None):
+        """nonlinear_snapshots.py:268-288 (``_fused``: sum(x), sum(x^2) when the upload sweep already removed the rest
+        shape -- see posSnapshots.standarize)."""
         eng, comm = self._engine, self._comm
         if self.rest_shape not in ("first", "average"):
             print('Error! unknown rest shape: ', self.rest_shape)
             sys.exit(1)
-        local_sum = eng.center(0 if self.rest_shape == "first" else 1, True)
+        local_sum, local_sumsq = _fused if _fused is not None else (eng.center(0 if self.rest_shape == "first" else 1, True), None)
         self.mean = comm.all_gather_rows(eng.get_mean(), self.frames_rows, axis=0)
         count = float(self.frs) * float(self.frames_rows) * 3.0
-        mu = comm.allreduce_sum(local_sum)[0] / count
-        var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
+        var = None
+        if local_sumsq is not None:
+            tot = comm.allreduce_sum([local_sum, local_sumsq])
+            mu = tot[0] / count
+            v = tot[1] / count - mu * mu
+            if v > 0 and mu * mu <= 10.0 * v:
+                var = v
+        else:
+            mu = comm.allreduce_sum(local_sum)[0] / count
+        if var is None:
+            var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
         self.pre_scale_factor = 1 / np.sqrt(var)
         eng.scale(self.pre_scale_factor)
         self._snapTensor = None

@@ -49,6 +49,7 @@ struct asb_ctx {
     bool have_mean = false;
     // per-vertex energies |X_v|^2 of the PREPARED tensor, a by-product of the last sweep that wrote it (k_scale_energy) or
     // of the first projection-mode begin after X changed; every writer of X clears e0_valid
+    double* tr_part = nullptr;  // per-strip [sum, sum of squares] of the fused layout change
     double* E0 = nullptr;       // (n_loc)
     double* e0_sc = nullptr;    // [|X|^2 of the shard, largest energy]
     bool e0_valid = false;

@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 
+extern "C" int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, double* local_sum);
+
 // --------------------------------------------------------------------------------------
 // Tiled transpose (F, C) <-> (C, Fp) through LDS; optional scaling of column c by
 // colscale[c/3] (mass weighting, posSnapshots.py:82).  32x32 tiles, 256 threads.
@@ -34,6 +36,74 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
         const long long c = c0 + ty + i * 8, r = r0 + tx;
         if (r < rows_in && c < cols_in) out[c * ld_out + r] = tile[tx][ty + i * 8];
     }
+}
+
+// --------------------------------------------------------------------------------------
+// rest_shape "first" fused into the layout change: the rest row of column c is frame 0 of that column, known before
+// anything else is read, so one sweep transposes, mass-weights, subtracts the rest shape (when standardising), writes the
+// zero padding and leaves sum(x) and sum(x^2) of what it wrote -- what k_transpose + k_center + k_sqdev did in three
+// sweeps.  One block per strip of 32 columns over all frames; per-block partials [sum, sum of squares], reduced in order.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_first(const double* __restrict__ in, long long F, long long C, long long ld_in,
+                                                         double* __restrict__ out, long long Fp, const double* __restrict__ colscale,
+                                                         int subtract, double* __restrict__ mean, double* __restrict__ part) {
+    __shared__ double tile[32][33];
+    __shared__ double m_sh[32];
+    __shared__ double red[8];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const long long c0 = (long long)blockIdx.x * 32;
+    if (tid < 32) {
+        const long long c = c0 + tid;
+        double m = 0.0;
+        if (c < C) {
+            m = in[c];
+            if (colscale) m *= colscale[c / 3];
+            mean[c] = m;
+        }
+        m_sh[tid] = m;
+    }
+    __syncthreads();
+    double v2[2] = {0.0, 0.0};
+    for (long long r0 = 0; r0 < F; r0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long r = r0 + ty + i * 8, c = c0 + tx;
+            double v = 0.0;
+            if (r < F && c < C) {
+                v = in[r * ld_in + c];
+                if (colscale) v *= colscale[c / 3];
+            }
+            tile[ty + i * 8][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long c = c0 + ty + i * 8, r = r0 + tx;
+            if (r < F && c < C) {
+                double v = tile[tx][ty + i * 8];
+                if (subtract) v -= m_sh[ty + i * 8];
+                out[c * Fp + r] = v;
+                v2[0] += v;
+                v2[1] += v * v;
+            }
+        }
+        __syncthreads();
+    }
+    const int pad = (int)(Fp - F);
+    for (int q = tid; q < 32 * pad; q += 256) {
+        const long long c = c0 + q / pad;
+        if (c < C) out[c * Fp + F + q % pad] = 0.0;
+    }
+    block_sum<2>(v2, red);
+    if (tid == 0) { part[2 * (long long)blockIdx.x] = v2[0]; part[2 * (long long)blockIdx.x + 1] = v2[1]; }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_pairs(const double* __restrict__ part, long long n, double* __restrict__ out) {
+    __shared__ double red[32];
+    double v[2] = {0.0, 0.0};
+    for (long long i = threadIdx.x; i < n; i += 1024) { v[0] += part[2 * i]; v[1] += part[2 * i + 1]; }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) { out[0] = v[0]; out[1] = v[1]; }
 }
 
 // --------------------------------------------------------------------------------------
@@ -259,7 +329,7 @@ extern "C" int asb_prof_get(asb_ctx* ctx, int64_t* launches, double* total_ms) {
     return ASB_OK;
 }
 
-static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_t n_loc) {
+static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_t n_loc, bool clear = true) {
     if (F < 1 || n_loc < 1 || v0 < 0 || v0 + n_loc > N_glob)
         ASB_FAIL(ctx, ASB_ERR_ARG, "bad snapshot shape F=%lld N=%lld v0=%lld n_loc=%lld", (long long)F,
                  (long long)N_glob, (long long)v0, (long long)n_loc);
@@ -274,7 +344,7 @@ static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->X, (size_t)n_loc * 3 * ctx->Fp))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->mean, (size_t)n_loc * 3))) return rc;
-    ASB_HIP(ctx, hipMemsetAsync(ctx->X, 0, (size_t)n_loc * 3 * ctx->Fp * sizeof(double), ctx->stream));
+    if (clear) ASB_HIP(ctx, hipMemsetAsync(ctx->X, 0, (size_t)n_loc * 3 * ctx->Fp * sizeof(double), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->mean, 0, (size_t)n_loc * 3 * sizeof(double), ctx->stream));
     return ASB_OK;
 }
@@ -330,6 +400,78 @@ extern "C" int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (mdev) (void)hipFree(mdev);
     if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_snapshots_adopt_dev: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// layout change + rest shape (+ its subtraction) in one go; sums_out[0] = sum(x), sums_out[1] = sum(x^2) of the shard as it
+// stands afterwards (rest_shape 1, "average", needs the column means first: the separate sweeps, sums_out[1] = -1)
+static int transpose_rest(asb_ctx* ctx, const double* stage_dev, const double* massL_dev, int rest_shape, int subtract, double* sums_out) {
+    const long long C = ctx->n_loc * 3;
+    if (rest_shape != 0) {
+        int rc = transpose_in(ctx, stage_dev, massL_dev);
+        if (rc) return rc;
+        sums_out[1] = -1.0;
+        return asb_snapshots_center(ctx, rest_shape, subtract, &sums_out[0]);
+    }
+    const long long nb = (C + 31) / 32;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->tr_part, (size_t)2 * nb))) return rc;
+    hipLaunchKernelGGL(k_transpose_first, dim3((unsigned)nb), dim3(256), 0, ctx->stream, stage_dev, (long long)ctx->F, C, C, ctx->X,
+                       (long long)ctx->Fp, massL_dev, subtract, ctx->mean, ctx->tr_part);
+    ASB_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->tr_part, nb, ctx->scalar_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->have_mean = true;
+    ctx->e0_valid = false;
+    ASB_HIP(ctx, hipMemcpyAsync(sums_out, ctx->scalar_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+extern "C" int asb_snapshots_upload_rest(asb_ctx* ctx, const double* X, int64_t F, int64_t N_glob, int64_t v0, int64_t n_loc,
+                                         const double* massL, int rest_shape, int subtract, double* sums_out) {
+    if (!ctx || !X || !sums_out) return ASB_ERR_ARG;
+    if (rest_shape != 0 && rest_shape != 1) ASB_FAIL(ctx, ASB_ERR_ARG, "unknown rest shape code %d", rest_shape);
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));
+    int rc = set_shape(ctx, F, N_glob, v0, n_loc, rest_shape != 0);
+    if (rc) return rc;
+    double* stage = nullptr;
+    double* mdev = nullptr;
+    const size_t C = (size_t)n_loc * 3;
+    ASB_HIP(ctx, hipMalloc((void**)&stage, (size_t)F * C * sizeof(double)));
+    hipError_t e = hipMemcpy2DAsync(stage, C * sizeof(double), X + v0 * 3, (size_t)N_glob * 3 * sizeof(double),
+                                    C * sizeof(double), (size_t)F, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && massL) {
+        e = hipMalloc((void**)&mdev, (size_t)n_loc * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(mdev, massL + v0, (size_t)n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        rc = transpose_rest(ctx, stage, mdev, rest_shape, subtract, sums_out);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(stage);
+    if (mdev) (void)hipFree(mdev);
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_snapshots_upload_rest: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int asb_snapshots_adopt_dev_rest(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc, const double* massL_loc,
+                                            int64_t v0, int64_t N_glob, int rest_shape, int subtract, double* sums_out) {
+    if (!ctx || !X_dev || !sums_out) return ASB_ERR_ARG;
+    if (rest_shape != 0 && rest_shape != 1) ASB_FAIL(ctx, ASB_ERR_ARG, "unknown rest shape code %d", rest_shape);
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));
+    int rc = set_shape(ctx, F, N_glob, v0, n_loc, rest_shape != 0);
+    if (rc) return rc;
+    double* mdev = nullptr;
+    if (massL_loc) {
+        ASB_HIP(ctx, hipMalloc((void**)&mdev, (size_t)n_loc * sizeof(double)));
+        ASB_HIP(ctx, hipMemcpyAsync(mdev, massL_loc, (size_t)n_loc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = transpose_rest(ctx, X_dev, mdev, rest_shape, subtract, sums_out);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (mdev) (void)hipFree(mdev);
+    if (e != hipSuccess) ASB_FAIL(ctx, ASB_ERR_HIP, "asb_snapshots_adopt_dev_rest: %s", hipGetErrorString(e));
     return rc;
 }
 

@@ -92,6 +92,30 @@ class HipEngine(object):
                                                   int(v0), N_glob))
         self.F, self.N_glob, self.v0, self.n_loc = int(F), N_glob, int(v0), int(n_loc)
 
+    def upload_rest(self, X, v0, n_loc, massL, rest_shape_code, subtract):
+        """upload + rest shape in one sweep: (sum(x), sum(x^2) or None)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        F, N, three = X.shape
+        assert three == 3
+        if massL is not None:
+            massL = np.ascontiguousarray(massL, dtype=np.float64)
+            assert massL.shape == (N,)
+        sums = np.zeros(2)
+        self._ck(self.lib.asb_snapshots_upload_rest(self.h, ptr(X), F, N, int(v0), int(n_loc), ptr(massL), int(rest_shape_code),
+                                                    int(bool(subtract)), ptr(sums)))
+        self.F, self.N_glob, self.v0, self.n_loc = F, N, int(v0), int(n_loc)
+        return float(sums[0]), (float(sums[1]) if sums[1] >= 0 else None)
+
+    def adopt_device_rest(self, dev_ptr, F, n_loc, massL_loc, v0, N_glob, rest_shape_code, subtract):
+        if massL_loc is not None:
+            massL_loc = np.ascontiguousarray(massL_loc, dtype=np.float64)
+        N_glob = int(n_loc if N_glob is None else N_glob)
+        sums = np.zeros(2)
+        self._ck(self.lib.asb_snapshots_adopt_dev_rest(self.h, ctypes.c_void_p(dev_ptr), int(F), int(n_loc), ptr(massL_loc),
+                                                       int(v0), N_glob, int(rest_shape_code), int(bool(subtract)), ptr(sums)))
+        self.F, self.N_glob, self.v0, self.n_loc = int(F), N_glob, int(v0), int(n_loc)
+        return float(sums[0]), (float(sums[1]) if sums[1] >= 0 else None)
+
     def center(self, rest_shape_code, subtract):
         s = ctypes.c_double()
         self._ck(self.lib.asb_snapshots_center(self.h, int(rest_shape_code), int(bool(subtract)), ctypes.byref(s)))

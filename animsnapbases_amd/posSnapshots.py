@@ -114,6 +114,7 @@ class posSnapshots:
         eng, comm = self._engine, self._comm
 
         massL = None
+        fused = None
         if massWeight:
             self.read_factorize_masses()
             assert self.nVerts == self.massL.shape[0]
@@ -134,18 +135,26 @@ class posSnapshots:
                 v0 += int(n)
             self.nVerts = int(counts.sum())
             self.frs = F
-            eng.adopt_device(ptr_, F, N, None, self._shards[comm.rank][0], self.nVerts)
+            code = 0 if self.rest_shape == "first" else 1
+            if hasattr(eng, "adopt_device_rest"):       # layout change + rest shape (+ sums for the std) in one sweep
+                fused = eng.adopt_device_rest(ptr_, F, N, None, self._shards[comm.rank][0], self.nVerts, code, standarize)
+            else:
+                eng.adopt_device(ptr_, F, N, None, self._shards[comm.rank][0], self.nVerts)
         else:
             v0, n_loc = comm.my_shard(self.nVerts)
             self._shards = comm.shards(self.nVerts)
             if min(n for _, n in self._shards) == 0:        # every rank sees the same partition and raises together
                 raise ValueError("%d vertices cannot be sharded over %d ranks: every rank needs at least one vertex"
                                  % (self.nVerts, comm.world))
-            eng.upload(self.verts, v0, n_loc, massL)      # (:73, :82) copy + M^{1/2} X, vertex-major
+            code = 0 if self.rest_shape == "first" else 1
+            if hasattr(eng, "upload_rest"):             # (:73, :82, :85-89) copy + M^{1/2} X, vertex-major, rest shape: one sweep
+                fused = eng.upload_rest(self.verts, v0, n_loc, massL, code, standarize)
+            else:
+                eng.upload(self.verts, v0, n_loc, massL)
 
         # rest shape (:85-89); the mean row is subtracted only when standardising (:168)
         code = 0 if self.rest_shape == "first" else 1
-        local_sum = eng.center(code, standarize)
+        local_sum, local_sumsq = fused if fused is not None else (eng.center(code, standarize), None)
         self.mean = comm.all_gather_rows(eng.get_mean(), self.nVerts, axis=0)
 
         # geodesics on the NON-weighted shape (:96-99); host SciPy
@@ -170,7 +179,7 @@ class posSnapshots:
                 backend="dense" if mode == "dense" else "pcg")
 
         if standarize:
-            self.standarize(_local_sum=local_sum)
+            self.standarize(_local_sum=local_sum, _local_sumsq=local_sumsq)
         print('Snapshots ready... Volkwein (' + str(massWeight) + '), standarized (' + str(standarize) + ').')
 
     @log_time("")
@@ -212,15 +221,26 @@ class posSnapshots:
         self.invMassL = 1.0 / self.massL
 
     @log_time("")
-    def standarize(self, _local_sum=None):
+    def standarize(self, _local_sum=None, _local_sumsq=None):
         """posSnapshots.py:163-172: after the mean row is gone, divide by the population
-        standard deviation of ALL entries (np.std: two passes)."""
+        standard deviation of ALL entries (np.std).  When the layout-change sweep already delivered sum(x) and sum(x^2),
+        var = sum(x^2)/n - mu^2 (relative error eps (1 + mu^2/var)); only if the mean dominates (mu^2 > 10 var) the exact
+        second pass over the tensor is taken."""
         eng, comm = self._engine, self._comm
         if _local_sum is None:
             _local_sum = eng.center(0 if self.rest_shape == "first" else 1, True)
         count = float(self.frs) * float(self.nVerts) * 3.0
-        mu = comm.allreduce_sum(_local_sum)[0] / count
-        var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
+        var = None
+        if _local_sumsq is not None:
+            tot = comm.allreduce_sum([_local_sum, _local_sumsq])
+            mu = tot[0] / count
+            v = tot[1] / count - mu * mu
+            if v > 0 and mu * mu <= 10.0 * v:
+                var = v
+        else:
+            mu = comm.allreduce_sum(_local_sum)[0] / count
+        if var is None:
+            var = comm.allreduce_sum(eng.sqdev(mu))[0] / count
         self.pre_scale_factor = 1 / np.sqrt(var)
         eng.scale(self.pre_scale_factor)
         self._snapTensor = None

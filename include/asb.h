@@ -77,6 +77,15 @@ int asb_snapshots_adopt_dev(asb_ctx* ctx, const double* X_dev, int64_t F, int64_
  * average (1); when subtract != 0 the mean row is subtracted.  local_sum = sum of all
  * entries of the shard afterwards (for the global mean of np.std). */
 int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, double* local_sum);
+/* asb_snapshots_upload / asb_snapshots_adopt_dev followed by asb_snapshots_center in ONE sweep over the data: with
+ * rest_shape 0 ("first", :86) the rest row is frame 0 of the input, so the layout change subtracts it on the fly and also
+ * returns sums_out[0] = sum(x) and sums_out[1] = sum(x^2) of the prepared shard (np.std of :170 then needs no sweep of its
+ * own: var = sum(x^2)/n - mu^2, the caller falls back to asb_snapshots_sqdev when mu^2 >> var).  rest_shape 1 ("average")
+ * runs the separate sweeps and returns sums_out[1] = -1. */
+int asb_snapshots_upload_rest(asb_ctx* ctx, const double* X, int64_t F, int64_t N_glob, int64_t v0, int64_t n_loc,
+                              const double* massL, int rest_shape, int subtract, double* sums_out);
+int asb_snapshots_adopt_dev_rest(asb_ctx* ctx, const double* X_dev, int64_t F, int64_t n_loc, const double* massL_loc,
+                                 int64_t v0, int64_t N_glob, int rest_shape, int subtract, double* sums_out);
 /* sum over the shard of (x - mu)^2 -- second pass of np.std, :171 */
 int asb_snapshots_sqdev(asb_ctx* ctx, double mu, double* local_sqdev);
 /* snapTensor *= pre_scale_factor, :172 */

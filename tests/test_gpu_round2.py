@@ -99,3 +99,35 @@ def test_panel_kernel_timeout_falls_back_to_the_two_kernel_loop(monkeypatch):
     ref, st = _run(verts, K)
     assert st[0]["coop_fallbacks"] == 0
     assert relerr(comp.comps, ref.comps) < 1e-11
+
+
+def test_panel_kernel_shares_the_gpu_with_other_contexts():
+    """Four vertex shards, each context on its OWN stream, ASB_PANEL_COOP left on: the co-resident panel kernels of
+    different contexts can be in flight together, so a launch may find part of the GPU taken.  Whatever happens -- all
+    blocks resident, or the record exchange timing out and the panel redone by the two-kernel loop -- every shard must
+    deliver the oracle's sequence and identical weights."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(61)
+    verts, K = rng.uniform(-1, 1, size=(80, 16000, 3)), 34
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0), comm=comm)
+            comp = posComponents(_param(K), snaps)
+            comp.deflate_mode = "project"
+            comp.compute_components_store_singvalues()
+        return comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), snaps._engine.deflate_stats()
+
+    outs = run_ranks(4, rank_fn)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    for idx, comps, weigs, st in outs:
+        assert idx.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comps, weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+        assert st["coop_fallbacks"] in (0, 1)
+    for o in outs[1:]:
+        assert np.array_equal(o[2], outs[0][2])
