@@ -41,6 +41,9 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     _, rows_loc, idx_loc, top_loc, top_all = bufs
     packed_ok = hasattr(eng, "panel_assemble_packed")
     spec_word = torch.zeros(1, dtype=torch.float64, device=dev) if (hasattr(eng, "panel_project_spec_dev") and dev.type != "cpu") else None
+    # lock-step protection of the co-resident panel kernel (see below): only with the real engine, several ranks, kernel on
+    coop_check = bool(spec_word is not None and comm.multi and hasattr(eng, "panel_set_coop") and
+                      os.environ.get("ASB_PANEL_COOP", "1") != "0")
     global_all = n_rows <= cap
     spec_budget = 16 if (hasattr(eng, "panel_run_spec") and os.environ.get("ASB_SPEC_PANELS", "1") != "0") else 0
     k, stalled, forced_next = 0, 0, -1
@@ -89,11 +92,43 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                 comm.all_gather_into(idx_g, idx_loc[:maxc])
                 eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
             steps = 1 if forced >= 0 else min(16, K - k)
-            if spec_budget and not take_all and stalled == 0:
-                done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)
-            else:
-                done = proven = eng.panel_run(k, steps, take_all)
-            if done > proven:                             # the tail is unproven: the pass decides how much of it stands
+            while True:
+                if spec_budget and not take_all and stalled == 0:
+                    done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)
+                else:
+                    done = proven = eng.panel_run(k, steps, take_all)
+                if not coop_check:
+                    if done < 0:          # one rank (tests): the context has switched the timed-out kernel off; repeat
+                        continue
+                    break
+                # The co-resident panel kernel can time out on ONE rank (its GPU shared with other work).  Every rank must
+                # then redo the panel the same way -- the two-kernel loop, whose steps are the provable ones -- or the
+                # ranks fall out of lock-step.  The status rides on the min all-reduce that panels with unproven steps
+                # need anyway: a rank whose launch failed contributes -1 (and skips its pass).
+                if done > proven and done > 0:
+                    eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
+                    passed = True
+                else:
+                    spec_word.fill_(float(done))             # -1: failed here; otherwise the fully proven count
+                    passed = False
+                comm.allreduce_min_tensor(spec_word)
+                agreed = int(spec_word.item())
+                if agreed >= 0:
+                    break
+                eng.panel_set_coop(False)                    # somewhere the exchange timed out: all ranks leave the kernel
+                coop_check = False
+            if coop_check:
+                if passed:                                    # unproven tail: `agreed` of the steps stand on every shard
+                    done = agreed
+                    eng.panel_commit(k, done)
+                    gain = done - proven
+                    spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
+                    if done > 0:
+                        stalled = 0
+                        k += done
+                        continue
+                # fully proven (or nothing ran): falls through to the plain pass / the refresh below
+            elif done > proven:                           # the tail is unproven: the pass decides how much of it stands
                 if spec_word is not None:                 # count stays on the device: min over ranks, ONE read
                     eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
                     comm.allreduce_min_tensor(spec_word)

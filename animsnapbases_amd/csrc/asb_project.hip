@@ -2406,6 +2406,14 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
             ctx->panel_coop = 0;
             ctx->coop_test_stall = 0;
             ctx->n_coop_fallbacks++;
+            if (assembled) {
+                // several ranks run this panel on identical data and must take identical decisions: the redo is the
+                // DRIVER's, on every rank together (committed = -1 tells it; see _panels.py)
+                ctx->n_panels--;
+                *committed = -1;
+                ctx->run_proven = 0;
+                return ASB_OK;
+            }
             ctx->n_panels--;
             rc = asb_panel_run(ctx, k0, steps, global_all, assembled, committed);
             ctx->run_coop_used = 0;
@@ -2555,6 +2563,13 @@ extern "C" int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max
     return ASB_OK;
 }
 
+// multi-rank driver: switch the co-resident panel kernel on / off for this context (all ranks together); returns the old value
+extern "C" int asb_panel_set_coop(asb_ctx* ctx, int on) {
+    if (!ctx) return ASB_ERR_ARG;
+    const int old = ctx->panel_coop;
+    ctx->panel_coop = on ? 1 : 0;
+    return old;
+}
 extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_cap : 0; }
 extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? ctx->m_target : 0; }
 

@@ -273,6 +273,10 @@ class HipEngine(object):
     def panel_project_spec_dev(self, k0, ncols, proven, out_dev_ptr):
         self._ck(self.lib.asb_panel_project_spec_dev(self.h, int(k0), int(ncols), int(proven), ctypes.c_void_p(out_dev_ptr)))
 
+    def panel_set_coop(self, on):
+        """Switches the co-resident panel kernel on / off; returns the previous setting."""
+        return int(self.lib.asb_panel_set_coop(self.h, int(bool(on))))
+
     def panel_commit(self, k0, kept):
         self._ck(self.lib.asb_panel_commit(self.h, int(k0), int(kept)))
 

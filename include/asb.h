@@ -209,6 +209,11 @@ int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes);
  * (k_panel_coop).  If that exchange times out -- the blocks were not all resident because something else shares the GPU --
  * the panel is redone by the two-kernel loop and the context stays on it; *n = how often that happened (lifetime). */
 int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
+/* Multi-rank runs (assembled candidate buffer): a timed-out exchange is NOT redone locally -- the ranks must stay in
+ * lock-step -- asb_panel_run / asb_panel_run_spec then return *committed = -1 with the kernel switched off for this context;
+ * the driver min-reduces that over the ranks, switches it off everywhere (asb_panel_set_coop, returns the old setting) and
+ * repeats the panel on every rank. */
+int asb_panel_set_coop(asb_ctx* ctx, int on);
 /* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
 int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 

@@ -131,3 +131,35 @@ def test_panel_kernel_shares_the_gpu_with_other_contexts():
         assert st["coop_fallbacks"] in (0, 1)
     for o in outs[1:]:
         assert np.array_equal(o[2], outs[0][2])
+
+
+def test_multirank_panel_kernel_timeout_is_redone_in_lock_step(monkeypatch):
+    """Three shards through the multi-rank panel protocol; every context's first co-resident launch is made to time out
+    (ASB_COOP_TEST_STALL).  The status rides on the panel's min all-reduce, all ranks switch the kernel off together and
+    repeat the panel with the two-kernel loop: oracle sequence, identical weights on every rank, one fallback each."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    monkeypatch.setenv("ASB_COOP_TEST_STALL", "1")
+    rng = np.random.default_rng(67)
+    verts, K = rng.uniform(-1, 1, size=(64, 9000, 3)), 26
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(_param(K), snaps)
+            comp.deflate_mode = "project"
+            comp.compute_components_store_singvalues()
+        return comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), snaps._engine.deflate_stats()
+
+    outs = run_ranks(3, rank_fn)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    for idx, comps, weigs, st in outs:
+        assert idx.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comps, weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+        assert st["coop_fallbacks"] == 1
+    for o in outs[1:]:
+        assert np.array_equal(o[2], outs[0][2])
