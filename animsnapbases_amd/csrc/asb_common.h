@@ -134,6 +134,7 @@ struct asb_ctx {
     PanelState* pstate = nullptr;
     PanelState* pstate2 = nullptr;         // double panels: the first sub-panel's state, kept for its check after the pass
     int double_panels = 0;                 // ASB_DOUBLE_PANELS=1 (experimental)
+    int dbl_budget = 12;                   // steps given to the second sub-panel (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
@@ -154,6 +155,7 @@ struct asb_ctx {
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
+    double* td_ppart = nullptr;                   // partial mat-vec vectors of the tridiagonalisation (one per column chunk)
     double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
     int64_t td_n = 0;
     // asb_smalldense.hip: tridiagonal eigen-solver, one-sided Jacobi, blocked Cholesky

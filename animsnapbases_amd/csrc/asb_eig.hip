@@ -18,7 +18,8 @@
 #define TD_T 1024
 
 // step `j` (j = -1: only the first Householder vector from row 0).  vcur = v_j, vnext = v_{j+1} (absolute row index).
-__global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n, int j, const double* __restrict__ p,
+// p arrives as `nch` partial vectors (one per column chunk of k_td_update, each n long): summed here in chunk order
+__global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n, int j, const double* __restrict__ p, int nch,
                                                   const double* __restrict__ vcur, double* __restrict__ w,
                                                   double* __restrict__ vnext, double* __restrict__ xbuf,
                                                   double* __restrict__ tau, double* __restrict__ d, double* __restrict__ e) {
@@ -29,11 +30,16 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
     double wfirst = 0.0;
     if (j >= 0) {
         double acc[1] = {0.0};
-        for (int r = r0 + tid; r < n; r += TD_T) acc[0] += p[r] * vcur[r];
+        for (int r = r0 + tid; r < n; r += TD_T) {
+            double pr = p[r];
+            for (int c = 1; c < nch; ++c) pr += p[(long long)c * n + r];
+            xbuf[r] = pr;                       // (xbuf is free until the row is formed below)
+            acc[0] += pr * vcur[r];
+        }
         block_sum<1>(acc, sh);
         const double half = 0.5 * tau[j] * acc[0];
         for (int r = r0 + tid; r < n; r += TD_T) {
-            const double wr = p[r] - half * vcur[r];
+            const double wr = xbuf[r] - half * vcur[r];
             w[r] = wr;
             if (r == r0) bc[0] = wr;
         }
@@ -84,16 +90,24 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
     }
 }
 
-// trailing block rows/cols >= r1 = j + 2:  A -= vcur w^T + w vcur^T (when `update`), then p[i] = taun * sum_c A[i][c] vnext[c]
+// trailing block rows/cols >= r1 = j + 2:  A -= vcur w^T + w vcur^T (when `update`), then the next step's symmetric mat-vec
+// p[i] = taun * sum_c A[i][c] vnext[c].  Work item = (group of R rows) x (chunk of TD_CW columns): a wave handles one item
+// and writes its partial row sums to p[chunk * n + i] (k_td_small adds the chunks in order: deterministic) -- a 2-D
+// decomposition, so that even the 128 MB start matrix gives every SIMD several waves and the sweep runs at the rate of the
+// Infinity Cache instead of one wave's latency chain per four rows.
+#define TD_CW 512
 template <int R>
 __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n, int r1, int update,
                                                   const double* __restrict__ vcur, const double* __restrict__ w,
                                                   const double* __restrict__ vnext, const double* __restrict__ tau_next,
-                                                  double* __restrict__ p) {
+                                                  double* __restrict__ p, int nch) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
     const double tn = *tau_next;
-    for (int i0 = r1 + wave * R; i0 < n; i0 += nwaves * R) {
+    const int ngroups = (n - r1 + R - 1) / R;
+    for (long long item = wave; item < (long long)ngroups * nch; item += nwaves) {
+        const int i0 = r1 + (int)(item / nch) * R, cc = (int)(item % nch);
+        const int c_lo = r1 + cc * TD_CW, c_hi = (c_lo + TD_CW < n) ? c_lo + TD_CW : n;
         double vi[R], wi[R], acc[R];
         double* rowp[R];
 #pragma unroll
@@ -104,22 +118,34 @@ __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n
             acc[q] = 0.0;
             rowp[q] = A + (long long)i * n;
         }
-        for (int c = r1 + lane; c < n; c += 64) {
+        for (int c = c_lo + lane; c < c_hi; c += 128) {       // two column positions per lane in flight
+            const int c2 = c + 64;
+            const bool on2 = c2 < c_hi;
             const double vc = update ? vcur[c] : 0.0, wc = update ? w[c] : 0.0, vn = vnext[c];
+            const double vc2 = (update && on2) ? vcur[c2] : 0.0, wc2 = (update && on2) ? w[c2] : 0.0, vn2 = on2 ? vnext[c2] : 0.0;
+            double a[R], b[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                double a = rowp[q][c];
+                a[q] = rowp[q][c];
+                b[q] = on2 ? rowp[q][c2] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
                 if (update) {
-                    a -= vi[q] * wc + wi[q] * vc;
-                    if (i0 + q < n) rowp[q][c] = a;
+                    a[q] -= vi[q] * wc + wi[q] * vc;
+                    b[q] -= vi[q] * wc2 + wi[q] * vc2;
+                    if (i0 + q < n) {
+                        rowp[q][c] = a[q];
+                        if (on2) rowp[q][c2] = b[q];
+                    }
                 }
-                acc[q] += a * vn;
+                acc[q] += a[q] * vn + b[q] * vn2;
             }
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const double s = wave_sum(acc[q]);
-            if (lane == 0 && i0 + q < n) p[i0 + q] = tn * s;
+            if (lane == 0 && i0 + q < n) p[(long long)cc * n + i0 + q] = tn * s;
         }
     }
 }
@@ -169,12 +195,14 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
     if (n64 > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: n = %lld too large", (long long)n64);
     const int n = (int)n64;
     int rc;
+    const int nch_max = (n + TD_CW - 1) / TD_CW;
     if ((rc = asb_alloc(ctx, &ctx->td_work, (size_t)8 * n))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->td_ppart, (size_t)nch_max * n))) return rc;
     double* vb0 = ctx->td_work;
     double* vb1 = vb0 + n;
     double* w = vb1 + n;
-    double* p = w + n;
-    double* xbuf = p + n;
+    double* p = ctx->td_ppart;                  // partial mat-vec results, one vector per column chunk
+    double* xbuf = ctx->td_work + (size_t)4 * n;      // (slot 3 n, the old single p vector, stays unused)
     double* tau = xbuf + n;
     double* d = tau + n;
     double* e = d + n;
@@ -193,18 +221,22 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
     // d[0] is never touched by a reflector
     ASB_HIP(ctx, hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     constexpr int R = 4;
+    int nch_prev = 1;
     for (int j = -1; j <= n - 3; ++j) {
         double* vcur = (j & 1) ? vb1 : vb0;          // j = -1 -> vb1 (unused)
         double* vnext = ((j + 1) & 1) ? vb1 : vb0;
         // k_td_small(j) writes d[j+1]; for j = -1 it would overwrite d[0] with the same value A[0][0]
-        hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, vcur, w, vnext, xbuf, tau, d, e);
+        hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, xbuf, tau, d, e);
         if (j + 1 <= n - 3) {
             const int r1 = j + 2, rows = n - r1;
-            int grid = (rows + 4 * R - 1) / (4 * R);
-            if (grid > 2048) grid = 2048;
+            const int nch = (rows + TD_CW - 1) / TD_CW;
+            const long long items = (long long)((rows + R - 1) / R) * nch;
+            long long gridl = (items + 3) / 4;
+            int grid = (int)(gridl > 4096 ? 4096 : gridl);
             if (grid < 1) grid = 1;
             hipLaunchKernelGGL((k_td_update<R>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
-                               tau + (j + 1), p);
+                               tau + (j + 1), p, nch);
+            nch_prev = nch;
         }
     }
     ASB_CHECK_LAUNCH(ctx);

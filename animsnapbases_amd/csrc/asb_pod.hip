@@ -286,39 +286,47 @@ __global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict_
 // k_deim_solve (one block per dimension): grows the inverse by last step's point / vector, then coef[i] = Minv b with
 // b = Mx[i][:k, k]; the solve is verified (|M x - b| against rounding level), a failure raises flags[0] and the caller
 // repeats the loop with the reference's lstsq on the host.
-__global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ Mx, double* __restrict__ Minv, int K, int k,
+// Both the matrices of points (Mx, and MxT[i][j][m] = Mx[i][m][j]) and the inverse (Minv and its transpose MinvT) are kept in
+// two layouts so that every product below reads consecutive words across a wave.
+__global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ Mx, const double* __restrict__ MxT,
+                                                    double* __restrict__ Minv, double* __restrict__ MinvT, int K, int k,
                                                     double* __restrict__ coef, int* __restrict__ flags) {
-    extern __shared__ double sh[];               // u (K), w (K), x (K), red (8)
+    extern __shared__ double sh[];               // u (K), w (K), x (K), red (16)
     double* u = sh;
     double* w = u + K;
     double* x = w + K;
     double* red = x + K;
     const int i = blockIdx.x, tid = threadIdx.x;
     const double* M = Mx + (size_t)i * K * K;
+    const double* MT = MxT + (size_t)i * K * K;
     double* A = Minv + (size_t)i * K * K;
+    double* AT = MinvT + (size_t)i * K * K;
     const int n = k - 1;                         // size of the inverse carried over
     if (k == 1) {
         if (tid == 0) {
             const double m00 = M[0];
             if (m00 == 0.0 || !(m00 == m00)) flags[0] = 1;
             A[0] = 1.0 / m00;
+            AT[0] = 1.0 / m00;
         }
     } else {
-        // u = A bcol, w = crow A   (bcol[m] = M[m][n], crow[j] = M[n][j])
+        // u = A bcol, w = crow A   (bcol[q] = M[q][n] = MT[n][q], crow[q] = M[n][q])
+        const double* bcol = MT + (size_t)n * K;
+        const double* crow = M + (size_t)n * K;
         for (int r = tid; r < n; r += 256) {
             double su = 0.0, sw = 0.0;
             for (int q = 0; q < n; ++q) {
-                su += A[(size_t)r * K + q] * M[(size_t)q * K + n];
-                sw += M[(size_t)n * K + q] * A[(size_t)q * K + r];
+                su += AT[(size_t)q * K + r] * bcol[q];        // A[r][q]
+                sw += crow[q] * A[(size_t)q * K + r];
             }
             u[r] = su;
             w[r] = sw;
         }
         __syncthreads();
         double part[1] = {0.0};
-        for (int q = tid; q < n; q += 256) part[0] += M[(size_t)n * K + q] * u[q];
+        for (int q = tid; q < n; q += 256) part[0] += crow[q] * u[q];
         block_sum<1>(part, red);
-        const double sch = M[(size_t)n * K + n] - part[0];
+        const double sch = crow[n] - part[0];
         if (sch == 0.0 || !(sch == sch) || fabs(sch) > 1.7e308) {
             if (tid == 0) flags[0] = 1;
             return;
@@ -327,35 +335,38 @@ __global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ M
         for (int e = tid; e < n * n; e += 256) {
             const int r = e / n, c = e % n;
             A[(size_t)r * K + c] += u[r] * w[c] * is;
+            AT[(size_t)r * K + c] += u[c] * w[r] * is;        // AT[r][c] = A[c][r]
         }
         for (int r = tid; r < n; r += 256) {
             A[(size_t)r * K + n] = -u[r] * is;
             A[(size_t)n * K + r] = -w[r] * is;
+            AT[(size_t)n * K + r] = -u[r] * is;
+            AT[(size_t)r * K + n] = -w[r] * is;
         }
-        if (tid == 0) A[(size_t)n * K + n] = is;
+        if (tid == 0) { A[(size_t)n * K + n] = is; AT[(size_t)n * K + n] = is; }
     }
     __threadfence_block();
     __syncthreads();
-    // x = A[:k, :k] b,  b[m] = M[m][k]
+    // x = A[:k, :k] b,  b[m] = M[m][k] = MT[k][m]
+    const double* b = MT + (size_t)k * K;
     double nb2 = 0.0, nx2 = 0.0, nm2 = 0.0;
     for (int r = tid; r < k; r += 256) {
         double sx = 0.0;
         for (int q = 0; q < k; ++q) {
-            sx += A[(size_t)r * K + q] * M[(size_t)q * K + k];
-            const double m = M[(size_t)r * K + q];
+            sx += AT[(size_t)q * K + r] * b[q];
+            const double m = MT[(size_t)q * K + r];
             nm2 += m * m;
         }
         x[r] = sx;
         coef[(size_t)i * k + r] = sx;
         nx2 += sx * sx;
-        const double b = M[(size_t)r * K + k];
-        nb2 += b * b;
+        nb2 += b[r] * b[r];
     }
     __syncthreads();
     double res2 = 0.0;
     for (int r = tid; r < k; r += 256) {
-        double sr = -M[(size_t)r * K + k];
-        for (int q = 0; q < k; ++q) sr += M[(size_t)r * K + q] * x[q];
+        double sr = -b[r];
+        for (int q = 0; q < k; ++q) sr += MT[(size_t)q * K + r] * x[q];     // M[r][q]
         res2 += sr * sr;
     }
     double v[4] = {nb2, nx2, nm2, res2};
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ M
 __global__ __launch_bounds__(256) void k_deim_pick(const double* __restrict__ pmax, const long long* __restrict__ pidx,
                                                    const double* __restrict__ pabs, int nblk, const double* __restrict__ comps,
                                                    long long n_vert, int K, int k, long long* __restrict__ Pt,
-                                                   double* __restrict__ maxabs, double* __restrict__ Mx) {
+                                                   double* __restrict__ maxabs, double* __restrict__ Mx, double* __restrict__ MxT) {
     __shared__ double sh_d[256];
     __shared__ long long sh_i[256];
     __shared__ double sh_a[256];
@@ -396,7 +407,9 @@ __global__ __launch_bounds__(256) void k_deim_pick(const double* __restrict__ pm
     if (threadIdx.x == 0) { Pt[k] = idx; maxabs[k] = sh_a[0]; }
     for (int q = threadIdx.x; q < 3 * K; q += 256) {
         const int i = q / K, j = q % K;
-        Mx[(size_t)i * K * K + (size_t)k * K + j] = comps[(long long)j * 3 * n_vert + 3 * idx + i];
+        const double val = comps[(long long)j * 3 * n_vert + 3 * idx + i];
+        Mx[(size_t)i * K * K + (size_t)k * K + j] = val;
+        MxT[(size_t)i * K * K + (size_t)j * K + k] = val;
     }
 }
 
@@ -409,12 +422,14 @@ extern "C" int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, i
     if (ctx->n_loc != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deim_run needs all rows on one rank");
     const int K = (int)ctx->K;
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->deim_m, (size_t)6 * K * K + 4 * (size_t)K + 2048 * 2))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->deim_m, (size_t)12 * K * K + 4 * (size_t)K + 2048 * 2))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->deim_pt, (size_t)K + 2048))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
     double* Mx = ctx->deim_m;
-    double* Minv = Mx + (size_t)3 * K * K;
-    double* coef = Minv + (size_t)3 * K * K;          // 3 K
+    double* MxT = Mx + (size_t)3 * K * K;
+    double* Minv = MxT + (size_t)3 * K * K;
+    double* MinvT = Minv + (size_t)3 * K * K;
+    double* coef = MinvT + (size_t)3 * K * K;         // 3 K
     double* maxabs = coef + (size_t)3 * K;            // K
     double* pmax = maxabs + K;                        // 2048
     double* pabs = pmax + 2048;                       // 2048
@@ -426,12 +441,12 @@ extern "C" int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, i
     const size_t lds_solve = ((size_t)3 * K + 16) * sizeof(double);
     for (int k = 0; k < K; ++k) {
         if (k > 0) {
-            hipLaunchKernelGGL(k_deim_solve, dim3(3), dim3(256), lds_solve, ctx->stream, Mx, Minv, K, k, coef, ctx->la_status);
+            hipLaunchKernelGGL(k_deim_solve, dim3(3), dim3(256), lds_solve, ctx->stream, Mx, MxT, Minv, MinvT, K, k, coef, ctx->la_status);
         }
         hipLaunchKernelGGL(k_deim_residual, dim3(grid), dim3(256), (size_t)(3 * k + 1) * sizeof(double), ctx->stream, ctx->comps,
                            (long long)ctx->n_loc, k, coef, (long long)ctx->v0, pmax, pidx, pabs);
         hipLaunchKernelGGL(k_deim_pick, dim3(1), dim3(256), 0, ctx->stream, pmax, pidx, pabs, grid, ctx->comps, (long long)ctx->n_loc,
-                           K, k, Pt, maxabs, Mx);
+                           K, k, Pt, maxabs, Mx, MxT);
     }
     ASB_CHECK_LAUNCH(ctx);
     int st[4];

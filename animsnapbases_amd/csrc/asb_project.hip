@@ -2641,9 +2641,16 @@ static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_ou
 // check and energy update, and only if all of it stands the second tile's against the updated energies.
 static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelState* st, int64_t* kept) {
     const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
-    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram);
+    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram,
+                       ctx->gram_s, ctx->wn2t3 + 16 * ct);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    if (ctx->correct_rows) {
+        long long cwr = (ctx->n_loc + 63) / 64;
+        hipLaunchKernelGGL(k_correct_rows<true>, dim3((unsigned)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap)), dim3(192), 0, ctx->stream,
+                           ctx->comps, (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)kb, nc, ctx->gram_s, ctx->wn2t3 + 16 * ct,
+                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev);
+    } else
     hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                        (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
                        ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0, st,
@@ -2693,7 +2700,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     if (ran == ASB_PANEL_COLS && ctx->run_coop_used && ctx->spec_panels && k + ASB_PANEL_COLS < k1) {
         // the first sub-panel's state (winner energies, provable head) is needed again after the pass
         ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
-        const int stepsB = (int)((k1 - kb[1]) < ASB_PANEL_COLS ? (k1 - kb[1]) : ASB_PANEL_COLS);
+        // the second sub-panel runs entirely unproven on rows chosen for the first: it is given as many steps as the last
+        // ones kept (+2), a rejected step costs a panel step and everything behind it
+        int stepsB = (int)((k1 - kb[1]) < ASB_PANEL_COLS ? (k1 - kb[1]) : ASB_PANEL_COLS);
+        if (stepsB > ctx->dbl_budget) stepsB = ctx->dbl_budget;
         int64_t ranB = 0;
         ctx->run_spec_max = ASB_PANEL_COLS;
         rc = asb_panel_run(ctx, kb[1], stepsB, 0, 0, &ranB);      // same candidates, rows as the first sub-panel left them
@@ -2736,6 +2746,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if (getenv("ASB_DEBUG_PANELS"))
             fprintf(stderr, "[asb] double panel at k=%lld tile %d: %d proven + %lld of %d unproven steps kept\n", k, ct, proven[ct],
                     (long long)(kept > proven[ct] ? kept - proven[ct] : 0), nc[ct] - proven[ct]);
+        if (ct == 1) {                                // adapt the second sub-panel's length to what stands
+            const int want = (int)kept + 2;
+            ctx->dbl_budget = want < 4 ? 4 : (want > ASB_PANEL_COLS ? ASB_PANEL_COLS : want);
+        }
         if (kept < nc[ct]) break;                    // what follows was built on a rejected step
     }
     if (total > 0) ctx->k_done = k + total;

@@ -245,10 +245,24 @@ __global__ __launch_bounds__(256) void k_jacobi_round(double* __restrict__ A, in
     if (j >= nv) return;                          // the padding player of an odd count
     double* ai = A + (long long)i * lda;
     double* aj = A + (long long)j * lda;
+    // rows of up to 4096 entries stay in registers between the three dot products and the rotation (one read, one write)
+    constexpr int EPT = 16;
+    const bool cached = m <= 256 * EPT;
+    double xr[EPT], yr[EPT];
     double v[3] = {0.0, 0.0, 0.0};
-    for (int c = threadIdx.x; c < m; c += 256) {
-        const double x = ai[c], y = aj[c];
-        v[0] += x * x; v[1] += y * y; v[2] += x * y;
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            xr[q] = c < m ? ai[c] : 0.0;
+            yr[q] = c < m ? aj[c] : 0.0;
+            v[0] += xr[q] * xr[q]; v[1] += yr[q] * yr[q]; v[2] += xr[q] * yr[q];
+        }
+    } else {
+        for (int c = threadIdx.x; c < m; c += 256) {
+            const double x = ai[c], y = aj[c];
+            v[0] += x * x; v[1] += y * y; v[2] += x * y;
+        }
     }
     block_sum<3>(v, sh);
     const double al = v[0], be = v[1], ga = v[2];
@@ -259,10 +273,21 @@ __global__ __launch_bounds__(256) void k_jacobi_round(double* __restrict__ A, in
     const double zeta = (be - al) / (2.0 * ga);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-    for (int c = threadIdx.x; c < m; c += 256) {
-        const double x = ai[c], y = aj[c];
-        ai[c] = cs * x - sn * y;
-        aj[c] = sn * x + cs * y;
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c < m) {
+                ai[c] = cs * xr[q] - sn * yr[q];
+                aj[c] = sn * xr[q] + cs * yr[q];
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < m; c += 256) {
+            const double x = ai[c], y = aj[c];
+            ai[c] = cs * x - sn * y;
+            aj[c] = sn * x + cs * y;
+        }
     }
     if (Q) {
         double* qi = Q + (long long)i * nq;
