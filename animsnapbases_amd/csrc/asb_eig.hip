@@ -95,7 +95,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
 // and writes its partial row sums to p[chunk * n + i] (k_td_small adds the chunks in order: deterministic) -- a 2-D
 // decomposition, so that even the 128 MB start matrix gives every SIMD several waves and the sweep runs at the rate of the
 // Infinity Cache instead of one wave's latency chain per four rows.
-#define TD_CW 512
+#define TD_CW 1024
 template <int R>
 __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n, int r1, int update,
                                                   const double* __restrict__ vcur, const double* __restrict__ w,

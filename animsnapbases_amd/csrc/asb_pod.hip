@@ -288,15 +288,20 @@ __global__ __launch_bounds__(256) void k_deim_residual(const double* __restrict_
 // repeats the loop with the reference's lstsq on the host.
 // Both the matrices of points (Mx, and MxT[i][j][m] = Mx[i][m][j]) and the inverse (Minv and its transpose MinvT) are kept in
 // two layouts so that every product below reads consecutive words across a wave.
-__global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ Mx, const double* __restrict__ MxT,
+// 1024 threads: thread (r = tid % 256, part = tid / 256) takes every fourth term of row r's dot products (four times shorter
+// latency chains), the parts meet in LDS.
+#define DS_T 1024
+__global__ __launch_bounds__(DS_T) void k_deim_solve(const double* __restrict__ Mx, const double* __restrict__ MxT,
                                                     double* __restrict__ Minv, double* __restrict__ MinvT, int K, int k,
                                                     double* __restrict__ coef, int* __restrict__ flags) {
-    extern __shared__ double sh[];               // u (K), w (K), x (K), red (16)
+    extern __shared__ double sh[];               // u (K), w (K), x (K), pu (4 K), pw (4 K), red (64)
     double* u = sh;
     double* w = u + K;
     double* x = w + K;
-    double* red = x + K;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    double* pu = x + K;
+    double* pw = pu + 4 * K;
+    double* red = pw + 4 * K;
+    const int i = blockIdx.x, tid = threadIdx.x, lane_r = tid & 255, part = tid >> 8;
     const double* M = Mx + (size_t)i * K * K;
     const double* MT = MxT + (size_t)i * K * K;
     double* A = Minv + (size_t)i * K * K;
@@ -313,31 +318,37 @@ __global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ M
         // u = A bcol, w = crow A   (bcol[q] = M[q][n] = MT[n][q], crow[q] = M[n][q])
         const double* bcol = MT + (size_t)n * K;
         const double* crow = M + (size_t)n * K;
-        for (int r = tid; r < n; r += 256) {
+        for (int r0 = 0; r0 < n; r0 += 256) {
+            const int r = r0 + lane_r;
             double su = 0.0, sw = 0.0;
-            for (int q = 0; q < n; ++q) {
-                su += AT[(size_t)q * K + r] * bcol[q];        // A[r][q]
-                sw += crow[q] * A[(size_t)q * K + r];
-            }
-            u[r] = su;
-            w[r] = sw;
+            if (r < n)
+                for (int q = part; q < n; q += 4) {
+                    su += AT[(size_t)q * K + r] * bcol[q];        // A[r][q]
+                    sw += crow[q] * A[(size_t)q * K + r];
+                }
+            if (r < n) { pu[part * K + r] = su; pw[part * K + r] = sw; }
         }
         __syncthreads();
-        double part[1] = {0.0};
-        for (int q = tid; q < n; q += 256) part[0] += crow[q] * u[q];
-        block_sum<1>(part, red);
-        const double sch = crow[n] - part[0];
+        for (int r = tid; r < n; r += DS_T) {
+            u[r] = (pu[r] + pu[K + r]) + (pu[2 * K + r] + pu[3 * K + r]);
+            w[r] = (pw[r] + pw[K + r]) + (pw[2 * K + r] + pw[3 * K + r]);
+        }
+        __syncthreads();
+        double part1[1] = {0.0};
+        for (int q = tid; q < n; q += DS_T) part1[0] += crow[q] * u[q];
+        block_sum<1>(part1, red);
+        const double sch = crow[n] - part1[0];
         if (sch == 0.0 || !(sch == sch) || fabs(sch) > 1.7e308) {
             if (tid == 0) flags[0] = 1;
             return;
         }
         const double is = 1.0 / sch;
-        for (int e = tid; e < n * n; e += 256) {
+        for (int e = tid; e < n * n; e += DS_T) {
             const int r = e / n, c = e % n;
             A[(size_t)r * K + c] += u[r] * w[c] * is;
             AT[(size_t)r * K + c] += u[c] * w[r] * is;        // AT[r][c] = A[c][r]
         }
-        for (int r = tid; r < n; r += 256) {
+        for (int r = tid; r < n; r += DS_T) {
             A[(size_t)r * K + n] = -u[r] * is;
             A[(size_t)n * K + r] = -w[r] * is;
             AT[(size_t)n * K + r] = -u[r] * is;
@@ -349,24 +360,39 @@ __global__ __launch_bounds__(256) void k_deim_solve(const double* __restrict__ M
     __syncthreads();
     // x = A[:k, :k] b,  b[m] = M[m][k] = MT[k][m]
     const double* b = MT + (size_t)k * K;
-    double nb2 = 0.0, nx2 = 0.0, nm2 = 0.0;
-    for (int r = tid; r < k; r += 256) {
+    double nm2 = 0.0;
+    for (int r0 = 0; r0 < k; r0 += 256) {
+        const int r = r0 + lane_r;
         double sx = 0.0;
-        for (int q = 0; q < k; ++q) {
-            sx += AT[(size_t)q * K + r] * b[q];
-            const double m = MT[(size_t)q * K + r];
-            nm2 += m * m;
-        }
+        if (r < k)
+            for (int q = part; q < k; q += 4) {
+                sx += AT[(size_t)q * K + r] * b[q];
+                const double m = MT[(size_t)q * K + r];
+                nm2 += m * m;
+            }
+        if (r < k) pu[part * K + r] = sx;
+    }
+    __syncthreads();
+    double nb2 = 0.0, nx2 = 0.0;
+    for (int r = tid; r < k; r += DS_T) {
+        const double sx = (pu[r] + pu[K + r]) + (pu[2 * K + r] + pu[3 * K + r]);
         x[r] = sx;
         coef[(size_t)i * k + r] = sx;
         nx2 += sx * sx;
         nb2 += b[r] * b[r];
     }
     __syncthreads();
+    for (int r0 = 0; r0 < k; r0 += 256) {
+        const int r = r0 + lane_r;
+        double sr = 0.0;
+        if (r < k)
+            for (int q = part; q < k; q += 4) sr += MT[(size_t)q * K + r] * x[q];     // M[r][q]
+        if (r < k) pw[part * K + r] = sr;
+    }
+    __syncthreads();
     double res2 = 0.0;
-    for (int r = tid; r < k; r += 256) {
-        double sr = -b[r];
-        for (int q = 0; q < k; ++q) sr += MT[(size_t)q * K + r] * x[q];     // M[r][q]
+    for (int r = tid; r < k; r += DS_T) {
+        const double sr = (pw[r] + pw[K + r]) + (pw[2 * K + r] + pw[3 * K + r]) - b[r];
         res2 += sr * sr;
     }
     double v[4] = {nb2, nx2, nm2, res2};
@@ -438,10 +464,12 @@ extern "C" int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, i
     ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
     long long want = (ctx->n_loc + 255) / 256;
     const int grid = (int)(want < 1024 ? want : 1024);
-    const size_t lds_solve = ((size_t)3 * K + 16) * sizeof(double);
+    const size_t lds_solve = ((size_t)11 * K + 64) * sizeof(double);
+    if (lds_solve > 48 * 1024)
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_deim_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
     for (int k = 0; k < K; ++k) {
         if (k > 0) {
-            hipLaunchKernelGGL(k_deim_solve, dim3(3), dim3(256), lds_solve, ctx->stream, Mx, MxT, Minv, MinvT, K, k, coef, ctx->la_status);
+            hipLaunchKernelGGL(k_deim_solve, dim3(3), dim3(DS_T), lds_solve, ctx->stream, Mx, MxT, Minv, MinvT, K, k, coef, ctx->la_status);
         }
         hipLaunchKernelGGL(k_deim_residual, dim3(grid), dim3(256), (size_t)(3 * k + 1) * sizeof(double), ctx->stream, ctx->comps,
                            (long long)ctx->n_loc, k, coef, (long long)ctx->v0, pmax, pidx, pabs);
