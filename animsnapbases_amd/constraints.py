@@ -254,15 +254,19 @@ class constraintsComponents:  # Components == bases
         """constraintsComponents.py:108-153."""
         p = self.param
         kind = p.constProj_basis_type
-        if kind not in ("pod_vectorized", "pca_blocks"):
-            if kind in ("pod", "pca_blocks_with_St"):
-                raise NotImplementedError("constProj_basis_type %r is out of scope of this build (SURVEY.md section 2 #3); "
+        if kind not in ("pod_vectorized", "pca_blocks", "pod"):
+            if kind == "pca_blocks_with_St":
+                raise NotImplementedError("constProj_basis_type %r needs the libigl-built differential operator S^T and the "
+                                          "reference's element adjacency (out of scope, SURVEY.md section 2 #3); 'pod', "
                                           "'pod_vectorized' and 'pca_blocks' run on the GPU" % kind)
             raise ValueError("Uknown basis type: ", kind)
         if kind == "pca_blocks":
             headerSing = ['component', 'idx', 'residual_matrix_norm'] + \
                          ['singVal' + str(i) for i in range(self.nonlinearSnapshots.constraintsSize)]
             run = self.compute_nonlinearity_bases_blocks
+        elif kind == "pod":
+            headerSing = ['component', 'singVal']
+            run = self.compute_pod_for_nonlinear_snapshots_tensor
         else:
             headerSing = ['component', 'singVal']
             run = self.compute_pod_for_vectorized_nonlinear_snapshots_tensor
@@ -337,6 +341,23 @@ class constraintsComponents:  # Components == bases
         self._comps, self._comps_on_device = None, True
         self.numComp = K
         print("bases shape", (Kp, ns.frames_rows, 3), "number of components", self.numComp)
+
+    @log_time(constProj_output_directory)
+    def compute_pod_for_nonlinear_snapshots_tensor(self, writer=None):
+        """constraintsComponents.py:274-294 ('pod'): a batched SVD over the (p, d) slices of the snapshots, each an e x F
+        matrix; component k carries the k-th left singular vector of every slice.  The reference runs torch's float32 SVD
+        on the CPU; here every slice goes through Gram matrix -> device eigen-solver -> U = M V S^-1 in float64 (nothing is
+        written to the CSV by the reference either)."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        if comm.multi:
+            raise NotImplementedError("constProj_basis_type 'pod' runs on one rank")
+        p = int(ns.constraintsSize)
+        e = ns.frames_rows // p
+        K = min(int(self.param.deim_desired_num_components), min(e, ns.frs))
+        eng.pod_slices(p, K)
+        self._comps, self._comps_on_device = None, True
+        self.numComp = K
 
     @log_time(constProj_output_directory)
     def compute_pod_for_vectorized_nonlinear_snapshots_tensor(self, writer=None):

@@ -12,6 +12,7 @@
 
 int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows,
                         const double* col_scale);
+extern "C" int asb_sym_eig_topk(asb_ctx* ctx, double* A_dev, int64_t n64, int64_t k64, double* lam_host, double* V_host, int64_t* n_bad);
 
 // G = X^T X over this shard's rows (F x F) into G_dev (caller's device buffer, to be all-reduced) or
 // G_host (single rank convenience; synchronises)
@@ -207,6 +208,56 @@ extern "C" int asb_pod_basis_dev(asb_ctx* ctx, int64_t K) {
     for (int64_t k0 = 0; k0 < K; k0 += 16) {
         const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
         if ((rc = asb_project_columns(ctx, ctx->eig_v, ctx->eig_k, k0, nc, ctx->comps + (size_t)k0 * n3, ctx->pod_s))) return rc;
+    }
+    return ASB_OK;
+}
+
+// V[f][k] /= sqrt(lam[k]) (columns scaled); status[1] = 1 when lam[k] is not resolved (<= tol_rel^2 lam[0])
+__global__ __launch_bounds__(256) void k_scale_cols_inv_sqrt(double* __restrict__ V, int F, int k, const double* __restrict__ lam,
+                                                             double tol_rel, int* __restrict__ status) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)F * k; e += (long long)gridDim.x * 256) {
+        const int j = (int)(e % k);
+        const double l = lam[j];
+        if (!(l > tol_rel * tol_rel * lam[0])) { if (e < k) status[1] = 1; V[e] = 0.0; }
+        else V[e] /= sqrt(l);
+    }
+}
+
+// constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, constraintsComponents.py:274-294): one SVD per
+// (constraint row p_i, coordinate d) of the e x F matrix M[e_i][f] = snapshots[f][e_i p + p_i][d]; component k holds, in
+// those rows, the k-th left singular vector.  Here per slice: Gram matrix (F x F) of the slice's rows -> eigen-problem on
+// the device -> U = M V S^-1 written straight into the strided rows of the basis.  (The reference computes these SVDs in
+// float32 on the CPU with torch; this is the float64 result.)  One rank holds all rows.
+extern "C" int asb_pod_slices(asb_ctx* ctx, int p, int64_t K) {
+    if (!ctx || !ctx->X || p < 1 || K < 1) return ASB_ERR_ARG;
+    if (ctx->n_loc != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_slices needs all rows on one rank");
+    if (ctx->n_loc % p) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_slices: %lld rows are not whole constraints of %d", (long long)ctx->n_loc, p);
+    const int64_t F = ctx->F, n3 = 3 * ctx->n_loc, e = ctx->n_loc / p;
+    if (K > F || K > e) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_slices: K = %lld exceeds min(e, F) = %lld", (long long)K, (long long)(e < F ? e : F));
+    if (F < 3) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_pod_slices needs F >= 3");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_g, (size_t)F * F))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->s_dev, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
+    ctx->K = K;
+    std::vector<double> lam((size_t)F);
+    const long long stride = 3LL * p * ctx->Fp;                 // between the rows of consecutive constraints of one slice
+    for (int s = 0; s < 3 * p; ++s) {                           // slice s: rows r = 3 (e_i p + p_i) + d with 3 p_i + d = s
+        const double* Xs = ctx->X + (long long)s * ctx->Fp;
+        if ((rc = asb_gemm_tn_s(ctx, Xs, stride, 1, Xs, stride, e, (int)F, (int)F, ctx->pod_g, F, 1))) return rc;
+        int64_t bad = 0;
+        if ((rc = asb_sym_eig_topk(ctx, ctx->pod_g, F, K, lam.data(), nullptr, &bad))) return rc;
+        ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_scale_cols_inv_sqrt, dim3(64), dim3(256), 0, ctx->stream, ctx->eig_v, (int)F, (int)K, ctx->eig_lam, 1e-7,
+                           ctx->la_status);
+        ASB_CHECK_LAUNCH(ctx);
+        // U[e_i][k] = sum_f M[e_i][f] V[f][k]  ->  comps[k][r(e_i)]
+        if ((rc = asb_gemm_tn_s(ctx, Xs, 1, stride, ctx->eig_v, K, F, (int)e, (int)K, ctx->comps + s, 3LL * p, n3))) return rc;
+        int st[4];
+        ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (st[1]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "pod: slice %d has fewer than %lld singular values above 1e-7 of its largest", s, (long long)K);
     }
     return ASB_OK;
 }

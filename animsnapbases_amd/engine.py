@@ -450,6 +450,10 @@ class HipEngine(object):
         self._ck(self.lib.asb_pod_basis_dev(self.h, int(K)))
         self.K = int(K)
 
+    def pod_slices(self, p, K):
+        self._ck(self.lib.asb_pod_slices(self.h, int(p), int(K)))
+        self.K = int(K)
+
     def pod_rotate(self, B_dev_ptr=None):
         S = np.empty(self.K)
         self._ck(self.lib.asb_pod_rotate(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, ptr(S)))

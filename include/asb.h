@@ -324,6 +324,10 @@ int asb_pod_basis_dev(asb_ctx* ctx, int64_t K);
  * K x F matrix B = Q^T A (B_dev, or the context's from asb_pod_project; overwritten) by one-sided Jacobi on its rows;
  * basis <- Q U_B.  Replaces the small host SVD between asb_pod_project and asb_components_transform. */
 int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host);
+/* constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, :274-294): one SVD per (constraint row, coordinate)
+ * slice of the snapshots -- e x F matrices -- by Gram matrix + device eigen-solver; the K leading left vectors of every
+ * slice become the device-resident basis (K, e p, 3).  The reference does this in float32 with torch on the CPU. */
+int asb_pod_slices(asb_ctx* ctx, int p, int64_t K);
 /* asb_qr_apply with ONE Cholesky factor of the sum of the three Gram matrices for all three slices: the basis becomes
  * orthonormal as (3 n)-vectors (the Q of the Rayleigh-Ritz step).  Any K. */
 int asb_qr_apply_joint(asb_ctx* ctx, const double* G_dev);

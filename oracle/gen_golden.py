@@ -293,6 +293,32 @@ def _blocksdeim(work):
     print("wrote block_deim_p3", out["deim_block_form_alpha"].tolist(), out["geom_alpha"].tolist(), list(out["files"]))
 
 
+def _podslices(work):
+    """constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, :274-294; torch float32 SVD per (p, d) slice)."""
+    ref = import_reference.cache
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    rng = np.random.default_rng(31)
+    e, p, F, K = 36, 2, 14, 5
+    modes = rng.normal(size=(9, e * p, 3))
+    coef = rng.normal(size=(F, 9)) * (0.6 ** np.arange(9))[None]
+    frames = 0.3 + np.tensordot(coef, modes, (1, 0)) + 1e-4 * rng.normal(size=(F, e * p, 3))
+    param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=False,
+                                  deim_desired_num_components=K, constProj_output_directory=work)
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param, ns.rest_shape, ns.dim, ns.frs, ns.constraintsSize = param, "first", 3, F, p
+    ns.num_constained_elements = e
+    ns.snapTensor = frames.astype(float).copy()
+    ns.mean, ns.pre_scale_factor, ns.massL, ns.invMassL = None, 1, None, None
+    ns.standarize()
+    cc = object.__new__(constraintsComponents)
+    cc.param, cc.nonlinearSnapshots, cc.numComp, cc.comps = param, ns, 0, None
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_pod_for_nonlinear_snapshots_tensor(None)
+    np.savez_compressed(os.path.join(OUT, "pod_slices_p2.npz"), frames=frames, K=np.array(K), p=np.array(p),
+                        comps=np.asarray(cc.comps, dtype=np.float64), numComp=np.array(cc.numComp))
+    print("wrote pod_slices_p2", cc.comps.shape, cc.comps.dtype)
+
+
 def _recon(work):
     """geom_constructed (:489-521) after deim on the POD basis of tests/golden/pod_deim_small.npz (p = 1), train and test frames."""
     g = np.load(os.path.join(OUT, "pod_deim_small.npz"))
@@ -447,6 +473,8 @@ def main():
                 return _blocksdeim(work)
             if only is not None and "recon" in only:
                 return _recon(work)
+            if only is not None and "podslices" in only:
+                return _podslices(work)
             if only is not None and "blocks" in only:
                 return _blocks(work)
             if only is not None and "ingest" not in only:
@@ -467,6 +495,7 @@ def main():
             _blocks(work)
             _blocksdeim(work)
             _recon(work)
+            _podslices(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

@@ -101,3 +101,25 @@ def test_device_deim_equals_the_lstsq_loop_and_the_oracle(ep, F, K, tmp_path, mo
     assert dev.tolist() == cc.geom_Pt.tolist()
     assert len(set(dev.tolist())) == K
     assert dev.tolist() == orc.deim(cc.comps, 1)["Pt"].tolist()
+
+
+def test_pod_per_slice_vs_reference_golden(tmp_path):
+    """constProj_basis_type 'pod' (:274-294): the reference's torch float32 SVD of every (p, d) slice; each vector of each
+    slice carries its own arbitrary sign.  Tolerance = float32 accuracy of the reference (the device result is float64;
+    it is also checked against numpy's float64 SVD of the same slices)."""
+    g = load_golden("pod_slices_p2")
+    K, p = int(g["K"]), int(g["p"])
+    ns, cc = _build(g["frames"], K, tmp_path, "deim", "pod", p)
+    assert cc.numComp == int(g["numComp"]) and cc.comps.shape == g["comps"].shape
+    X = ns.snapTensor                                              # (F, e p, 3) standardised
+    e = X.shape[1] // p
+    for pi in range(p):
+        for d in range(3):
+            got = cc.comps[:, pi::p, d]                            # (K, e)
+            ref32 = g["comps"][:, pi::p, d]
+            U = np.linalg.svd(X[:, pi::p, d].T, full_matrices=False)[0][:, :K].T      # float64 reference of the slice
+            for k in range(K):
+                s32 = np.sign(np.dot(got[k], ref32[k]))
+                s64 = np.sign(np.dot(got[k], U[k]))
+                assert relerr(got[k] * s32, ref32[k]) < 2e-4, (pi, d, k)
+                assert relerr(got[k] * s64, U[k]) < 1e-8, (pi, d, k)
