@@ -31,6 +31,11 @@ struct asb_geo {
     int np = 0;
     double *Hinv = nullptr, *Pinv = nullptr;
     double* sv_part = nullptr;      // k_symv_tiles partial sums
+    // two-level preconditioner (asb_geodesic_coarse_setup): piecewise-constant aggregates, coarse inverses, coarse vectors
+    bool coarse = false;
+    int nc = 0, ncp = 0;
+    int *agg = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr;
+    double *AcH = nullptr, *AcP = nullptr, *rc = nullptr, *zc = nullptr;
     // distance fields kept for SPLOCS (asb_geodesic_cache_add): slot q lives in slab[q / 64] at row q % 64
     double* slab[ASB_GEO_CACHE_SLABS] = {};
     long long cached = 0;
@@ -112,6 +117,38 @@ __global__ __launch_bounds__(256) void k_cg_direction(int rows, int nblk_in, con
 }
 
 __global__ void k_cg_commit(double* __restrict__ rz) { rz[threadIdx.x] = rz[GB + threadIdx.x]; }
+
+// ---- two-level additive preconditioner  z = D^-1 r + P Ac^-1 P^T r  (P: piecewise-constant prolongation from aggregates of
+// ~50 mesh vertices, Ac = P^T A P inverted densely once).  Jacobi alone needs O(1/h) iterations on the Poisson system
+// (thousands on a 14 000-vertex scan); the coarse term carries the smooth error components, and the count becomes a
+// property of the aggregate size, not of the mesh size.
+// rc[a] = sum of r over the members of aggregate a (one wave per aggregate, members in index order: deterministic)
+__global__ __launch_bounds__(256) void k_restrict64(const int* __restrict__ agg_ptr, const int* __restrict__ agg_mem, int nc,
+                                                    const double* __restrict__ r, double* __restrict__ rc) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int a = blockIdx.x * 4 + wid; a < nc; a += gridDim.x * 4) {
+        double s = 0.0;
+        for (int j = agg_ptr[a]; j < agg_ptr[a + 1]; ++j) s += r[(long long)agg_mem[j] * GB + lane];
+        rc[(long long)a * GB + lane] = s;
+    }
+}
+// z += zc[agg]; partial r.z with the complete z (replaces the Jacobi-only partials of k_cg_update / k_cg_start)
+__global__ __launch_bounds__(256) void k_prolong_rz(int rows, const int* __restrict__ agg, const double* __restrict__ zc,
+                                                    const double* __restrict__ r, double* __restrict__ z,
+                                                    double* __restrict__ part_rz) {
+    __shared__ double sh[4][GB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
+        const long long e = (long long)i * GB + lane;
+        const double zn = z[e] + zc[(long long)agg[i] * GB + lane];
+        z[e] = zn;
+        s += r[e] * zn;
+    }
+    sh[wid][lane] = s;
+    __syncthreads();
+    if (wid == 0) part_rz[(long long)blockIdx.x * GB + lane] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
 
 // z = r / diag, partial r.z / r.r  (start of CG with x = 0, r = b)
 __global__ __launch_bounds__(256) void k_cg_start(int rows, const double* __restrict__ diag, const double* __restrict__ r,
@@ -197,6 +234,7 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
     asb_geo* G = ctx->geo;
     G->n = n; G->m3 = m3;
     G->dense = false;                  // a new mesh: explicit inverses and cached fields of the old one are void
+    G->coarse = false;
     G->cached = 0;
     int rc;
     if ((rc = upload_csr(ctx, G->heat, n, n, heat_rp, heat_ci, heat_v))) return rc;
@@ -219,9 +257,58 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
     return ASB_OK;
 }
 
+// Coarse level of the two-level preconditioner (after asb_geodesic_setup): agg (n) = aggregate of every vertex, its CSR
+// form (agg_ptr nc + 1, agg_mem n), and the two coarse operators P^T (A - tL) P and P^T (-L) P + gauge (host, nc x nc, SPD),
+// which are inverted here on the device (blocked Gauss-Jordan, asb_dense.hip).
+extern "C" int asb_geodesic_coarse_setup(asb_ctx* ctx, int nc, const int* agg, const int* agg_ptr, const int* agg_mem,
+                                         const double* heat_c, const double* lap_c) {
+    if (!ctx || !ctx->geo || nc < 1 || !agg || !agg_ptr || !agg_mem || !heat_c || !lap_c) return ASB_ERR_ARG;
+    asb_geo* G = ctx->geo;
+    const int n = G->n, ncp = (nc + 15) / 16 * 16;
+    if (nc > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "geodesics: %d aggregates are too many for a dense coarse level", nc);
+    int rc;
+    if ((rc = asb_alloc(ctx, &G->agg, (size_t)n))) return rc;
+    if ((rc = asb_alloc(ctx, &G->agg_ptr, (size_t)nc + 1))) return rc;
+    if ((rc = asb_alloc(ctx, &G->agg_mem, (size_t)n))) return rc;
+    if ((rc = asb_alloc(ctx, &G->AcH, (size_t)ncp * ncp))) return rc;
+    if ((rc = asb_alloc(ctx, &G->AcP, (size_t)ncp * ncp))) return rc;
+    if ((rc = asb_alloc(ctx, &G->rc, (size_t)ncp * GB))) return rc;
+    if ((rc = asb_alloc(ctx, &G->zc, (size_t)ncp * GB))) return rc;
+    if ((rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(G->agg, agg, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(G->agg_ptr, agg_ptr, ((size_t)nc + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(G->agg_mem, agg_mem, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(G->rc, 0, (size_t)ncp * GB * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(G->zc, 0, (size_t)ncp * GB * sizeof(double), ctx->stream));
+    std::vector<double> pad((size_t)ncp * ncp);
+    const double* src[2] = {heat_c, lap_c};
+    double* dst[2] = {G->AcH, G->AcP};
+    for (int q = 0; q < 2; ++q) {
+        for (int i = 0; i < ncp; ++i)
+            for (int j = 0; j < ncp; ++j)
+                pad[(size_t)i * ncp + j] = (i < nc && j < nc) ? src[q][(size_t)i * nc + j] : (i == j ? 1.0 : 0.0);
+        ASB_HIP(ctx, hipMemcpyAsync(dst[q], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = asb_dense_spd_inverse(ctx, dst[q], ncp))) return rc;
+    }
+    G->nc = nc;
+    G->ncp = ncp;
+    G->coarse = true;
+    return ASB_OK;
+}
+
 // x <- A^-1 b by Jacobi-PCG on all 64 columns (b is consumed: it becomes the residual buffer)
+static int coarse_correct(asb_ctx* ctx, asb_geo* G, const double* Acinv, const double* r, double* part_rz) {
+    const int gb = (G->nc + 3) / 4 < 1024 ? (G->nc + 3) / 4 : 1024;
+    hipLaunchKernelGGL(k_restrict64, dim3(gb), dim3(256), 0, ctx->stream, G->agg_ptr, G->agg_mem, G->nc, r, G->rc);
+    int rc = asb_gemm_nn(ctx, Acinv, G->ncp, G->rc, GB, G->zc, GB, G->ncp, GB, G->ncp, 1.0, 0.0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_prolong_rz, dim3(G->nblk), dim3(256), 0, ctx->stream, G->n, G->agg, G->zc, r, G->z, part_rz);
+    return ASB_OK;
+}
+
 static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, double* b, double* x, int nsrc, double tol,
-                int max_iter, int* iters_out) {
+                int max_iter, int* iters_out, const double* Acinv = nullptr) {
     const int n = G->n, nb = G->nblk;
     double *part_pap = G->part, *part_rz = G->part + (size_t)nb * GB, *part_rr = G->part + (size_t)2 * nb * GB;
     double *rz = G->sc, *rr = G->sc + 2 * GB;       // rz[0..63] current, [64..127] staged, [192..255] initial; rr = sc[128..191]
@@ -229,7 +316,9 @@ static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, 
     ASB_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * GB * sizeof(double), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(G->sc, 0, (size_t)4 * GB * sizeof(double), ctx->stream));
     double* r = b;
+    int rcc;
     hipLaunchKernelGGL(k_cg_start, dim3(nb), dim3(256), 0, ctx->stream, n, diag, r, G->z, part_rz, part_rr);
+    if (Acinv && (rcc = coarse_correct(ctx, G, Acinv, r, part_rz))) return rcc;
     hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 1, tol2);
     hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
     double rr0[GB], rrk[GB];
@@ -244,6 +333,7 @@ static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, 
             hipLaunchKernelGGL(k_spmm64, dim3(nb), dim3(256), 0, ctx->stream, A.rowptr, A.colidx, A.vals, n, G->p, G->ap, part_pap);
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_pap, rz, diag, x, r, G->p, G->ap, G->z,
                                part_rz, part_rr, tol2);
+            if (Acinv && (rcc = coarse_correct(ctx, G, Acinv, r, part_rz))) return rcc;
             hipLaunchKernelGGL(k_cg_direction, dim3(nb), dim3(256), 0, ctx->stream, n, nb, part_rz, part_rr, rz, rr, G->z, G->p, 0, tol2);
             hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(GB), 0, ctx->stream, rz);
         }
@@ -362,7 +452,7 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     } else {
         ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
-        if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1))) return rc;
+        if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1, G->coarse ? G->AcH : nullptr))) return rc;
     }
     // gradient, normalise, divergence
     const int gb = (G->m3 + 3) / 4 < 1024 ? (G->m3 + 3) / 4 : 1024;
@@ -375,7 +465,7 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
     if (G->dense) {        // y = (-L + gamma/n 1 1^T)^-1 div : one (np x np) by (np x 64) product
         if ((rc = asb_gemm_nn(ctx, G->Pinv, G->np, G->b, GB, G->x, GB, G->np, GB, G->np, 1.0, 0.0))) return rc;
-    } else if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2))) return rc;
+    } else if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2, G->coarse ? G->AcP : nullptr))) return rc;
     // phi = -y; phi -= min(phi)  ==  max(y) - y : done by negating in place first
     hipLaunchKernelGGL(k_scale_vec, dim3(G->nblk), dim3(256), 0, ctx->stream, G->x, (long long)n * GB, -1.0);
     if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;

@@ -346,9 +346,10 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ post-processing
     # ------------------------------------------------------------------ device geodesics
-    def geodesic_setup(self, heat, lap, grad, div, dense=False):
+    def geodesic_setup(self, heat, lap, grad, div, dense=False, coarse=None):
         """heat, lap, grad, div: scipy CSR matrices (float64).  dense: invert the two SPD systems explicitly on the
-        device (asb_geodesic_dense_setup) instead of solving them by PCG per batch."""
+        device (asb_geodesic_dense_setup) instead of solving them by PCG per batch.  coarse = (agg, heat_c, lap_c): the
+        aggregates and dense coarse operators of the PCG mode's two-level preconditioner."""
         keep = []
 
         def csr(m):
@@ -368,6 +369,18 @@ class HipEngine(object):
         self.geodesic_dense = bool(dense)
         if dense:
             self._ck(self.lib.asb_geodesic_dense_setup(self.h))
+        elif coarse is not None:
+            agg, heat_c, lap_c = coarse
+            agg = np.ascontiguousarray(agg, dtype=np.int32)
+            nc = int(agg.max()) + 1
+            order = np.argsort(agg, kind="stable").astype(np.int32)
+            ptr_ = np.zeros(nc + 1, dtype=np.int32)
+            np.cumsum(np.bincount(agg, minlength=nc), out=ptr_[1:])
+            heat_c = np.ascontiguousarray(heat_c, dtype=np.float64)
+            lap_c = np.ascontiguousarray(lap_c, dtype=np.float64)
+            assert heat_c.shape == lap_c.shape == (nc, nc) and agg.shape == (n,)
+            self._ck(self.lib.asb_geodesic_coarse_setup(self.h, nc, agg.ctypes.data, ptr_.ctypes.data, order.ctypes.data,
+                                                        heat_c.ctypes.data, lap_c.ctypes.data))
 
     def apply_geodesic(self, k, dmin, dmax):
         self._ck(self.lib.asb_deflate_apply_geodesic(self.h, int(k), float(dmin), float(dmax)))

@@ -160,20 +160,18 @@ class posSnapshots:
         # geodesics on the NON-weighted shape (:96-99); host SciPy
         if self.tris is not None and self.verts is not None:
             shape0 = self.verts[0] if self.rest_shape == "first" else np.mean(self.verts, axis=0)
-            # "dense" (default): both SPD systems inverted once on the device, a query = gather + one dense product; the
-            # N x N inverses cost 2 N^3 flop each and 8 N^2 bytes, so meshes above DENSE_GEODESIC_MAX_VERTS are refused
-            # rather than silently moved to the CPU.  Opt-in alternatives: ASB_GEODESIC=host (SciPy SuperLU, what the
-            # reference does) and ASB_GEODESIC=device (sparse batched Jacobi-PCG, experimental).
+            # "dense" (default up to DENSE_GEODESIC_MAX_VERTS): both SPD systems inverted once on the device, a query =
+            # gather + one dense product; the N x N inverses cost 2 N^3 flop each and 8 N^2 bytes, so larger meshes take
+            # "device": sparse batched PCG with a two-level (Jacobi + aggregate coarse space) preconditioner.  Opt-in:
+            # ASB_GEODESIC=host (SciPy SuperLU, what the reference does).
             mode = os.environ.get("ASB_GEODESIC", getattr(self, "geodesic_backend", "auto"))
             if mode == "auto":
                 if not hasattr(eng, "geodesic_setup"):          # CPU test double of the engine (tests only)
                     mode = "host"
                 elif self.nVerts <= DENSE_GEODESIC_MAX_VERTS:
                     mode = "dense"
-                else:
-                    raise ValueError("heat-method geodesics on the device invert two %d x %d matrices; above %d vertices "
-                                     "choose ASB_GEODESIC=host (SciPy SuperLU on the CPU) or ASB_GEODESIC=device (sparse "
-                                     "PCG, experimental) explicitly" % (self.nVerts, self.nVerts, DENSE_GEODESIC_MAX_VERTS))
+                else:                                           # two N x N inverses no longer fit / pay: sparse two-level PCG
+                    mode = "device"
             self.compute_geodesic_distance = GeodesicDistanceComputation(
                 shape0, self.tris, engine=eng if mode in ("dense", "device") else None,
                 backend="dense" if mode == "dense" else "pcg")

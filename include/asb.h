@@ -263,6 +263,12 @@ int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_rp, const in
                        const int* lap_rp, const int* lap_ci, const double* lap_v, const int* grad_rp,
                        const int* grad_ci, const double* grad_v, const int* div_rp, const int* div_ci,
                        const double* div_v, const double* heat_diag, const double* lap_diag);
+/* Two-level preconditioner for the sparse (PCG) mode -- what lets it scale past the dense mode's 46 000 vertices: agg (n) =
+ * aggregate (0 .. nc-1) of every vertex, agg_ptr / agg_mem its CSR form, heat_c / lap_c (host, nc x nc, SPD) the coarse
+ * operators P^T (A - tL) P and P^T (-L) P + gauge with P the piecewise-constant prolongation; they are inverted on the
+ * device and every PCG step adds P Ac^-1 P^T r to the Jacobi step. */
+int asb_geodesic_coarse_setup(asb_ctx* ctx, int nc, const int* agg, const int* agg_ptr, const int* agg_mem,
+                              const double* heat_c, const double* lap_c);
 /* distances (min-shifted, :206) from nsrc <= 64 sources: out host (nsrc, n); tol = relative residual of the
  * CG solves; iters (optional, 2 ints) = iterations of the heat and the Poisson solve */
 int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters);

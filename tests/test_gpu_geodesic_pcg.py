@@ -1,0 +1,52 @@
+"""GPU (-m gpu): the sparse mode of the device geodesics (two-level PCG: Jacobi + aggregate coarse space,
+csrc/asb_geodesic.hip) against the reference's algorithm with SuperLU (oracle.Geodesics, utils/support.py:139-208) -- on
+the bunny (where Jacobi alone needed thousands of iterations) and on a mesh ABOVE the dense mode's 46 000 vertices, where
+it is what `support='local'` uses by default."""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import asb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_level_pcg_on_the_bunny_vs_superlu():
+    from animsnapbases_amd import GeodesicDistanceComputation, HipEngine
+    g = load_golden("c2_bunny_pca_global")
+    V, T = g["rest"], g["tris"].astype(np.int64)
+    eng = HipEngine(0)
+    geo = GeodesicDistanceComputation(V, T, engine=eng, backend="pcg")
+    ref = orc.Geodesics(V, T)
+    src = [0, 123, 7777, 14289]
+    phi = geo.solve_many(src)
+    its = geo.last_iterations[0]
+    assert its[0] < 400 and its[1] < 400, its                 # (heat, Poisson) iterations; Jacobi alone: thousands
+    for q, s in enumerate(src):
+        assert relerr(phi[q], ref(s)) < 1e-8
+    assert geo.n_aggregates > 500
+    eng.close()
+
+
+def test_local_support_above_the_dense_limit_uses_the_sparse_solver(monkeypatch):
+    """47 122 vertices: posSnapshots' automatic choice is the sparse two-level PCG (dense inverses stop at 46 000); the
+    local-support deflation must give the oracle's sequence and basis (oracle: SuperLU on the host)."""
+    from animsnapbases_amd import posComponents, posSnapshots
+    rest, tris = orc.synth_mesh(152, 310, seed=5)
+    assert rest.shape[0] == 47122
+    verts = orc.synth_snapshots(rest, 12, rank=4, seed=5, kind="bumps")
+    K = 4
+    param = types.SimpleNamespace(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                                  q_support="local", vertPos_numComponents=K, store_vertPos_PCA_sing_val=False,
+                                  vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.3, vertPos_rest_shape="first",
+                                  name="t", vertPos_output_directory=".")
+    snaps = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False)
+    assert snaps.compute_geodesic_distance._engine is not None and not snaps._engine.geodesic_dense
+    comp = posComponents(param, snaps)
+    comp.compute_components_store_singvalues()
+    pre = orc.prepare_snapshots(verts, "first", True)
+    d = orc.extract_k_components(pre["snapTensor"], K, "local", orc.Geodesics(verts[0], tris), 0.1, 0.3)
+    assert comp.selected_vertices.tolist() == d["idx"].tolist()
+    assert relerr(comp.comps, d["comps"]) < 1e-7 and relerr(comp.weigs, d["weigs"]) < 1e-9
