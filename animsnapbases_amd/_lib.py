@@ -70,7 +70,7 @@ PROTOTYPES = {
     "asb_energy_block_argmax": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
     "asb_components_expand": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp]),
     "asb_pod_slices": (c_int, [ctypes.c_void_p, c_int, c_i64]),
-    "asb_geodesic_coarse_setup": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_geodesic_coarse_setup": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dbl]),
     "asb_deim_run": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), c_dp, ctypes.POINTER(c_int)]),
     "asb_deim_block_residual": (c_int, [ctypes.c_void_p, c_i64, c_int, c_dp, ctypes.POINTER(c_dbl)]),
     "asb_sym_eig_topk": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),

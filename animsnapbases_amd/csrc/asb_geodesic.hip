@@ -33,6 +33,7 @@ struct asb_geo {
     double* sv_part = nullptr;      // k_symv_tiles partial sums
     // two-level preconditioner (asb_geodesic_coarse_setup): piecewise-constant aggregates, coarse inverses, coarse vectors
     bool coarse = false;
+    double heat_omega = 1.0;
     int nc = 0, ncp = 0;
     int *agg = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr;
     double *AcH = nullptr, *AcP = nullptr, *rc = nullptr, *zc = nullptr;
@@ -73,7 +74,9 @@ __global__ __launch_bounds__(256) void k_cg_update(int rows, int nblk_in, const 
     for (int q = 0; q < nblk_in; ++q) pap += part_pap[(long long)q * GB + lane];
     // a column that has reached the tolerance (or was zero from the start) is frozen: it must not keep dividing
     // by a vanishing p^T A p while the other columns still iterate
-    const bool active = rz[lane] > tol2 * rz[3 * GB + lane] && pap > 0.0;
+    // (the test is on |r|^2 against its start value, sc[2 GB..] / sc[4 GB..], not on r.z: with the coarse term in the
+    //  preconditioner r.z of a smooth start residual is orders of magnitude above what it is later for the same |r|)
+    const bool active = rz[2 * GB + lane] > tol2 * rz[4 * GB + lane] && rz[lane] > 0.0 && pap > 0.0;
     const double a = active ? rz[lane] / pap : 0.0;
     double s_rz = 0.0, s_rr = 0.0;
     for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_cg_direction(int rows, int nblk_in, con
     double rzn = 0.0, rrn = 0.0;
     for (int q = 0; q < nblk_in; ++q) { rzn += part_rz[(long long)q * GB + lane]; rrn += part_rr[(long long)q * GB + lane]; }
     const double old = rz[lane];
-    const double beta = (first || old == 0.0 || !(old > tol2 * rz[3 * GB + lane])) ? 0.0 : rzn / old;
+    const double beta = (first || old == 0.0 || !(rrn > tol2 * rz[4 * GB + lane])) ? 0.0 : rzn / old;      // (rrn: every block sums the same partials)
     for (int i = blockIdx.x * 4 + wid; i < rows; i += gridDim.x * 4) {
         const long long e = (long long)i * GB + lane;
         p[e] = z[e] + beta * p[e];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void k_cg_direction(int rows, int nblk_in, con
     if (blockIdx.x == gridDim.x - 1 && wid == 0) {       // staged: see k_cg_commit
         rz[GB + lane] = rzn;
         rr[lane] = rrn;
-        if (first) rz[3 * GB + lane] = rzn;               // r0.z0 of the column: the freeze reference
+        if (first) { rz[3 * GB + lane] = rzn; rz[4 * GB + lane] = rrn; }      // r0.z0 and |r0|^2 of the column: the freeze reference
     }
 }
 
@@ -186,6 +189,59 @@ __global__ __launch_bounds__(256) void k_scale_vec(double* __restrict__ x, long 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= a;
 }
 
+// ---- heat step of the sparse mode: (A - tL) u = delta by plain Jacobi sweeps from u = 0.  u falls off like exp(-d / sqrt(t))
+// -- 14 orders of magnitude across a 14 000-vertex mesh -- and the heat method needs the DIRECTION of grad u everywhere, i.e.
+// u to relative accuracy in every component.  A Krylov method converges in a norm (absolute accuracy: the far field is lost,
+// measured 0.7 % error in the distances); the Jacobi sweep of this M-matrix only ever adds non-negative terms, so every
+// component is built up without cancellation and converges to rounding level relative to ITSELF -- what SuperLU's
+// factorisation delivers in the reference.  Rate 1 - area / (area + t sum w) ~ 0.976 per sweep: ~2000 sweeps, each one SpMM.
+// xout = (b - offdiag(A) xin) / diag;  part[block][lane] = max over the block's rows of |xout - xin| / |xout| (1 where 0)
+__global__ __launch_bounds__(256) void k_heat_jacobi(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                     const double* __restrict__ vals, const double* __restrict__ diag, int rows,
+                                                     const double* __restrict__ b, const double* __restrict__ xin,
+                                                     double* __restrict__ xout, double* __restrict__ part, int nsrc, double omega) {
+    __shared__ double sh[4][GB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double worst = 0.0;
+    for (int r = blockIdx.x * 4 + wid; r < rows; r += gridDim.x * 4) {
+        double acc = b[(long long)r * GB + lane];
+        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+            const int c = colidx[j];
+            if (c != r) acc -= vals[j] * xin[(long long)c * GB + lane];
+        }
+        const double xo = xin[(long long)r * GB + lane];
+        const double xn = (1.0 - omega) * xo + omega * (acc / diag[r]);     // omega < 1 only where obtuse triangles break diagonal dominance
+        xout[(long long)r * GB + lane] = xn;
+        if (part && lane < nsrc) {
+            const double rel = xn == 0.0 ? 1.0 : fabs(xn - xo) / fabs(xn);
+            worst = fmax(worst, rel);
+        }
+    }
+    if (part) {
+        sh[wid][lane] = worst;
+        __syncthreads();
+        if (wid == 0) part[(long long)blockIdx.x * GB + lane] = fmax(fmax(sh[0][lane], sh[1][lane]), fmax(sh[2][lane], sh[3][lane]));
+    }
+}
+__global__ __launch_bounds__(64) void k_colmax(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    double m = 0.0;
+    for (int q = 0; q < nblk; ++q) m = fmax(m, part[(long long)q * GB + threadIdx.x]);
+    out[threadIdx.x] = m;
+}
+
+// b[:, c] -= mean(b[:, c]): the Poisson system is singular (constants); a right-hand side with a component along the null
+// vector has no solution, its residual cannot fall below that component, and a preconditioner with a coarse level would
+// amplify it into the search directions.  (The divergence of the normalised gradient field sums to zero only up to rounding.)
+__global__ __launch_bounds__(256) void k_remove_mean(double* __restrict__ b, int n) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += 256) v[0] += b[(long long)i * GB + c];
+    block_sum<1>(v, sh);
+    const double m = v[0] / (double)n;
+    for (int i = threadIdx.x; i < n; i += 256) b[(long long)i * GB + c] -= m;
+}
+
 // b[idx[c]][c] = 1 for the batch's sources (others 0)
 __global__ void k_set_sources(double* __restrict__ b, const long long* __restrict__ idx, int nsrc) {
     const int c = threadIdx.x;
@@ -252,8 +308,48 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
     if ((rc = asb_alloc(ctx, &G->g, (size_t)m3 * GB))) return rc;
     G->nblk = (n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024;
     if ((rc = asb_alloc(ctx, &G->part, (size_t)3 * G->nblk * GB))) return rc;
-    if ((rc = asb_alloc(ctx, &G->sc, (size_t)4 * GB))) return rc;
+    if ((rc = asb_alloc(ctx, &G->sc, (size_t)5 * GB))) return rc;
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// x <- (A - tL)^-1 b for the 64 columns by Jacobi sweeps (see k_heat_jacobi); uses G->p as the second buffer
+static int heat_jacobi64(asb_ctx* ctx, asb_geo* G, const double* b, double* x, int nsrc, int* iters_out) {
+    const int n = G->n, nb = G->nblk;
+    const asb_csr& A = G->heat;
+    ASB_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * GB * sizeof(double), ctx->stream));
+    double* cur = x;
+    double* nxt = G->p;
+    int it = 0;
+    double prev_worst = 2.0;
+    int flat = 0;
+    double h[GB];
+    double worst = 1.0;
+    for (; it < 24000;) {
+        for (int q = 0; q < 64; ++q, ++it) {
+            const bool check = q == 63;
+            hipLaunchKernelGGL(k_heat_jacobi, dim3(nb), dim3(256), 0, ctx->stream, A.rowptr, A.colidx, A.vals, G->dheat, n, b, cur, nxt,
+                               check ? G->part : (double*)nullptr, nsrc, G->heat_omega);
+            double* t = cur; cur = nxt; nxt = t;
+        }
+        hipLaunchKernelGGL(k_colmax, dim3(1), dim3(GB), 0, ctx->stream, G->part, nb, G->sc);
+        ASB_CHECK_LAUNCH(ctx);
+        ASB_HIP(ctx, hipMemcpyAsync(h, G->sc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        worst = 0.0;
+        for (int c = 0; c < nsrc; ++c) worst = h[c] > worst ? h[c] : worst;
+        if (worst <= 2e-15) break;
+        // rounding floor / unreachable vertices (another connected component): stop when the measure no longer moves
+        if (worst < 1e-9 && worst > 0.97 * prev_worst) { if (++flat >= 6) break; } else flat = 0;
+        prev_worst = worst;
+    }
+    if (cur != x) ASB_HIP(ctx, hipMemcpyAsync(x, cur, (size_t)n * GB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (iters_out) *iters_out = it;
+    // the sweep's rate is 1 - min_i area_i / (area_i + t sum_j w_ij): fine on quasi-uniform meshes (scans), hopeless where
+    // element sizes differ by orders of magnitude -- say so instead of returning an unconverged heat field
+    if (!(worst <= 1e-11))
+        ASB_FAIL(ctx, ASB_ERR_NUMERIC, "device geodesics (sparse mode): the heat step's Jacobi sweeps reached a relative change of %.1e "
+                 "after %d sweeps (badly graded mesh); use the host SuperLU backend (ASB_GEODESIC=host)", worst, it);
     return ASB_OK;
 }
 
@@ -261,9 +357,11 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
 // form (agg_ptr nc + 1, agg_mem n), and the two coarse operators P^T (A - tL) P and P^T (-L) P + gauge (host, nc x nc, SPD),
 // which are inverted here on the device (blocked Gauss-Jordan, asb_dense.hip).
 extern "C" int asb_geodesic_coarse_setup(asb_ctx* ctx, int nc, const int* agg, const int* agg_ptr, const int* agg_mem,
-                                         const double* heat_c, const double* lap_c) {
+                                         const double* heat_c, const double* lap_c, double heat_omega) {
     if (!ctx || !ctx->geo || nc < 1 || !agg || !agg_ptr || !agg_mem || !heat_c || !lap_c) return ASB_ERR_ARG;
+    if (!(heat_omega > 0.0 && heat_omega <= 1.0)) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_geodesic_coarse_setup: damping %.3g not in (0, 1]", heat_omega);
     asb_geo* G = ctx->geo;
+    G->heat_omega = heat_omega;
     const int n = G->n, ncp = (nc + 15) / 16 * 16;
     if (nc > 46000) ASB_FAIL(ctx, ASB_ERR_LIMIT, "geodesics: %d aggregates are too many for a dense coarse level", nc);
     int rc;
@@ -314,7 +412,7 @@ static int cg64(asb_ctx* ctx, asb_geo* G, const asb_csr& A, const double* diag, 
     double *rz = G->sc, *rr = G->sc + 2 * GB;       // rz[0..63] current, [64..127] staged, [192..255] initial; rr = sc[128..191]
     const double tol2 = tol * tol;
     ASB_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * GB * sizeof(double), ctx->stream));
-    ASB_HIP(ctx, hipMemsetAsync(G->sc, 0, (size_t)4 * GB * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(G->sc, 0, (size_t)5 * GB * sizeof(double), ctx->stream));
     double* r = b;
     int rcc;
     hipLaunchKernelGGL(k_cg_start, dim3(nb), dim3(256), 0, ctx->stream, n, diag, r, G->z, part_rz, part_rr);
@@ -452,7 +550,9 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     } else {
         ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
-        if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1, G->coarse ? G->AcH : nullptr))) return rc;
+        if (G->coarse) {        // sparse mode proper: componentwise-accurate heat step (Jacobi sweeps), PCG only for Poisson
+            if ((rc = heat_jacobi64(ctx, G, G->b, G->x, nsrc, &it1))) return rc;
+        } else if ((rc = cg64(ctx, G, G->heat, G->dheat, G->b, G->x, nsrc, tol, 4000, &it1))) return rc;
     }
     // gradient, normalise, divergence
     const int gb = (G->m3 + 3) / 4 < 1024 ? (G->m3 + 3) / 4 : 1024;
@@ -465,7 +565,10 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
     if (G->dense) {        // y = (-L + gamma/n 1 1^T)^-1 div : one (np x np) by (np x 64) product
         if ((rc = asb_gemm_nn(ctx, G->Pinv, G->np, G->b, GB, G->x, GB, G->np, GB, G->np, 1.0, 0.0))) return rc;
-    } else if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2, G->coarse ? G->AcP : nullptr))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_remove_mean, dim3(GB), dim3(256), 0, ctx->stream, G->b, n);
+        if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2, G->coarse ? G->AcP : nullptr))) return rc;
+    }
     // phi = -y; phi -= min(phi)  ==  max(y) - y : done by negating in place first
     hipLaunchKernelGGL(k_scale_vec, dim3(G->nblk), dim3(256), 0, ctx->stream, G->x, (long long)n * GB, -1.0);
     if ((rc = asb_alloc(ctx, &ctx->geo_out, (size_t)GB * n))) return rc;

@@ -370,7 +370,7 @@ class HipEngine(object):
         if dense:
             self._ck(self.lib.asb_geodesic_dense_setup(self.h))
         elif coarse is not None:
-            agg, heat_c, lap_c = coarse
+            agg, heat_c, lap_c, omega = coarse
             agg = np.ascontiguousarray(agg, dtype=np.int32)
             nc = int(agg.max()) + 1
             order = np.argsort(agg, kind="stable").astype(np.int32)
@@ -380,7 +380,7 @@ class HipEngine(object):
             lap_c = np.ascontiguousarray(lap_c, dtype=np.float64)
             assert heat_c.shape == lap_c.shape == (nc, nc) and agg.shape == (n,)
             self._ck(self.lib.asb_geodesic_coarse_setup(self.h, nc, agg.ctypes.data, ptr_.ctypes.data, order.ctypes.data,
-                                                        heat_c.ctypes.data, lap_c.ctypes.data))
+                                                        heat_c.ctypes.data, lap_c.ctypes.data, float(omega)))
 
     def apply_geodesic(self, k, dmin, dmax):
         self._ck(self.lib.asb_deflate_apply_geodesic(self.h, int(k), float(dmin), float(dmax)))

@@ -172,7 +172,12 @@ class GeodesicDistanceComputation(object):
             if backend != "dense" and n >= 512:      # sparse mode: aggregates + dense coarse operators (two-level PCG)
                 agg, nc = mesh_aggregates(self._A_heat.tocsr())
                 Hc, Lc = coarse_operators(self._A_heat, L, agg, nc)
-                coarse = (agg, Hc, Lc)
+                # damping of the heat step's Jacobi sweeps: 1 on diagonally dominant matrices (non-obtuse meshes), below
+                # where obtuse triangles (negative cotan weights) push lambda_max(D^-1 A) <= 1 + g towards 2 and beyond
+                dg = self._A_heat.diagonal()
+                g = float(((abs(self._A_heat).sum(axis=1).A1 - dg) / dg).max())
+                omega = 1.0 if g <= 0.98 else min(1.0, 1.8 / (1.0 + g))
+                coarse = (agg, Hc, Lc, omega)
                 self.n_aggregates = nc
             engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D, dense=(backend == "dense"), coarse=coarse)
             self._engine = engine

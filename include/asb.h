@@ -266,9 +266,13 @@ int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_rp, const in
 /* Two-level preconditioner for the sparse (PCG) mode -- what lets it scale past the dense mode's 46 000 vertices: agg (n) =
  * aggregate (0 .. nc-1) of every vertex, agg_ptr / agg_mem its CSR form, heat_c / lap_c (host, nc x nc, SPD) the coarse
  * operators P^T (A - tL) P and P^T (-L) P + gauge with P the piecewise-constant prolongation; they are inverted on the
- * device and every PCG step adds P Ac^-1 P^T r to the Jacobi step. */
+ * device and every PCG step of the POISSON system adds P Ac^-1 P^T r to the Jacobi step.  The HEAT system is solved by
+ * (damped, heat_omega in (0, 1]) Jacobi sweeps from zero instead: its solution spans many orders of magnitude and the
+ * method needs every component to relative accuracy, which a sweep that only adds non-negative terms delivers and a Krylov
+ * method does not.  Quasi-uniform meshes only (the sweep's rate is 1 - min area / (area + t sum w)); otherwise the solve
+ * fails with ASB_ERR_NUMERIC and the host backend is the way. */
 int asb_geodesic_coarse_setup(asb_ctx* ctx, int nc, const int* agg, const int* agg_ptr, const int* agg_mem,
-                              const double* heat_c, const double* lap_c);
+                              const double* heat_c, const double* lap_c, double heat_omega);
 /* distances (min-shifted, :206) from nsrc <= 64 sources: out host (nsrc, n); tol = relative residual of the
  * CG solves; iters (optional, 2 ints) = iterations of the heat and the Poisson solve */
 int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double tol, double* out, int* iters);
