@@ -83,7 +83,10 @@ struct asb_ctx {
     int spec_budget = 16;             // adapted to how many unproven steps survived in the last panels
     long long run_proven = 0;         // provable head of the last asb_panel_run
     double* w_fk = nullptr;                 // weights in the reference's (F, K) order for the read-back
-    unsigned char* host_pin = nullptr;      // pinned host memory for the per-panel read-backs (PanelState + flags)
+    unsigned char* host_pin = nullptr;      // pinned (coherent, device-mapped) host memory for the small read-backs
+    unsigned char* host_pin_dev = nullptr;  // its device address: tiny kernels publish state there, the host polls (asb_pin_alloc)
+    unsigned long long pin_seq = 0;         // sequence number of the last publication
+    int host_poll = 1;                      // ASB_HOST_POLL=0: read-backs by copy + stream synchronisation
     long long n_spec_steps = 0, n_spec_kept = 0;      // statistics (asb_deflate_stats)
     int super_panels = 0;             // ASB_SUPER_PANELS=1
     long long band_target = 12288, band_cap = 16384;
@@ -227,6 +230,16 @@ int asb_deflate_apply_dev(asb_ctx* ctx, int64_t k, const double* s_dev);      //
 int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out);
 
 #define ASB_CHECK_LAUNCH(ctx) ASB_HIP(ctx, hipGetLastError())
+
+// 1 KiB of pinned host memory shared by the small per-panel / per-sweep read-backs:
+//   [0, 256) PanelState, [256, 272) panel-kernel flags, [384, 392) counters, [448, 456) publication sequence number
+static inline int asb_pin_alloc(asb_ctx* ctx) {
+    if (ctx->host_pin) return ASB_OK;
+    ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 1024, hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i < 1024; ++i) ctx->host_pin[i] = 0;
+    if (hipHostGetDevicePointer((void**)&ctx->host_pin_dev, ctx->host_pin, 0) != hipSuccess) ctx->host_pin_dev = nullptr;
+    return ASB_OK;
+}
 
 // (Re)allocates *p to hold `count` elements; an existing allocation that is already large
 // enough (and not more than 2x too large) is kept, so repeated runs on one context do not

@@ -20,6 +20,8 @@
 #include "asb_kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1297,13 +1299,93 @@ static void launch_project(asb_ctx* ctx, int ncols, double* out);
 
 // Per-panel read-back of the panel state (and the panel kernel's flags) through pinned host memory: ONE wait, no staging
 // copy (a pageable destination costs an extra copy kernel and a second round trip for the flags).
-static int read_panel_state(asb_ctx* ctx, PanelState* h, unsigned* flags) {
-    if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
-    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToHost, ctx->stream));
+// Round 2: instead of copy + hipStreamSynchronize (an interrupt-driven wait of 15-25 us, twice per panel), a one-wave kernel
+// writes the state straight into coherent pinned host memory, its sequence number last (system-scope fence in between), and
+// the host polls that word: the wait ends a microsecond or two after the producing kernels do.  Falls back to the
+// synchronising copy if the word does not arrive (or with ASB_HOST_POLL=0).
+__global__ __launch_bounds__(64) void k_publish_state(const PanelState* __restrict__ st, const unsigned* __restrict__ flags,
+                                                      unsigned char* __restrict__ pin, unsigned long long seq) {
+    const int l = threadIdx.x;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(st);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(pin);
+    if (l < (int)(sizeof(PanelState) / 8)) dst[l] = src[l];
+    if (flags && l < 4) reinterpret_cast<unsigned*>(pin + 256)[l] = flags[l];
+    __threadfence_system();
+    __syncthreads();
+    if (l == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(pin + 448), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+static int read_panel_state_from(asb_ctx* ctx, const PanelState* st, PanelState* h, unsigned* flags) {
+    int rc = asb_pin_alloc(ctx);
+    if (rc) return rc;
+    static_assert(sizeof(PanelState) % 8 == 0 && sizeof(PanelState) <= 256, "PanelState must fit its pinned slot");
+    if (ctx->host_poll && ctx->host_pin_dev) {
+        const unsigned long long seq = ++ctx->pin_seq;
+        hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, st, flags ? ctx->coop_bar : (const unsigned*)nullptr,
+                           ctx->host_pin_dev, seq);
+        ASB_CHECK_LAUNCH(ctx);
+        volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->host_pin + 448);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (*word == seq) { arrived = true; break; }
+            if ((spins & 1023) == 1023 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;      // (a kernel fault: the sync below reports it)
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (arrived) {
+            memcpy(h, ctx->host_pin, sizeof(PanelState));
+            if (flags) memcpy(flags, ctx->host_pin + 256, 4 * sizeof(unsigned));
+            return ASB_OK;
+        }
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(h, ctx->host_pin, sizeof(PanelState));
+        if (flags) memcpy(flags, ctx->host_pin + 256, 4 * sizeof(unsigned));
+        return ASB_OK;
+    }
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin, st, sizeof(PanelState), hipMemcpyDeviceToHost, ctx->stream));
     if (flags) ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin + 256, ctx->coop_bar, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(h, ctx->host_pin, sizeof(PanelState));
     if (flags) memcpy(flags, ctx->host_pin + 256, 4 * sizeof(unsigned));
+    return ASB_OK;
+}
+static int read_panel_state(asb_ctx* ctx, PanelState* h, unsigned* flags) { return read_panel_state_from(ctx, ctx->pstate, h, flags); }
+
+// the same for up to 16 device words (8 bytes each): pinned slot [512, 640), sequence word at 648
+__global__ __launch_bounds__(64) void k_publish_words(const unsigned long long* __restrict__ src, int n, unsigned char* __restrict__ pin,
+                                                      unsigned long long seq) {
+    if ((int)threadIdx.x < n) reinterpret_cast<unsigned long long*>(pin + 512)[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(pin + 648), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int fetch_words(asb_ctx* ctx, const void* dev, int n, void* host) {
+    int rc = asb_pin_alloc(ctx);
+    if (rc) return rc;
+    if (n < 1 || n > 16) ASB_FAIL(ctx, ASB_ERR_ARG, "fetch_words: %d words", n);
+    if (ctx->host_poll && ctx->host_pin_dev) {
+        const unsigned long long seq = ++ctx->pin_seq;
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)dev, n, ctx->host_pin_dev, seq);
+        ASB_CHECK_LAUNCH(ctx);
+        volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->host_pin + 648);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (*word == seq) { arrived = true; break; }
+            if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!arrived) ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(host, ctx->host_pin + 512, (size_t)n * 8);
+        return ASB_OK;
+    }
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin + 512, dev, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->host_pin + 512, (size_t)n * 8);
     return ASB_OK;
 }
 
@@ -2077,8 +2159,7 @@ extern "C" int asb_panel_global_tau(asb_ctx* ctx, const double* tab_dev, int wor
                        (long long)ctx->m_target + 1, ctx->scalar_dev, ctx->bam_idx);
     ASB_CHECK_LAUNCH(ctx);
     long long h[16];
-    ASB_HIP(ctx, hipMemcpyAsync(h, ctx->bam_idx, (size_t)world * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = fetch_words(ctx, ctx->bam_idx, world, h))) return rc;
     for (int r = 0; r < world; ++r) counts_out[r] = h[r];
     return ASB_OK;
 }
@@ -2661,11 +2742,9 @@ static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelSta
     ctx->nblk = cgrid;
     hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, -1, kb, ctx->scal, st);
     ASB_CHECK_LAUNCH(ctx);
-    if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
-    ASB_HIP(ctx, hipMemcpyAsync(ctx->host_pin, st, sizeof(PanelState), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PanelState h;
-    memcpy(&h, ctx->host_pin, sizeof(h));
+    int rcs = read_panel_state_from(ctx, st, &h, nullptr);
+    if (rcs) return rcs;
     *kept = h.committed;
     return ASB_OK;
 }

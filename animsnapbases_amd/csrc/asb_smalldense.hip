@@ -365,7 +365,7 @@ int asb_jacobi_rows_dev(asb_ctx* ctx, double* A, int nv, int m, long long lda, d
     hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(256), 0, ctx->stream, ctx->jac_sig, nv, fro2);
     int sweep = 0;
     bool converged = nv == 1;
-    if (!ctx->host_pin) ASB_HIP(ctx, hipHostMalloc((void**)&ctx->host_pin, 512, hipHostMallocDefault));
+    { int rcp = asb_pin_alloc(ctx); if (rcp) return rcp; }
     for (; sweep < 60 && !converged; ++sweep) {
         ASB_HIP(ctx, hipMemsetAsync(n_rot, 0, sizeof(unsigned), ctx->stream));
         for (int r = 0; r < n2 - 1; ++r)

@@ -264,6 +264,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if (const char* pc = getenv("ASB_PANEL_COOP")) ctx->panel_coop = atoi(pc);
     if (const char* ts = getenv("ASB_COOP_TEST_STALL")) ctx->coop_test_stall = atoi(ts);
     if (const char* er = getenv("ASB_E0_REUSE")) ctx->e0_reuse = atoi(er);
+    if (const char* hp = getenv("ASB_HOST_POLL")) ctx->host_poll = atoi(hp);
     if (const char* cr = getenv("ASB_CORRECT_ROWS")) ctx->correct_rows = atoi(cr);
     if (const char* sp = getenv("ASB_SUPER_PANELS")) ctx->super_panels = atoi(sp);
     if (const char* sp = getenv("ASB_SPEC_PANELS")) ctx->spec_panels = atoi(sp);
