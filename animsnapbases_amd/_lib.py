@@ -81,6 +81,7 @@ PROTOTYPES = {
     "asb_test_jacobi_rows": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),
     "asb_test_chol_tinv": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp]),
     "asb_deflate_energy_passes": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
+    "asb_fetch_double": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "asb_panel_set_coop": (c_int, [ctypes.c_void_p, c_int]),
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),

@@ -41,6 +41,9 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     _, rows_loc, idx_loc, top_loc, top_all = bufs
     packed_ok = hasattr(eng, "panel_assemble_packed")
     spec_word = torch.zeros(1, dtype=torch.float64, device=dev) if (hasattr(eng, "panel_project_spec_dev") and dev.type != "cpu") else None
+    # the reduced word comes back through the engine's polled pinned slot when the collective ran on the engine's stream
+    same_stream = spec_word is not None and hasattr(eng, "fetch_double") and getattr(comm, "on_engine_stream", True)
+    read_word = (lambda: eng.fetch_double(spec_word.data_ptr())) if same_stream else (lambda: spec_word.item())
     # lock-step protection of the co-resident panel kernel (see below): only with the real engine, several ranks, kernel on
     coop_check = bool(spec_word is not None and comm.multi and hasattr(eng, "panel_set_coop") and
                       os.environ.get("ASB_PANEL_COOP", "1") != "0")
@@ -112,7 +115,7 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                     spec_word.fill_(float(done))             # -1: failed here; otherwise the fully proven count
                     passed = False
                 comm.allreduce_min_tensor(spec_word)
-                agreed = int(spec_word.item())
+                agreed = int(read_word())
                 if agreed >= 0:
                     break
                 eng.panel_set_coop(False)                    # somewhere the exchange timed out: all ranks leave the kernel
@@ -132,7 +135,7 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                 if spec_word is not None:                 # count stays on the device: min over ranks, ONE read
                     eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
                     comm.allreduce_min_tensor(spec_word)
-                    done = int(spec_word.item())
+                    done = int(read_word())
                 else:
                     mine = eng.panel_project_spec(k, done, proven)
                     done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine

@@ -2644,6 +2644,12 @@ extern "C" int asb_panel_scale(asb_ctx* ctx, double* normX2_local, double* e0max
     return ASB_OK;
 }
 
+// one device word (the min-all-reduced count of a panel) to the host without a stream synchronisation: published into
+// pinned memory behind whatever the stream still has to do (the collective included) and polled
+extern "C" int asb_fetch_double(asb_ctx* ctx, const double* dev, double* out) {
+    if (!ctx || !dev || !out) return ASB_ERR_ARG;
+    return fetch_words(ctx, dev, 1, out);
+}
 // multi-rank driver: switch the co-resident panel kernel on / off for this context (all ranks together); returns the old value
 extern "C" int asb_panel_set_coop(asb_ctx* ctx, int on) {
     if (!ctx) return ASB_ERR_ARG;

@@ -273,6 +273,11 @@ class HipEngine(object):
     def panel_project_spec_dev(self, k0, ncols, proven, out_dev_ptr):
         self._ck(self.lib.asb_panel_project_spec_dev(self.h, int(k0), int(ncols), int(proven), ctypes.c_void_p(out_dev_ptr)))
 
+    def fetch_double(self, dev_ptr):
+        v = ctypes.c_double()
+        self._ck(self.lib.asb_fetch_double(self.h, ctypes.c_void_p(dev_ptr), ctypes.byref(v)))
+        return v.value
+
     def panel_set_coop(self, on):
         """Switches the co-resident panel kernel on / off; returns the previous setting."""
         return int(self.lib.asb_panel_set_coop(self.h, int(bool(on))))

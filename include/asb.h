@@ -214,6 +214,9 @@ int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
  * the driver min-reduces that over the ranks, switches it off everywhere (asb_panel_set_coop, returns the old setting) and
  * repeats the panel on every rank. */
 int asb_panel_set_coop(asb_ctx* ctx, int on);
+/* *out = *dev (one float64 in device memory, e.g. the min-all-reduced count of asb_panel_project_spec_dev) in stream order,
+ * published into pinned host memory and polled there instead of a stream synchronisation */
+int asb_fetch_double(asb_ctx* ctx, const double* dev, double* out);
 /* the final residual in the reference layout (F, n_loc, 3) (R of :125) */
 int asb_deflate_download_residual(asb_ctx* ctx, double* out);
 

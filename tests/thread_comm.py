@@ -34,6 +34,7 @@ class ThreadComm(object):
         self.multi = self.world > 1
         self._torch = torch
         self._dev = torch.device("cuda", 0)
+        self.on_engine_stream = False       # the emulated collectives run on torch's stream behind device-wide syncs
 
     def shards(self, N):
         return partition(N, self.world)
