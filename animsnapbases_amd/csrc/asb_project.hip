@@ -2097,6 +2097,7 @@ __global__ __launch_bounds__(1024) void k_global_tau(const double* __restrict__ 
                                                      double* __restrict__ sc, long long* __restrict__ counts) {
     extern __shared__ unsigned long long keys[];          // world * cap
     __shared__ unsigned hist[256];
+    __shared__ long long wsum[4];
     __shared__ unsigned long long prefix_sh;
     __shared__ long long remaining_sh;
     __shared__ double tau_sh;
@@ -2117,15 +2118,32 @@ __global__ __launch_bounds__(1024) void k_global_tau(const double* __restrict__ 
             if (byte == 7 || (kx >> (8 * (byte + 1))) == prefix) atomicAdd(&hist[(kx >> (8 * byte)) & 255ull], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            long long rem = remaining_sh;
-            int b = 255;
-            for (; b > 0; --b) {
-                if ((long long)hist[b] >= rem) break;
-                rem -= hist[b];
+        // the bin where the count from the top reaches what is still wanted: a scan over the 256 bins by 256 threads
+        // (thread i <-> bin 255 - i) instead of one thread walking them
+        {
+            const long long rem = remaining_sh;
+            long long v = 0, incl = 0;
+            if (tid < 256) {
+                v = hist[255 - tid];
+                incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const long long up = __shfl_up(incl, o, 64);
+                    if ((tid & 63) >= o) incl += up;
+                }
+                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
             }
-            remaining_sh = rem;
-            prefix_sh = (prefix << 8) | (unsigned long long)b;
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < (tid >> 6); ++w) incl += wsum[w];
+                const long long excl = incl - v;
+                const int b = 255 - tid;
+                // bins 255 .. 1: the first whose running count reaches rem; bin 0 takes what is left when none does
+                if ((b > 0 && excl < rem && incl >= rem) || (b == 0 && excl < rem)) {
+                    remaining_sh = rem - excl;
+                    prefix_sh = (prefix << 8) | (unsigned long long)b;
+                }
+            }
         }
         __syncthreads();
     }
