@@ -84,6 +84,7 @@ PROTOTYPES = {
     "asb_fetch_double": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "asb_panel_set_coop": (c_int, [ctypes.c_void_p, c_int]),
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
+    "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_deflate_block_argmax": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp]),
     "asb_deflate_force_next": (c_int, [ctypes.c_void_p, c_i64]),

@@ -51,7 +51,14 @@ struct asb_ctx {
     // of the first projection-mode begin after X changed; every writer of X clears e0_valid
     double* tr_part = nullptr;  // per-strip [sum, sum of squares] of the fused layout change
     double* E0 = nullptr;       // (n_loc)
-    double* e0_sc = nullptr;    // [|X|^2 of the shard, largest energy]
+    double* e0_sc = nullptr;    // [|X|^2 of the shard, largest energy, energy along the constant-in-time direction]
+    // EV[v] = E0[v] - sum_d (sum_f X[v,d,f])^2 / F: the energy left once the constant-in-time direction is gone -- what the
+    // first panel uses to GUESS its later winners when that direction carries much of |X|^2 (mean_frac; rest shape "first")
+    double* EV = nullptr;
+    double* mean_part = nullptr;      // per-block partials of that energy
+    double mean_frac = 0.0;
+    int first_panel_mean = 1;   // ASB_FIRST_PANEL_MEAN=0: first panel from the initial energies alone
+    const double* sel_e2 = nullptr;      // != NULL while a panel's candidates are { E > tau } u { sel_e2 > tau_v }
     bool e0_valid = false;
     int64_t n_energy_pass = 0;  // reads of X the last asb_deflate_begin spent on initial energies (statistics)
 
@@ -74,6 +81,7 @@ struct asb_ctx {
     int e0_reuse = 1;                 // ASB_E0_REUSE=0 -> asb_project_begin always re-reads X for the initial energies
     int correct_rows = 1;             // ASB_CORRECT_ROWS=0 -> the one-thread-per-vertex correction kernel (k_correct)
     int coop_test_stall = 0;          // ASB_COOP_TEST_STALL=1 (tests): the first co-resident launch is made to time out
+    int64_t n_guess_panels = 0;       // first panels of the last run whose candidates were guessed (asb_project_run)
     int64_t n_coop_fallbacks = 0;     // launches of k_panel_coop whose record exchange timed out (redone by the two-kernel loop)
     // super-panels (asb_project.hip): how the next asb_panel_run behaves / what it did
     int run_writeback = 0, run_theta_band = 0, run_coop_used = 0;

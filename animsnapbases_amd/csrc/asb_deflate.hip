@@ -44,6 +44,7 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->k_done = 0;
     ctx->n_panels = ctx->n_refresh = 0;
     ctx->n_spec_steps = ctx->n_spec_kept = 0;
+    ctx->n_guess_panels = 0;
     ctx->spec_budget = ASB_PANEL_COLS;
     if (mode == ASB_DEFLATE_PROJECT) return asb_project_begin(ctx, K);
     const size_t rows = (size_t)ctx->n_loc * 3;
@@ -306,6 +307,12 @@ extern "C" int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes) {
 extern "C" int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n) {
     if (!ctx || !n) return ASB_ERR_ARG;
     *n = ctx->n_coop_fallbacks;
+    return ASB_OK;
+}
+
+extern "C" int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n) {
+    if (!ctx || !n) return ASB_ERR_ARG;
+    *n = ctx->n_guess_panels;
     return ASB_OK;
 }
 

@@ -30,7 +30,21 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // layout of ctx->scalar_dev (doubles)
 enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
-       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13 };        // 8..10: k_best_energy; 11..13: super-panels (band)
+       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16 };  // 8..10: k_best_energy; 11..13: super-panels (band);
+                                                                     // 16..16+ASB_NG-1: thresholds of a guessed selection
+// Guessed candidates of a first panel (see asb_project_run): the scores EV + g (E - EV), g on a geometric grid -- E - EV
+// is the energy along the constant-in-time direction, of which the first components leave a falling share g behind
+#define ASB_NG 5
+__device__ __forceinline__ double guess_g(int q) {
+    return q == 0 ? 0.0 : (q == 1 ? 0.02 : (q == 2 ? 0.05 : (q == 3 ? 0.12 : 0.3)));
+}
+__device__ __forceinline__ bool in_guess(double e, double ev, const double* __restrict__ sc) {
+    const double m = e - ev;
+    bool in = false;
+#pragma unroll
+    for (int q = 0; q < ASB_NG; ++q) in = in || (ev + guess_g(q) * m > sc[SC_TAUG + q]);
+    return in;
+}
 
 // --------------------------------------------------------------------------------------
 // k_gather: item s -> vertex v = idx_map[s] - v0 (or s); rebuilds its residual row
@@ -185,14 +199,15 @@ __global__ void k_range_restore(double* __restrict__ sc, const double* __restric
 // covers the whole dynamic range of the energies (they fall by 1e8 on low-rank data);
 // level 2: linear bins inside the crossing binade [lo, hi).
 __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long long n, const double* __restrict__ sc,
-                                              int* __restrict__ hist, int by_exponent) {
+                                              int* __restrict__ hist, int by_exponent, const double* __restrict__ E2 = nullptr,
+                                              double g = 0.0) {
     __shared__ int lh[ASB_NBINS];
     for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const double lo = sc[SC_LO], hi = sc[SC_HI];
     const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const double e = E[i];
+        const double e = E2 ? E2[i] + g * (E[i] - E2[i]) : E[i];       // a guessed selection's score
         int b;
         if (by_exponent) {
             if (!(e >= 0.0)) continue;
@@ -273,7 +288,8 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
 #define ASB_CBLOCKS 128
 __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E, long long n, long long v0,
                                                    const double* __restrict__ sc, int take_all, long long m_cap,
-                                                   long long* __restrict__ tmp, long long* __restrict__ cnt, int hi_slot = -1) {
+                                                   long long* __restrict__ tmp, long long* __restrict__ cnt, int hi_slot = -1,
+                                                   const double* __restrict__ E2 = nullptr) {
     __shared__ long long pre[256];
     const int tid = threadIdx.x;
     const double tau = take_all ? -1.0e300 : sc[SC_TAU];
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     const long long sub = (seg + 255) / 256;
     const long long a = s0 + tid * sub, b = (a + sub < s1) ? a + sub : s1;
     long long c = 0;
-    for (long long i = a; i < b; ++i) c += (E[i] > tau && !(E[i] > tau_hi));
+    for (long long i = a; i < b; ++i) c += ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc)));
     pre[tid] = c;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     long long pos = pre[tid] - c;
     long long* out = tmp + (long long)blockIdx.x * m_cap;
     for (long long i = a; i < b; ++i)
-        if (E[i] > tau && !(E[i] > tau_hi)) {
+        if ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc))) {
             if (pos < m_cap) out[pos] = v0 + i;
             ++pos;
         }
@@ -432,7 +448,8 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                                                  double* __restrict__ psum, double* __restrict__ colpart,
                                                  const long long* __restrict__ vmap = nullptr,
                                                  const PanelState* __restrict__ bstate = nullptr, long long v0 = 0,
-                                                 PanelState* __restrict__ spec = nullptr, const double* __restrict__ sc = nullptr) {
+                                                 PanelState* __restrict__ spec = nullptr, const double* __restrict__ sc = nullptr,
+                                                 const double* __restrict__ E2 = nullptr) {
     if (vmap != nullptr) n_vert = bstate->n_cand;
     __shared__ int sh_viol[4];
     int viol = ASB_PANEL_COLS;
@@ -506,7 +523,8 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
         if (SPEC) {
             if (valid) {
                 double e = E[vi];
-                const bool outside = !(e > sp_tau);           // the compaction took E > tau
+                // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds)
+                const bool outside = !(e > sp_tau) && !(E2 && in_guess(e, E2[vi], sc));
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     if (t < ncols) {
@@ -577,7 +595,8 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                                                       const double* __restrict__ wn2, double* __restrict__ E,
                                                       double* __restrict__ pmax, long long* __restrict__ pidx,
                                                       double* __restrict__ psum, double* __restrict__ colpart,
-                                                      PanelState* __restrict__ spec, const double* __restrict__ sc) {
+                                                      PanelState* __restrict__ spec, const double* __restrict__ sc,
+                                                      const double* __restrict__ E2 = nullptr) {
     __shared__ double qs[16 * 192];
     const int tid = threadIdx.x;
     const long long n_rows = 3 * n_vert;
@@ -630,7 +649,8 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
             if (v < n_vert) {
                 double e = E[v];
                 if (SPEC) {
-                    const bool outside = !(e > sc[SC_TAU]);           // the compaction took E > tau
+                    // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds)
+                    const bool outside = !(e > sc[SC_TAU]) && !(E2 && in_guess(e, E2[v], sc));
                     const double margin = spec->margin;
                     const int proven = (int)spec->proven;
 #pragma unroll
@@ -1440,12 +1460,12 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
         if (rows_kernel)
             hipLaunchKernelGGL(k_correct_rows<true>, dim3(cgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                                (long long)ctx->n_loc, (int)k0, ncols, ctx->gram_s, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
-                               ctx->psum, ctx->colpart, ctx->pstate, ctx->scalar_dev);
+                               ctx->psum, ctx->colpart, ctx->pstate, ctx->scalar_dev, ctx->sel_e2);
         else
             hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                                (long long)ctx->n_loc, (int)k0, ncols, ctx->gram, ctx->wn2t, ctx->energy, ctx->pmax, ctx->pidx,
                                ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0,
-                               ctx->pstate, ctx->scalar_dev);
+                               ctx->pstate, ctx->scalar_dev, ctx->sel_e2);
         ASB_CHECK_LAUNCH(ctx);
         if (check_only) return ASB_OK;
         return project_commit(ctx, k0, -1, kept);
@@ -1716,8 +1736,9 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
                        ctx->scalar_dev, 1);
     ASB_CHECK_LAUNCH(ctx);
     ctx->n_energy_pass = 1;
+    ctx->mean_frac = 0.0;          // EV comes with the standardisation sweep only
     if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)2))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)4))) return rc;
     ASB_HIP(ctx, hipMemcpyAsync(ctx->E0, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     ASB_HIP(ctx, hipMemcpyAsync(ctx->e0_sc, ctx->scalar_dev + SC_NORMX2, 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     ctx->e0_valid = true;
@@ -2008,7 +2029,7 @@ extern "C" int asb_panel_select(asb_ctx* ctx, int64_t k, int64_t forced_gidx, in
                            idx, ctx->pstate);
     } else {
         hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, n, (long long)ctx->v0,
-                           ctx->scalar_dev, global_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt);
+                           ctx->scalar_dev, global_all, (long long)ctx->m_cap, ctx->ctmp, ctx->ccnt, -1, ctx->sel_e2);
         hipLaunchKernelGGL(k_compact_b, dim3(ASB_CBLOCKS), dim3(64), 0, ctx->stream, ctx->ctmp, ctx->ccnt, ASB_CBLOCKS,
                            (long long)ctx->m_cap, idx, ctx->pstate);
     }
@@ -2860,6 +2881,18 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     return ASB_OK;
 }
 
+// two-level histogram threshold of the energies (E2 == NULL) or of the score E2 + g (E - E2): sc[SC_TAU] such that about
+// m_target of the n_loc values lie above it
+static int panel_threshold(asb_ctx* ctx, const double* E, const double* E2, double g, long long m_target, long long m_cap) {
+    for (int level = 1; level <= 2; ++level) {
+        hipLaunchKernelGGL(k_hist, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, E, (long long)ctx->n_loc, ctx->scalar_dev,
+                           ctx->hist, level == 1 ? 1 : 0, E2, g);
+        hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level, m_target, m_cap);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
     long long k = k0;
@@ -2875,6 +2908,7 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     }
     const bool use_double = ctx->double_panels && !use_super && !global_all && ctx->panel_coop && ctx->Fp <= 2048 && ctx->spec_panels;
     while (k < k1) {
+        ctx->sel_e2 = nullptr;
         if (use_double && stalled == 0) {
             int64_t done = 0;
             if ((rc = double_panel(ctx, k, k1, &done))) return rc;
@@ -2904,9 +2938,37 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
             forced = ctx->v0 + li;
             (void)be;
         } else if (!global_all) {
-            for (int level = 1; level <= 2; ++level) {
-                if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
-                if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+            // First panel of a tensor whose energy sits largely in the constant-in-time direction (rest shape "first":
+            // every row carries its own offset): the first components remove that direction from EVERY vertex, after which
+            // the initial energies say nothing about who wins next, and a panel chosen by them alone ends after ~3 steps
+            // (config 4).  EV -- the energy without that direction, a by-product of the standardisation sweep -- is a good
+            // GUESS of the later ranking; the components do not remove the constant direction at once but leave a falling
+            // share g of it behind (0.1, 0.05, 0.04, 0.03 ... on config 4), so the ranking that matters at step t is that
+            // of EV + g_t (E - EV) with g_t unknown beforehand.  The candidates are { E > tau_E } (few: the provable first
+            // steps) united with the top vertices of that score for g on a geometric grid.  Nothing rests on the guess:
+            // steps beyond the provable ones are unproven steps, checked by the pass against every vertex outside the
+            // candidate set like any others.
+            const bool guess = k == 0 && stalled == 0 && ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop &&
+                               ctx->Fp <= 2048 && ctx->EV && ctx->e0_valid && ctx->n_energy_pass == 0 && ctx->mean_frac > 0.25 &&
+                               ctx->m_target >= 256;
+            if (guess) {
+                // ~590 candidates on config 4 (the sets overlap), at most 894 + bin overshoot of the 1024 resident waves
+                static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3};
+                static const int mq[ASB_NG] = {400, 140, 140, 90, 60};
+                for (int q = 0; q < ASB_NG; ++q) {
+                    const long long m = mq[q] * ctx->m_target / 768;
+                    if ((rc = panel_threshold(ctx, ctx->energy, ctx->EV, gq[q], m, m + m / 8))) return rc;
+                    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAUG + q, (int)SC_TAU);
+                }
+                const long long me = ctx->m_target / 12;
+                if ((rc = panel_threshold(ctx, ctx->energy, nullptr, 0.0, me, me + me / 2))) return rc;
+                ctx->sel_e2 = ctx->EV;
+                ctx->n_guess_panels++;
+            } else {
+                for (int level = 1; level <= 2; ++level) {
+                    if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+                    if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+                }
             }
         }
         if ((rc = asb_panel_select(ctx, k, forced, forced >= 0 ? 1 : global_all, nullptr, nullptr, nullptr, nullptr))) return rc;
@@ -2948,6 +3010,7 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
         if ((rc = asb_panel_project(ctx, k, (int)done))) return rc;
         k += done;
     }
+    ctx->sel_e2 = nullptr;
     return ASB_OK;
 }
 

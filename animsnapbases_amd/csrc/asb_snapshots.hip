@@ -177,51 +177,70 @@ __global__ __launch_bounds__(256) void k_scale(double* __restrict__ X, long long
 }
 
 // k_scale_energy: row *= a AND the per-vertex energies of the scaled tensor in the same sweep (one wave per vertex: its
-// three rows are 3 Fp contiguous doubles; the zero padding stays zero).  E0[v] = sum of the scaled squares; per-block
-// (sum, max) partials for |X|^2 and the largest energy -- what the projection path would otherwise re-read all of X for.
-__global__ __launch_bounds__(256) void k_scale_energy(double* __restrict__ X, long long n_vert, int Fp, double a,
-                                                      double* __restrict__ E0, double* __restrict__ psum,
-                                                      double* __restrict__ pmax) {
-    __shared__ double sh[8];
+// three rows are 3 Fp contiguous doubles; the zero padding stays zero).  E0[v] = sum of the scaled squares; EV[v] = E0[v]
+// minus the energy along the constant-in-time direction (row sums squared / F); per-block (sum, max, sum of that energy)
+// partials for |X|^2, the largest energy and the share of the constant direction -- what the projection path would
+// otherwise re-read all of X for.
+__global__ __launch_bounds__(256) void k_scale_energy(double* __restrict__ X, long long n_vert, int Fp, int F, double a,
+                                                      double* __restrict__ E0, double* __restrict__ EV,
+                                                      double* __restrict__ psum, double* __restrict__ pmax,
+                                                      double* __restrict__ pmean) {
+    __shared__ double sh[12];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n2 = 3 * Fp / 2;
-    double bsum = 0.0, bmax = 0.0;
+    const int h2 = Fp / 2;
+    const double inv_f = 1.0 / (double)F;
+    double bsum = 0.0, bmax = 0.0, bmean = 0.0;
     for (long long v = (long long)blockIdx.x * 4 + wid; v < n_vert; v += (long long)gridDim.x * 4) {
-        double2* p = reinterpret_cast<double2*>(X + v * 3 * Fp);
-        double e0 = 0.0, e1 = 0.0;
-        for (int i = lane; i < n2; i += 64) {
-            double2 q = p[i];
-            q.x *= a;
-            q.y *= a;
-            p[i] = q;
-            e0 += q.x * q.x;
-            e1 += q.y * q.y;
+        double e0 = 0.0, e1 = 0.0, m = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double2* p = reinterpret_cast<double2*>(X + (v * 3 + d) * Fp);
+            double s = 0.0;
+            for (int i = lane; i < h2; i += 64) {
+                double2 q = p[i];
+                q.x *= a;
+                q.y *= a;
+                p[i] = q;
+                e0 += q.x * q.x;
+                e1 += q.y * q.y;
+                s += q.x + q.y;
+            }
+            s = wave_sum(s);
+            m += s * s;
         }
         const double e = wave_sum(e0 + e1);
-        if (lane == 0) E0[v] = e;
+        m *= inv_f;
+        if (lane == 0) {
+            E0[v] = e;
+            EV[v] = e > m ? e - m : 0.0;
+        }
         bsum += e;
+        bmean += m;
         bmax = fmax(bmax, e);
     }
-    if (lane == 0) { sh[wid] = bsum; sh[4 + wid] = bmax; }
+    if (lane == 0) { sh[wid] = bsum; sh[4 + wid] = bmax; sh[8 + wid] = bmean; }
     __syncthreads();
     if (threadIdx.x == 0) {
         psum[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         pmax[blockIdx.x] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+        pmean[blockIdx.x] = (sh[8] + sh[9]) + (sh[10] + sh[11]);
     }
 }
 
-__global__ __launch_bounds__(256) void k_e0_finish(const double* __restrict__ psum, const double* __restrict__ pmax, int n,
-                                                   double* __restrict__ out) {
-    __shared__ double sh[8];
-    double s = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { s += psum[i]; m = fmax(m, pmax[i]); }
+__global__ __launch_bounds__(256) void k_e0_finish(const double* __restrict__ psum, const double* __restrict__ pmax,
+                                                   const double* __restrict__ pmean, int n, double* __restrict__ out) {
+    __shared__ double sh[12];
+    double s = 0.0, m = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s += psum[i]; m = fmax(m, pmax[i]); c += pmean[i]; }
     s = wave_sum(s);
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = m; }
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = m; sh[8 + (threadIdx.x >> 6)] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         out[1] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7]));
+        out[2] = (sh[8] + sh[9]) + (sh[10] + sh[11]);
     }
 }
 
@@ -264,6 +283,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if (const char* pc = getenv("ASB_PANEL_COOP")) ctx->panel_coop = atoi(pc);
     if (const char* ts = getenv("ASB_COOP_TEST_STALL")) ctx->coop_test_stall = atoi(ts);
     if (const char* er = getenv("ASB_E0_REUSE")) ctx->e0_reuse = atoi(er);
+    if (const char* er = getenv("ASB_FIRST_PANEL_MEAN")) ctx->first_panel_mean = atoi(er);
     if (const char* hp = getenv("ASB_HOST_POLL")) ctx->host_poll = atoi(hp);
     if (const char* cr = getenv("ASB_CORRECT_ROWS")) ctx->correct_rows = atoi(cr);
     if (const char* sp = getenv("ASB_SUPER_PANELS")) ctx->super_panels = atoi(sp);
@@ -276,7 +296,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if ((rc = asb_alloc(ctx, &ctx->pmax, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pidx, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->psum, (size_t)ctx->nblk_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)32))) return rc;
     return ASB_OK;
 }
 
@@ -517,15 +537,22 @@ extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     // asb_project_begin then needs no pass over X of its own
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)2))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->EV, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)4))) return rc;
     long long want = (ctx->n_loc + 3) / 4;
     const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
-    hipLaunchKernelGGL(k_scale_energy, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc, (int)ctx->Fp, a,
-                       ctx->E0, ctx->psum, ctx->pmax);
+    if ((rc = asb_alloc(ctx, &ctx->mean_part, (size_t)ctx->nblk_cap))) return rc;
+    hipLaunchKernelGGL(k_scale_energy, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc, (int)ctx->Fp, (int)ctx->F,
+                       a, ctx->E0, ctx->EV, ctx->psum, ctx->pmax, ctx->mean_part);
     ASB_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_e0_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->psum, ctx->pmax, grid, ctx->e0_sc);
+    hipLaunchKernelGGL(k_e0_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->psum, ctx->pmax, ctx->mean_part, grid, ctx->e0_sc);
     ASB_CHECK_LAUNCH(ctx);
     ctx->e0_valid = true;
+    // share of |X|^2 along the constant-in-time direction (this sweep is part of the preparation, not of a deflation step)
+    double h[3];
+    ASB_HIP(ctx, hipMemcpyAsync(h, ctx->e0_sc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->mean_frac = h[0] > 0.0 ? h[2] / h[0] : 0.0;
     return ASB_OK;
 }
 

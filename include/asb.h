@@ -209,6 +209,12 @@ int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes);
  * (k_panel_coop).  If that exchange times out -- the blocks were not all resident because something else shares the GPU --
  * the panel is redone by the two-kernel loop and the context stays on it; *n = how often that happened (lifetime). */
 int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
+/* First panel of a tensor whose energy sits largely (> 1/4) in the constant-in-time direction (rest shape "first" on
+ * noise-like data): its candidates are guessed from the energies without that direction (a by-product of
+ * asb_snapshots_scale) in addition to the few largest initial energies; the steps taken on the guess are unproven steps
+ * like any others (asb_deflate_spec_stats), so the sequence is still that of posComponents.py:75-77.  *n = 1 if the last
+ * run did so.  ASB_FIRST_PANEL_MEAN=0 switches it off. */
+int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
 /* Multi-rank runs (assembled candidate buffer): a timed-out exchange is NOT redone locally -- the ranks must stay in
  * lock-step -- asb_panel_run / asb_panel_run_spec then return *committed = -1 with the kernel switched off for this context;
  * the driver min-reduces that over the ranks, switches it off everywhere (asb_panel_set_coop, returns the old setting) and

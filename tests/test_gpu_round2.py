@@ -163,3 +163,37 @@ def test_multirank_panel_kernel_timeout_is_redone_in_lock_step(monkeypatch):
         assert st["coop_fallbacks"] == 1
     for o in outs[1:]:
         assert np.array_equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("shape", [(130, 9000, 40), (400, 30000, 48)])
+def test_first_panel_guessed_from_the_energies_without_the_constant_direction(shape, monkeypatch):
+    """Rest shape "first" on noise: half of |X|^2 is each row's own offset, the first components remove it from every
+    vertex, and a first panel chosen by the initial energies alone ends after a few steps.  With the guess
+    (ASB_FIRST_PANEL_MEAN, default on) the first panel's candidates also come from the energies without the constant
+    direction; everything beyond the provable steps is checked by the pass, so sequence and basis are the oracle's either
+    way -- and fewer reads of X are needed."""
+    F, N, K = shape
+    rng = np.random.default_rng(21)
+    verts = rng.uniform(-1, 1, size=(F, N, 3))
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    comp, st = _run(verts, K, calls=2)
+    _check(comp, d)
+    assert [s["guessed_panels"] for s in st] == [1, 1]
+    monkeypatch.setenv("ASB_FIRST_PANEL_MEAN", "0")
+    comp0, st0 = _run(verts, K)
+    _check(comp0, d)
+    assert st0[0]["guessed_panels"] == 0
+    assert relerr(comp.comps, comp0.comps) < 1e-12 and relerr(comp.weigs, comp0.weigs) < 1e-12
+    assert st[0]["panels"] <= st0[0]["panels"]
+    # rest shape "average" removes the constant direction beforehand: nothing to guess
+    monkeypatch.delenv("ASB_FIRST_PANEL_MEAN")
+    from animsnapbases_amd import posComponents, posSnapshots
+    snaps = posSnapshots.from_arrays(verts, None, "average", standarize=True, massWeight=False)
+    p = _param(K)
+    p.vertPos_rest_shape = "average"
+    compa = posComponents(p, snaps)
+    compa.deflate_mode = "project"
+    compa.compute_components_store_singvalues()
+    assert snaps._engine.deflate_stats()["guessed_panels"] == 0
+    da = orc.extract_k_components(orc.prepare_snapshots(verts, "average", True)["snapTensor"], K)
+    _check(compa, da)
