@@ -85,6 +85,10 @@ PROTOTYPES = {
     "asb_panel_set_coop": (c_int, [ctypes.c_void_p, c_int]),
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
+    "asb_panel_guess_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(c_int)]),
+    "asb_panel_guess_begin": (c_int, [ctypes.c_void_p, c_int]),
+    "asb_panel_guess_end": (c_int, [ctypes.c_void_p]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_deflate_block_argmax": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp]),
     "asb_deflate_force_next": (c_int, [ctypes.c_void_p, c_i64]),

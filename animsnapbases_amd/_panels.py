@@ -49,11 +49,25 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                       os.environ.get("ASB_PANEL_COOP", "1") != "0")
     global_all = n_rows <= cap
     spec_budget = 16 if (hasattr(eng, "panel_run_spec") and os.environ.get("ASB_SPEC_PANELS", "1") != "0") else 0
+    # first panel guessed from the energies without the constant-in-time direction (asb.h: asb_panel_guess_*): a collective
+    # decision -- every rank must be able to, and the share of that direction in |X|^2 over ALL shards must exceed 1/4
+    guess_ok = False
+    if spec_budget and not global_all and hasattr(eng, "panel_guess_stats") and os.environ.get("ASB_FIRST_PANEL_MEAN", "1") != "0":
+        me, nx, possible = eng.panel_guess_stats()
+        tot = comm.allreduce_sum([me, nx, 0.0 if possible else 1.0])
+        guess_ok = bool(tot[2] == 0 and tot[1] > 0 and tot[0] > 0.25 * tot[1])
+    guessing = False
     k, stalled, forced_next = 0, 0, -1
     while k < K:
+        if guessing:
+            eng.panel_guess_end()
+            guessing = False
         forced = forced_next if stalled >= 2 else -1
         take_all = forced >= 0 or global_all
         if not take_all:
+            if guess_ok and k == 0 and stalled == 0:
+                eng.panel_guess_begin(comm.world)
+                guessing = True
             for level in (1, 2):                         # local threshold: ~m_target of this rank's vertices above it
                 eng.panel_hist(level, None)
                 eng.panel_tau(level, None)
@@ -63,17 +77,21 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             if counts is None:                            # table too large for the selection kernel: same rule with torch
                 tab = top_all.view(comm.world, cap + 1)
                 exported = tab[:, :cap].reshape(-1)
-                kth = torch.topk(exported, m_target + 1).values[-1].clamp(min=0.0)
+                kth = torch.topk(exported, eng.panel_target() + 1).values[-1].clamp(min=0.0)
                 tau = torch.maximum(kth, tab[:, cap].max()).reshape(1).contiguous()
                 eng.panel_set_tau(tau.data_ptr())
                 counts = (tab[:, :cap] > tau).sum(dim=1).cpu().numpy().astype(np.int64)
-            packed = packed_ok and 0 < int(counts.sum()) <= cap
-            if packed:      # the ids go right behind this rank's maxc rows: rows and ids travel in ONE all-gather
+            packed = packed_ok and not guessing and 0 < int(counts.sum()) <= cap
+            if guessing:    # the union's size is not in the gathered energies: one more small exchange, first panel only
+                n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), -1, False)
+                info = comm.all_gather_ints([n_c, int(ov)])
+                counts = info[:, 0].copy()
+            elif packed:      # the ids go right behind this rank's maxc rows: rows and ids travel in ONE all-gather
                 maxc = int(counts.max())
                 eng.panel_select(k, rows_loc.data_ptr(), rows_loc.data_ptr() + 8 * maxc * rl, -1, False, want_counts=False)
             else:
                 eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), -1, False, want_counts=False)
-            overflow = False
+            overflow = bool(guessing and info[:, 1].any())
         else:
             packed = False
             n_c, ov = eng.panel_select(k, rows_loc.data_ptr(), idx_loc.data_ptr(), forced, True)
@@ -163,3 +181,5 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
         stalled = 0
         eng.panel_project(k, done)
         k += done
+    if guessing:
+        eng.panel_guess_end()

@@ -56,7 +56,8 @@ struct asb_ctx {
     // first panel uses to GUESS its later winners when that direction carries much of |X|^2 (mean_frac; rest shape "first")
     double* EV = nullptr;
     double* mean_part = nullptr;      // per-block partials of that energy
-    double mean_frac = 0.0;
+    double mean_frac = 0.0, mean_energy = 0.0, prep_normx2 = 0.0;     // share / energy along that direction, |X|^2 (host)
+    int64_t m_target_eff = 0;   // != 0 while a guessed panel is being selected: the (smaller) target of the energies proper
     int first_panel_mean = 1;   // ASB_FIRST_PANEL_MEAN=0: first panel from the initial energies alone
     const double* sel_e2 = nullptr;      // != NULL while a panel's candidates are { E > tau } u { sel_e2 > tau_v }
     bool e0_valid = false;

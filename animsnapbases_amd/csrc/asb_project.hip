@@ -1965,7 +1965,7 @@ extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
 extern "C" int asb_panel_tau(asb_ctx* ctx, int level, const int* hist_dev) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
     hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, hist_dev ? const_cast<int*>(hist_dev) : ctx->hist, ctx->scalar_dev, level,
-                       (long long)ctx->m_target, (long long)ctx->m_cap);
+                       (long long)(ctx->m_target_eff ? ctx->m_target_eff : ctx->m_target), (long long)ctx->m_cap);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
@@ -2195,7 +2195,7 @@ extern "C" int asb_panel_global_tau(asb_ctx* ctx, const double* tab_dev, int wor
     if (lds > 48 * 1024)
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_global_tau, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_global_tau, dim3(1), dim3(1024), lds, ctx->stream, tab_dev, world, (long long)cap,
-                       (long long)ctx->m_target + 1, ctx->scalar_dev, ctx->bam_idx);
+                       (long long)(ctx->m_target_eff ? ctx->m_target_eff : ctx->m_target) + 1, ctx->scalar_dev, ctx->bam_idx);
     ASB_CHECK_LAUNCH(ctx);
     long long h[16];
     if ((rc = fetch_words(ctx, ctx->bam_idx, world, h))) return rc;
@@ -2697,7 +2697,7 @@ extern "C" int asb_panel_set_coop(asb_ctx* ctx, int on) {
     return old;
 }
 extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_cap : 0; }
-extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? ctx->m_target : 0; }
+extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? (ctx->m_target_eff ? ctx->m_target_eff : ctx->m_target) : 0; }
 
 // single-rank driver: all K components with no host round trip inside a panel
 // Super-panel (ASB_SUPER_PANELS=1): up to three sub-panels of <= 16 greedy steps on the SAME candidate rows (the panel
@@ -2893,6 +2893,54 @@ static int panel_threshold(asb_ctx* ctx, const double* E, const double* E2, doub
     return ASB_OK;
 }
 
+// ---- guessed candidates of a first panel (see asb_project_run)
+static bool guess_possible(const asb_ctx* ctx) {
+    return ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop && ctx->Fp <= 2048 && ctx->EV && ctx->e0_valid &&
+           ctx->n_energy_pass == 0 && ctx->m_target >= 256 && ctx->n_loc > ctx->m_cap;
+}
+// thresholds of the scores EV + g (E - EV) into sc[SC_TAUG ..]: about mq[q] / world of this shard's vertices above each.
+// ~590 candidates on config 4 (the sets overlap), at most 830 + bin overshoot + the energies' own of the 1024 resident waves
+static int guess_thresholds(asb_ctx* ctx, int world) {
+    static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3};
+    static const int mq[ASB_NG] = {400, 140, 140, 90, 60};
+    int rc;
+    for (int q = 0; q < ASB_NG; ++q) {
+        long long m = mq[q] * ctx->m_target / 768 / world;
+        if (m < 8) m = 8;
+        if ((rc = panel_threshold(ctx, ctx->energy, ctx->EV, gq[q], m, m + m / 8))) return rc;
+        hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAUG + q, (int)SC_TAU);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+// multi-rank driver: what this shard contributes to the decision (the ranks sum both and compare), then begin / end
+// around the first panel: begin installs the score thresholds and the smaller target for the energies proper, which
+// asb_panel_tau / asb_panel_global_tau / asb_panel_target then use; asb_panel_select takes the union; the pass checks
+// against it; end restores the plain selection.
+extern "C" int asb_panel_guess_stats(asb_ctx* ctx, double* mean_energy_local, double* normx2_local, int* possible) {
+    if (!ctx || !mean_energy_local || !normx2_local || !possible) return ASB_ERR_ARG;
+    *possible = guess_possible(ctx) ? 1 : 0;
+    *mean_energy_local = *possible ? ctx->mean_energy : 0.0;
+    *normx2_local = *possible ? ctx->prep_normx2 : 0.0;
+    return ASB_OK;
+}
+extern "C" int asb_panel_guess_begin(asb_ctx* ctx, int world) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || world < 1) return ASB_ERR_ARG;
+    if (!guess_possible(ctx)) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_guess_begin: no energies without the constant direction");
+    int rc;
+    if ((rc = guess_thresholds(ctx, world))) return rc;
+    ctx->sel_e2 = ctx->EV;
+    ctx->m_target_eff = ctx->m_target / 12;
+    ctx->n_guess_panels++;
+    return ASB_OK;
+}
+extern "C" int asb_panel_guess_end(asb_ctx* ctx) {
+    if (!ctx) return ASB_ERR_ARG;
+    ctx->sel_e2 = nullptr;
+    ctx->m_target_eff = 0;
+    return ASB_OK;
+}
+
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
     long long k = k0;
@@ -2948,18 +2996,9 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
             // steps) united with the top vertices of that score for g on a geometric grid.  Nothing rests on the guess:
             // steps beyond the provable ones are unproven steps, checked by the pass against every vertex outside the
             // candidate set like any others.
-            const bool guess = k == 0 && stalled == 0 && ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop &&
-                               ctx->Fp <= 2048 && ctx->EV && ctx->e0_valid && ctx->n_energy_pass == 0 && ctx->mean_frac > 0.25 &&
-                               ctx->m_target >= 256;
+            const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
             if (guess) {
-                // ~590 candidates on config 4 (the sets overlap), at most 894 + bin overshoot of the 1024 resident waves
-                static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3};
-                static const int mq[ASB_NG] = {400, 140, 140, 90, 60};
-                for (int q = 0; q < ASB_NG; ++q) {
-                    const long long m = mq[q] * ctx->m_target / 768;
-                    if ((rc = panel_threshold(ctx, ctx->energy, ctx->EV, gq[q], m, m + m / 8))) return rc;
-                    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAUG + q, (int)SC_TAU);
-                }
+                if ((rc = guess_thresholds(ctx, 1))) return rc;
                 const long long me = ctx->m_target / 12;
                 if ((rc = panel_threshold(ctx, ctx->energy, nullptr, 0.0, me, me + me / 2))) return rc;
                 ctx->sel_e2 = ctx->EV;

@@ -553,6 +553,8 @@ extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     ASB_HIP(ctx, hipMemcpyAsync(h, ctx->e0_sc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->mean_frac = h[0] > 0.0 ? h[2] / h[0] : 0.0;
+    ctx->mean_energy = h[2];
+    ctx->prep_normx2 = h[0];
     return ASB_OK;
 }
 

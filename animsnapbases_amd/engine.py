@@ -196,6 +196,17 @@ class HipEngine(object):
         self._ck(self.lib.asb_panel_scale(self.h, ctypes.byref(a), ctypes.byref(b), float(set_e0max)))
         return a.value, b.value
 
+    def panel_guess_stats(self):
+        a, b, ok = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self.lib.asb_panel_guess_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ok)))
+        return a.value, b.value, bool(ok.value)
+
+    def panel_guess_begin(self, world):
+        self._ck(self.lib.asb_panel_guess_begin(self.h, int(world)))
+
+    def panel_guess_end(self):
+        self._ck(self.lib.asb_panel_guess_end(self.h))
+
     def panel_hist(self, level, hist_ptr=None):
         self._ck(self.lib.asb_panel_hist(self.h, int(level), ctypes.c_void_p(hist_ptr) if hist_ptr else None))
 

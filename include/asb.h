@@ -215,6 +215,17 @@ int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
  * like any others (asb_deflate_spec_stats), so the sequence is still that of posComponents.py:75-77.  *n = 1 if the last
  * run did so.  ASB_FIRST_PANEL_MEAN=0 switches it off. */
 int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
+/* The same for the multi-rank driver (animsnapbases_amd/_panels.py).  asb_panel_guess_stats: this shard's energy along the
+ * constant direction, its |X|^2 and whether the context could guess at all (0: both values are 0); the ranks sum all three
+ * and guess only if every rank can and the share exceeds 1/4.  asb_panel_guess_begin (before the first panel's
+ * asb_panel_hist): installs the score thresholds (each rank its share 1/world of the targets) and a smaller target for the
+ * energies proper, which asb_panel_tau / asb_panel_global_tau / asb_panel_target then use; asb_panel_select takes the
+ * union (the counts returned by asb_panel_global_tau do not include it: ask asb_panel_select for them);
+ * asb_panel_project_spec* check against the same union.  asb_panel_guess_end (after that panel, whatever its outcome)
+ * restores the plain selection. */
+int asb_panel_guess_stats(asb_ctx* ctx, double* mean_energy_local, double* normx2_local, int* possible);
+int asb_panel_guess_begin(asb_ctx* ctx, int world);
+int asb_panel_guess_end(asb_ctx* ctx);
 /* Multi-rank runs (assembled candidate buffer): a timed-out exchange is NOT redone locally -- the ranks must stay in
  * lock-step -- asb_panel_run / asb_panel_run_spec then return *committed = -1 with the kernel switched off for this context;
  * the driver min-reduces that over the ranks, switches it off everywhere (asb_panel_set_coop, returns the old setting) and

@@ -129,6 +129,7 @@ def test_panel_kernel_shares_the_gpu_with_other_contexts():
         comps, weigs = align_signs(comps, weigs, d["comps"])
         assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
         assert st["coop_fallbacks"] in (0, 1)
+        assert st["guessed_panels"] == 1            # rest shape "first" on noise: the first panel's candidates are guessed
     for o in outs[1:]:
         assert np.array_equal(o[2], outs[0][2])
 
@@ -197,3 +198,38 @@ def test_first_panel_guessed_from_the_energies_without_the_constant_direction(sh
     assert snaps._engine.deflate_stats()["guessed_panels"] == 0
     da = orc.extract_k_components(orc.prepare_snapshots(verts, "average", True)["snapTensor"], K)
     _check(compa, da)
+
+
+def test_multirank_first_panel_guess_is_a_collective_decision(monkeypatch):
+    """Two shards through the multi-rank protocol with and without the guessed first panel: the decision is taken on
+    all-reduced sums, each rank contributes its share of the guessed candidates, the pass checks them on every shard --
+    same oracle sequence, same weights on both ranks, no more panels than without."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(71)
+    verts, K = rng.uniform(-1, 1, size=(200, 24000, 3)), 40
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(_param(K), snaps)
+            comp.deflate_mode = "project"
+            comp.compute_components_store_singvalues()
+        return comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), snaps._engine.deflate_stats()
+
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("ASB_FIRST_PANEL_MEAN", on)
+        outs = run_ranks(2, rank_fn)
+        for idx, comps, weigs, st in outs:
+            assert idx.tolist() == d["idx"].tolist()
+            comps, weigs = align_signs(comps, weigs, d["comps"])
+            assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+            assert st["guessed_panels"] == int(on)
+        assert np.array_equal(outs[0][2], outs[1][2])
+        res[on] = outs[0][3]["panels"]
+    assert res["1"] <= res["0"]
