@@ -145,8 +145,9 @@ struct asb_ctx {
     int* hist = nullptr;
     PanelState* pstate = nullptr;
     PanelState* pstate2 = nullptr;         // double panels: the first sub-panel's state, kept for its check after the pass
-    int double_panels = 0;                 // ASB_DOUBLE_PANELS=1 (experimental)
-    int dbl_budget = 12;                   // steps given to the second sub-panel (adapted to what the last ones kept)
+    int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
+    double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
+    int dbl_budget = 16;                   // steps given to the second sub-panel (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)

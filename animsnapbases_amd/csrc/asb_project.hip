@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                                                  const long long* __restrict__ vmap = nullptr,
                                                  const PanelState* __restrict__ bstate = nullptr, long long v0 = 0,
                                                  PanelState* __restrict__ spec = nullptr, const double* __restrict__ sc = nullptr,
-                                                 const double* __restrict__ E2 = nullptr) {
+                                                 const double* __restrict__ E2 = nullptr, const double* __restrict__ Ecl = nullptr) {
     if (vmap != nullptr) n_vert = bstate->n_cand;
     __shared__ int sh_viol[4];
     int viol = ASB_PANEL_COLS;
@@ -523,8 +523,10 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
         if (SPEC) {
             if (valid) {
                 double e = E[vi];
-                // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds)
-                const bool outside = !(e > sp_tau) && !(E2 && in_guess(e, E2[vi], sc));
+                // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds) -- E as it
+                // was when the candidates were chosen (Ecl: a later tile of a double panel sees updated energies in E)
+                const double es = Ecl ? Ecl[vi] : e;
+                const bool outside = !(es > sp_tau) && !(E2 && in_guess(es, E2[vi], sc));
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     if (t < ncols) {
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                                                       double* __restrict__ pmax, long long* __restrict__ pidx,
                                                       double* __restrict__ psum, double* __restrict__ colpart,
                                                       PanelState* __restrict__ spec, const double* __restrict__ sc,
-                                                      const double* __restrict__ E2 = nullptr) {
+                                                      const double* __restrict__ E2 = nullptr, const double* __restrict__ Ecl = nullptr) {
     __shared__ double qs[16 * 192];
     const int tid = threadIdx.x;
     const long long n_rows = 3 * n_vert;
@@ -649,8 +651,10 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
             if (v < n_vert) {
                 double e = E[v];
                 if (SPEC) {
-                    // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds)
-                    const bool outside = !(e > sc[SC_TAU]) && !(E2 && in_guess(e, E2[v], sc));
+                    // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds) -- E as
+                    // it was when the candidates were chosen (Ecl: a later tile of a double panel sees updated energies)
+                    const double es = Ecl ? Ecl[v] : e;
+                    const bool outside = !(es > sc[SC_TAU]) && !(E2 && in_guess(es, E2[v], sc));
                     const double margin = spec->margin;
                     const int proven = (int)spec->proven;
 #pragma unroll
@@ -1066,8 +1070,8 @@ __global__ __launch_bounds__(512) void k_project_l2(
 // drains for that long at the end of every launch with fewer and fewer loads in flight; S waves per tile cut that tail
 // S times while the bytes in flight per CU stay the same.  The quad also reads S * G * 128 B contiguous bytes of a row at
 // a time instead of G * 128.
-template <int NT, int G, int S, int NQ>
-__global__ __launch_bounds__(64 * S * NQ) void k_project_l2s(
+template <int NT, int G, int S, int NQ, int OCC = 1>
+__global__ __launch_bounds__(64 * S * NQ, OCC) void k_project_l2s(
     const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
     int ncols, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
     // NQ tiles in flight per block (NQ * S waves): NQ = 1 keeps the barriers inside the group of waves that shares a tile
@@ -1253,6 +1257,149 @@ __global__ __launch_bounds__(512) void k_project_wide(
                         }
                     }
             }
+    }
+}
+
+// k_project_l2w: the NCT-tile product with S waves per row tile (k_project_l2s's split: wave `sub` takes every S-th group of
+// G frame chunks, partial accumulators summed through LDS in a fixed order) and BOTH operands of the next group in flight
+// while the current group's 4 * NT * NCT * G MFMAs issue.  k_project_wide gives a whole 64-row tile to one wave -- 125 chunks
+// x 32 MFMAs x 64 cycles with two waves per SIMD = 210 us per tile, 2.3 tiles per wave on config 4: a third of the launch
+// is the queue draining -- and fetches its L2 operand right in front of the MFMAs that need it.
+template <int NT, int G, int S, int NCT, int OCC = 1, int PD = 1>
+__global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
+    __shared__ double red[S - 1][NT][NCT][4][64];
+    __shared__ unsigned int tile_sh;
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4, sub = threadIdx.x >> 6;
+    constexpr int TR = 16 * NT;
+    const long long ntiles = (rows + TR - 1) / TR;
+    const int nchunk = Fp / 16;
+    const double4* wq[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) wq[ct] = reinterpret_cast<const double4*>(Wq + (long long)ct * Fp * 16) + (g * 16 + i);
+    for (;;) {
+        if (threadIdx.x == 0) tile_sh = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int t = tile_sh;
+        if ((long long)t >= ntiles) break;                      // the same for every wave of the block
+        d4 acc[NT][NCT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            long long r = (long long)t * TR + 16 * m + i;
+            if (r >= rows) r = rows - 1;
+            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+        }
+        double4 a[NT][G], an[NT][G], b[NCT][G], bn[NCT][G];
+        int gi = sub;                                           // group gi = chunks gi * G .. gi * G + G - 1
+#define ASB_L2W_LOAD_A(DST, GRP)                                                                       \
+    _Pragma("unroll") for (int q = 0; q < G; ++q) {                                                   \
+        const int c = (GRP) * G + q < nchunk ? (GRP) * G + q : nchunk - 1;                             \
+        _Pragma("unroll") for (int m = 0; m < NT; ++m) DST[m][q] = xp[m][4 * c];                       \
+    }
+#define ASB_L2W_LOAD_B(DST, GRP)                                                                       \
+    _Pragma("unroll") for (int q = 0; q < G; ++q) {                                                   \
+        const int c = (GRP) * G + q < nchunk ? (GRP) * G + q : nchunk - 1;                             \
+        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) DST[ct][q] = wq[ct][64 * c];                \
+    }
+#define ASB_L2W_MFMA(GRP)                                                                              \
+    _Pragma("unroll") for (int q = 0; q < G; ++q)                                                     \
+        if ((GRP) * G + q < nchunk) {                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                      \
+                _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
+                    acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].x, b[ct][q].x, acc[m][ct], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
+                    acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].y, b[ct][q].y, acc[m][ct], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
+                    acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].z, b[ct][q].z, acc[m][ct], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
+                    acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].w, b[ct][q].w, acc[m][ct], 0, 0, 0); \
+            }                                                                                          \
+        }
+        if (PD == 2) {
+            // the HBM operand two groups ahead, the L2 operand one: 2 * NT * G * 2 KB in flight per wave
+            double4 a2[NT][G];
+            if (gi * G < nchunk) {
+                ASB_L2W_LOAD_B(b, gi)
+                ASB_L2W_LOAD_A(a, gi)
+                if ((gi + S) * G < nchunk) { ASB_L2W_LOAD_A(an, gi + S) }
+            }
+            while (gi * G < nchunk) {
+                // B first: loads retire in order, and this group's MFMAs wait for the B issued one iteration ago -- anything
+                // issued in front of it (an A two groups ahead) would have to have landed as well
+                if ((gi + S) * G < nchunk) { ASB_L2W_LOAD_B(bn, gi + S) }
+                if ((gi + 2 * S) * G < nchunk) { ASB_L2W_LOAD_A(a2, gi + 2 * S) }
+                ASB_L2W_MFMA(gi)
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) b[ct][q] = bn[ct][q];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) { a[m][q] = an[m][q]; an[m][q] = a2[m][q]; }
+                }
+                gi += S;
+            }
+        } else {
+            if (gi * G < nchunk) {
+                ASB_L2W_LOAD_B(b, gi)
+                ASB_L2W_LOAD_A(a, gi)
+            }
+            while (gi * G < nchunk) {
+                const int gn = gi + S;
+                if (gn * G < nchunk) {
+                    ASB_L2W_LOAD_B(bn, gn)
+                    ASB_L2W_LOAD_A(an, gn)
+                }
+                ASB_L2W_MFMA(gi)
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) b[ct][q] = bn[ct][q];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
+                }
+                gi = gn;
+            }
+        }
+#undef ASB_L2W_LOAD_A
+#undef ASB_L2W_LOAD_B
+#undef ASB_L2W_MFMA
+        if (sub > 0) {
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[sub - 1][m][ct][q][l] = acc[m][ct][q];
+        }
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < S - 1; ++s2)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[m][ct][q] += red[s2][m][ct][q][l];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                if (i < wa.nc[ct]) {
+                    const double inv = wn2[16 * ct + i];
+                    double* dst = comps + (wa.kb[ct] + i) * comp_stride + (long long)t * TR + g;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if ((long long)t * TR + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = acc[m][ct][q] / inv;
+                }
+        }
+        // the next iteration's first barrier (tile id) also orders these reads of `red` before its next writes
     }
 }
 
@@ -1549,6 +1696,97 @@ static int band_pass(asb_ctx* ctx, long long kb, int nc) {
     return wide_correct_tile(ctx, 0, kb, nc, true);
 }
 
+// the multi-tile projection kernel (bracketed by the profiling events); tiles built by wide_build_tile
+template <int NCT>
+static void launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 63) / 64;
+    if (variant == 10)         // two waves per SIMD, HBM operand two chunks ahead
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT, 2, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 11)    // the same, four waves per tile
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT, 2, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 13) {  // 48-row tiles, two waves per SIMD, HBM operand two chunks ahead
+        const long long nt3 = (rows + 47) / 48;
+        hipLaunchKernelGGL((k_project_l2w<3, 1, 2, NCT, 2, 2>), dim3((unsigned)(nt3 < 4 * ctx->n_cu ? nt3 : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 14) {  // the same, three waves per SIMD
+        const long long nt3 = (rows + 47) / 48;
+        hipLaunchKernelGGL((k_project_l2w<3, 1, 2, NCT, 3, 2>), dim3((unsigned)(nt3 < 6 * ctx->n_cu ? nt3 : 6 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 15) {  // 32-row tiles, two chunks per group, two waves per SIMD
+        const long long nt2 = (rows + 31) / 32;
+        hipLaunchKernelGGL((k_project_l2w<2, 2, 2, NCT, 2, 1>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 16) {  // 32-row tiles, three chunks per group
+        const long long nt2 = (rows + 31) / 32;
+        hipLaunchKernelGGL((k_project_l2w<2, 3, 2, NCT, 2, 1>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 12)    // one wave per SIMD, two chunks per group, HBM operand two groups ahead
+        hipLaunchKernelGGL((k_project_l2w<4, 2, 2, NCT, 1, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 6) {        // 32-row tiles, two chunks in flight, three waves per SIMD
+        const long long nt2 = (rows + 31) / 32;
+        hipLaunchKernelGGL((k_project_l2w<2, 2, 2, NCT, 3>), dim3((unsigned)(nt2 < 6 * ctx->n_cu ? nt2 : 6 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 7) {
+        const long long nt2 = (rows + 31) / 32;
+        hipLaunchKernelGGL((k_project_l2w<2, 2, 4, NCT, 3>), dim3((unsigned)(nt2 < 3 * ctx->n_cu ? nt2 : 3 * ctx->n_cu)), dim3(256), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 8) {  // 48-row tiles, two chunks in flight, two waves per SIMD
+        const long long nt3 = (rows + 47) / 48;
+        hipLaunchKernelGGL((k_project_l2w<3, 2, 2, NCT, 2>), dim3((unsigned)(nt3 < 4 * ctx->n_cu ? nt3 : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 9) {  // 32-row tiles, four chunks in flight, two waves per SIMD
+        const long long nt2 = (rows + 31) / 32;
+        hipLaunchKernelGGL((k_project_l2w<2, 4, 2, NCT, 2>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    } else if (variant == 4)          // two waves per SIMD
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 5)
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 2)
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else if (variant == 3)
+        hipLaunchKernelGGL((k_project_l2w<4, 2, 2, NCT>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    else
+        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
+                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+}
+static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc;
+    static const int variant = getenv("ASB_WIDE_VARIANT") ? atoi(getenv("ASB_WIDE_VARIANT")) : 4;
+    size_t slot;
+    int rc;
+    if ((rc = prof_begin(ctx, slot))) return rc;
+    if (variant == 0) {
+        if (ntile == 1)
+            hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+        else if (ntile == 2)
+            hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+        else
+            hipLaunchKernelGGL((k_project_wide<4, 1, 3, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
+    } else if (ntile == 1) {          // one tile: the single-panel kernel on the tile's operands
+        const long long ntiles = (rows + 63) / 64;
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream,
+                           ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa.nc[0], ctx->comps + (size_t)wa.kb[0] * rows, rows, ctx->tile_counter);
+    } else if (ntile == 2) {
+        launch_l2w<2>(ctx, variant, wa);
+    } else {
+        launch_l2w<3>(ctx, variant, wa);
+    }
+    if ((rc = prof_end(ctx, slot))) return rc;
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 // ONE pass over X for up to three sub-panels
 static int project_pass_wide(asb_ctx* ctx, int ntile, const long long* kb, const int* nc) {
     WideArgs wa{{0, 0, 0}, {0, 0, 0}};
@@ -1558,21 +1796,8 @@ static int project_pass_wide(asb_ctx* ctx, int ntile, const long long* kb, const
         wa.nc[ct] = nc[ct];
     }
     ASB_CHECK_LAUNCH(ctx);
-    const long long rows = 3 * ctx->n_loc;
-    size_t slot;
     int rc;
-    if ((rc = prof_begin(ctx, slot))) return rc;
-    if (ntile == 1)
-        hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    else if (ntile == 2)
-        hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    else
-        hipLaunchKernelGGL((k_project_wide<4, 1, 3, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    if ((rc = prof_end(ctx, slot))) return rc;
-    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = launch_wide(ctx, ntile, wa))) return rc;
     for (int ct = 0; ct < ntile; ++ct)
         if ((rc = wide_correct_tile(ctx, ct, kb[ct], nc[ct], false))) return rc;
     return ASB_OK;
@@ -1630,6 +1855,9 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else if (variant == 4)      // default: two waves (one 128-thread block) per 64-row tile
         hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
+    else if (variant == 6)      // the same compiled for two waves per SIMD (<= 256 registers)
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else if (variant == 5)      // four waves per tile: loses at the barriers what it gains at the end of the launch
         hipLaunchKernelGGL((k_project_l2s<4, 2, 4, 1>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
@@ -2521,8 +2749,8 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
             // an RCCL kernel or a second context holds part of the GPU.  Every block has left through the abort flag (the
             // stream is idle again); what the dead launch wrote (W / scal rows from k0 on, the panel state) is rewritten by
             // the two-kernel loop, which needs no co-residency.  The context stays on that loop from now on.
-            if (ctx->run_writeback)     // super / double panels only (opt-in): the candidate rows were deflated in place
-                ASB_FAIL(ctx, ASB_ERR_NUMERIC, "panel kernel: the record exchange timed out while the rows were updated in place");
+            // (Double / super panels let the kernel write the deflated rows back for the next sub-panel: it does so only
+            // behind its last step, past every abort exit, so a launch that timed out has left the rows as it found them.)
             ctx->panel_coop = 0;
             ctx->coop_test_stall = 0;
             ctx->n_coop_fallbacks++;
@@ -2775,12 +3003,12 @@ static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelSta
         long long cwr = (ctx->n_loc + 63) / 64;
         hipLaunchKernelGGL(k_correct_rows<true>, dim3((unsigned)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap)), dim3(192), 0, ctx->stream,
                            ctx->comps, (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)kb, nc, ctx->gram_s, ctx->wn2t3 + 16 * ct,
-                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev);
+                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev, ctx->sel_e2, ctx->e_class);
     } else
     hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                        (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
                        ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0, st,
-                       ctx->scalar_dev);
+                       ctx->scalar_dev, ctx->sel_e2, ctx->e_class);
     hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                        (long long)ctx->n_loc, (int)kb, st, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
                        ctx->colpart, -1);
@@ -2794,6 +3022,7 @@ static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelSta
     return ASB_OK;
 }
 
+static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
 static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
     int rc;
     *done_out = 0;
@@ -2802,11 +3031,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)48))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)1))) return rc;
-    for (int level = 1; level <= 2; ++level) {
-        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
-        if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
-    }
-    if ((rc = asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
+    if ((rc = panel_candidates(ctx, k, 0))) return rc;
+    // who is a candidate is decided by the energies NOW; the second tile's check runs after the first tile's update
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     long long kb[2] = {k, k + ASB_PANEL_COLS};
     int nc[2] = {0, 0}, proven[2] = {0, 0};
     int64_t ran = 0;
@@ -2849,17 +3077,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         wa.nc[ct] = nc[ct];
     }
     ASB_CHECK_LAUNCH(ctx);
-    const long long rows = 3 * ctx->n_loc;
-    size_t slot;
-    if ((rc = prof_begin(ctx, slot))) return rc;
-    if (ntile == 1)
-        hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    else
-        hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                           ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    if ((rc = prof_end(ctx, slot))) return rc;
-    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = launch_wide(ctx, ntile, wa))) return rc;
     int64_t total = 0;
     for (int ct = 0; ct < ntile; ++ct) {
         int64_t kept = 0;
@@ -2941,6 +3159,34 @@ extern "C" int asb_panel_guess_end(asb_ctx* ctx) {
     return ASB_OK;
 }
 
+// candidate selection of the single-rank drivers: threshold + compaction + exact rows.
+// First panel of a tensor whose energy sits largely in the constant-in-time direction (rest shape "first": every row
+// carries its own offset): the first components remove that direction from EVERY vertex, after which the initial energies
+// say nothing about who wins next, and a panel chosen by them alone ends after ~3 steps (config 4).  EV -- the energy
+// without that direction, a by-product of the standardisation sweep -- is a good GUESS of the later ranking; the components
+// do not remove the constant direction at once but leave a falling share g of it behind (0.1, 0.05, 0.04, 0.03 ... on
+// config 4), so the ranking that matters at step t is that of EV + g_t (E - EV) with g_t unknown beforehand.  The
+// candidates are { E > tau_E } (few: the provable first steps) united with the top vertices of that score for g on a
+// geometric grid.  Nothing rests on the guess: steps beyond the provable ones are unproven steps, checked by the pass
+// against every vertex outside the candidate set like any others.
+static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
+    int rc;
+    const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
+    if (guess) {
+        if ((rc = guess_thresholds(ctx, 1))) return rc;
+        const long long me = ctx->m_target / 12;
+        if ((rc = panel_threshold(ctx, ctx->energy, nullptr, 0.0, me, me + me / 2))) return rc;
+        ctx->sel_e2 = ctx->EV;
+        ctx->n_guess_panels++;
+    } else {
+        for (int level = 1; level <= 2; ++level) {
+            if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
+            if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
+        }
+    }
+    return asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
     long long k = k0;
@@ -2986,31 +3232,9 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
             forced = ctx->v0 + li;
             (void)be;
         } else if (!global_all) {
-            // First panel of a tensor whose energy sits largely in the constant-in-time direction (rest shape "first":
-            // every row carries its own offset): the first components remove that direction from EVERY vertex, after which
-            // the initial energies say nothing about who wins next, and a panel chosen by them alone ends after ~3 steps
-            // (config 4).  EV -- the energy without that direction, a by-product of the standardisation sweep -- is a good
-            // GUESS of the later ranking; the components do not remove the constant direction at once but leave a falling
-            // share g of it behind (0.1, 0.05, 0.04, 0.03 ... on config 4), so the ranking that matters at step t is that
-            // of EV + g_t (E - EV) with g_t unknown beforehand.  The candidates are { E > tau_E } (few: the provable first
-            // steps) united with the top vertices of that score for g on a geometric grid.  Nothing rests on the guess:
-            // steps beyond the provable ones are unproven steps, checked by the pass against every vertex outside the
-            // candidate set like any others.
-            const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
-            if (guess) {
-                if ((rc = guess_thresholds(ctx, 1))) return rc;
-                const long long me = ctx->m_target / 12;
-                if ((rc = panel_threshold(ctx, ctx->energy, nullptr, 0.0, me, me + me / 2))) return rc;
-                ctx->sel_e2 = ctx->EV;
-                ctx->n_guess_panels++;
-            } else {
-                for (int level = 1; level <= 2; ++level) {
-                    if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
-                    if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
-                }
-            }
-        }
-        if ((rc = asb_panel_select(ctx, k, forced, forced >= 0 ? 1 : global_all, nullptr, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = panel_candidates(ctx, k, stalled))) return rc;
+        } else if ((rc = asb_panel_select(ctx, k, forced, 1, nullptr, nullptr, nullptr, nullptr))) return rc;
+        if (forced >= 0 && (rc = asb_panel_select(ctx, k, forced, 1, nullptr, nullptr, nullptr, nullptr))) return rc;
         const int steps = forced >= 0 ? 1 : (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
         int64_t done = 0;
         // unproven steps only on the plain path: a stalled panel is repeated with provable steps alone

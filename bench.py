@@ -348,7 +348,11 @@ def main():
         # this build at this shape (tools/summarise_pmc.py), an OFFLINE measurement committed under profiles/ -- counters
         # cannot be read from inside the run
         traffic, traffic_src = None, None
-        kname = {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
+        # single rank, default settings: two 16-column sub-panels per read of X (k_project_l2w); the multi-rank protocol and
+        # ASB_DOUBLE_PANELS=0 read X once per 16-column panel (k_project_l2s)
+        wide = (mode == "project" and pk == 3 and world == 1 and not forced and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0"
+                and os.environ.get("ASB_WIDE_VARIANT", "4") == "4")
+        kname = "k_project_l2w<4, 1, 2, 2, 2, 1>" if wide else {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
         try:
             pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
             if mode == "project" and kname in pm["kernels"] and (N, F, world) == (100000, 2000, 1) and \
@@ -372,9 +376,17 @@ def main():
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ({2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
-                                    " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep
+                         "kernel": (("k_project_l2w<4,1,2,2,2,1> (f64-MFMA projection on two 16-column sub-panels, 1 launch = one "
+                                     "read of X per 32 components)" if wide else
+                                     {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
+                                     " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep)
                                     if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
+                         # the same launches against the f64 MFMA peak: 2 * rows * F flops per component column
+                         "mfma": ({"achieved": 2.0 * 3 * n_loc * F * K * args.steps / launches / (avg_ms * 1e-3) / 1e12,
+                                   "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": 2.0 * 3 * n_loc * F * K * args.steps / launches / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                   "note": "HBM time at peak (0.60 ms) exceeds MFMA time at peak (0.49 ms for 32 columns): "
+                                           "bound stays hbm"} if (mode == "project" and launches) else None),
                          "algorithm": mode, "panels_per_step": stats["panels"],
                          "refreshes": stats["refreshes"], "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
