@@ -55,6 +55,9 @@ struct asb_ctx {
     // EV[v] = E0[v] - sum_d (sum_f X[v,d,f])^2 / F: the energy left once the constant-in-time direction is gone -- what the
     // first panel uses to GUESS its later winners when that direction carries much of |X|^2 (mean_frac; rest shape "first")
     double* EV = nullptr;
+    int* hist6 = nullptr;             // histograms / range blocks of the scores of a guessed selection
+    double* scm = nullptr;
+    bool hist6_clear = false;
     double* mean_part = nullptr;      // per-block partials of that energy
     double mean_frac = 0.0, mean_energy = 0.0, prep_normx2 = 0.0;     // share / energy along that direction, |X|^2 (host)
     int64_t m_target_eff = 0;   // != 0 while a guessed panel is being selected: the (smaller) target of the energies proper
@@ -147,7 +150,11 @@ struct asb_ctx {
     PanelState* pstate2 = nullptr;         // double panels: the first sub-panel's state, kept for its check after the pass
     int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
-    int dbl_budget = 16;                   // steps given to the second sub-panel (adapted to what the last ones kept)
+    int sub_panels = 3;                    // most sub-panels per read of X with double_panels (ASB_SUB_PANELS, 1..8; from 4 on
+                                           // the projection kernel needs more than 256 registers and loses what the saved read gains)
+    int sub_first = 3;                     // sub-panels of the first read (ASB_SUB_FIRST); then adapted: sub_cur
+    int sub_cur = 0;
+    int sub_budget[8] = {16, 16, 16, 16, 16, 16, 16, 16};      // steps given to the later sub-panels (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)

@@ -199,15 +199,14 @@ __global__ void k_range_restore(double* __restrict__ sc, const double* __restric
 // covers the whole dynamic range of the energies (they fall by 1e8 on low-rank data);
 // level 2: linear bins inside the crossing binade [lo, hi).
 __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long long n, const double* __restrict__ sc,
-                                              int* __restrict__ hist, int by_exponent, const double* __restrict__ E2 = nullptr,
-                                              double g = 0.0) {
+                                              int* __restrict__ hist, int by_exponent) {
     __shared__ int lh[ASB_NBINS];
     for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const double lo = sc[SC_LO], hi = sc[SC_HI];
     const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const double e = E2 ? E2[i] + g * (E[i] - E2[i]) : E[i];       // a guessed selection's score
+        const double e = E[i];
         int b;
         if (by_exponent) {
             if (!(e >= 0.0)) continue;
@@ -226,10 +225,8 @@ __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ E, long
 
 // level 1: find the bin where the count from the top reaches m_target -> next range.
 // level 2: final tau (lower edge of the crossing bin; upper edge if that overflows m_cap).
-__global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __restrict__ sc, int level,
-                                             long long m_target, long long m_cap) {
-    __shared__ int lh[ASB_NBINS];
-    __shared__ int seg[256];
+__device__ __forceinline__ void tau_body(int* __restrict__ hist, double* __restrict__ sc, int level, long long m_target,
+                                         long long m_cap, int* lh, int* seg) {
     constexpr int PER = ASB_NBINS / 256;
     int ssum = 0;
     for (int q = 0; q < PER; ++q) {
@@ -280,6 +277,55 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
         if (acc + lh[b] > m_cap && acc > 0) tau = edge_hi;
         sc[SC_TAU] = nextafter(tau, -1.0e300);      // strict '>' in the compaction keeps e == edge
     }
+}
+
+__global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __restrict__ sc, int level,
+                                             long long m_target, long long m_cap) {
+    __shared__ int lh[ASB_NBINS];
+    __shared__ int seg[256];
+    tau_body(hist, sc, level, m_target, m_cap, lh, seg);
+}
+
+// ---- the thresholds of a guessed selection in one go: ASB_NG + 1 scores EV + g (E - EV) (the last one, g = 1, is the
+// energy itself), each with its own histogram, range block scm[q * 8 ..] (slots as in sc) and target; block q of k_tau_multi
+// is k_tau for score q, and at level 2 it leaves the threshold where the compaction looks for it
+struct GuessTargets { double g[ASB_NG + 1]; long long m_target[ASB_NG + 1], m_cap[ASB_NG + 1]; };
+__global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E, const double* __restrict__ EV, long long n,
+                                                    const double* __restrict__ scm, int* __restrict__ hist, int by_exponent,
+                                                    GuessTargets gt, int nq) {
+    // one score at a time through the same LDS histogram: E / EV are re-read from cache, LDS holds 8 KB
+    __shared__ int lh[ASB_NBINS];
+    for (int q = 0; q < nq; ++q) {
+        for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
+        __syncthreads();
+        const double lo = scm[q * 8 + SC_LO], hi = scm[q * 8 + SC_HI], g = gt.g[q];
+        const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const double ev = EV[i], e = ev + g * (E[i] - ev);
+            int b;
+            if (by_exponent) {
+                if (!(e >= 0.0)) continue;
+                b = (int)((__double_as_longlong(e) >> 52) & 0x7FF);
+            } else {
+                if (e < lo || e >= hi) continue;
+                b = (int)((e - lo) * scale);
+                if (b > ASB_NBINS - 1) b = ASB_NBINS - 1;
+            }
+            atomicAdd(&lh[b], 1);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x)
+            if (lh[i]) atomicAdd(&hist[q * ASB_NBINS + i], lh[i]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_tau_multi(int* __restrict__ hist, double* __restrict__ scm, double* __restrict__ sc, int level,
+                                                   GuessTargets gt) {
+    __shared__ int lh[ASB_NBINS];
+    __shared__ int seg[256];
+    const int q = blockIdx.x;
+    tau_body(hist + q * ASB_NBINS, scm + q * 8, level, gt.m_target[q], gt.m_cap[q], lh, seg);
+    if (level == 2 && threadIdx.x == 0) sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
 }
 
 // ordered compaction, two stages: cand_idx = global ids of { v : E[v] > tau } in increasing
@@ -1176,7 +1222,8 @@ __global__ __launch_bounds__(64 * S * NQ, OCC) void k_project_l2s(
 // ct writes its columns i < nc[ct] to component rows kb[ct] + i.  MAP: the rows are those of the vertices vmap[.]
 // (the band of a super-panel) instead of all of the shard's.
 // --------------------------------------------------------------------------------------
-struct WideArgs { long long kb[3]; int nc[3]; };
+#define ASB_MAX_SUB 8          // sub-panels (16-column tiles) per read of X
+struct WideArgs { long long kb[ASB_MAX_SUB]; int nc[ASB_MAX_SUB]; };
 template <int NT, int G, int NCT, bool MAP>
 __global__ __launch_bounds__(512) void k_project_wide(
     const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
@@ -1265,12 +1312,14 @@ __global__ __launch_bounds__(512) void k_project_wide(
 // while the current group's 4 * NT * NCT * G MFMAs issue.  k_project_wide gives a whole 64-row tile to one wave -- 125 chunks
 // x 32 MFMAs x 64 cycles with two waves per SIMD = 210 us per tile, 2.3 tiles per wave on config 4: a third of the launch
 // is the queue draining -- and fetches its L2 operand right in front of the MFMAs that need it.
-template <int NT, int G, int S, int NCT, int OCC = 1, int PD = 1>
+template <int NT, int G, int S, int NCT, int OCC = 1, int PD = 1, int MODE = 0>      // MODE != 0: timing probes (asb_test_l2w_probe)
 __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
     const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
     WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
-    __shared__ double red[S - 1][NT][NCT][4][64];
-    __shared__ unsigned int tile_sh;
+    extern __shared__ double l2w_lds[];                        // (S - 1) * NT * NCT * 4 * 64 doubles (64 KB for 8 tiles) + the tile id
+    typedef double (*red_t)[NT][NCT][4][64];
+    red_t red = reinterpret_cast<red_t>(l2w_lds);
+    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2w_lds + (size_t)(S - 1) * NT * NCT * 4 * 64);
     const int l = threadIdx.x & 63, i = l & 15, g = l >> 4, sub = threadIdx.x >> 6;
     constexpr int TR = 16 * NT;
     const long long ntiles = (rows + TR - 1) / TR;
@@ -1291,7 +1340,7 @@ __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
         const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
-            long long r = (long long)t * TR + 16 * m + i;
+            long long r = (long long)(MODE == 1 ? t % 4 : t) * TR + 16 * m + i;      // probe 1: four cache-resident tiles
             if (r >= rows) r = rows - 1;
             xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
         }
@@ -1309,7 +1358,11 @@ __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
     }
 #define ASB_L2W_MFMA(GRP)                                                                              \
     _Pragma("unroll") for (int q = 0; q < G; ++q)                                                     \
-        if ((GRP) * G + q < nchunk) {                                                                  \
+        if (MODE == 2) {          /* probe 2: the loads alone */                                       \
+            _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct)                                        \
+                _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
+                    acc[m][ct][0] += (a[m][q].x + a[m][q].y) * b[ct][q].x + (a[m][q].z + a[m][q].w) * b[ct][q].w; \
+        } else if ((GRP) * G + q < nchunk) {                                                           \
             _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                      \
                 _Pragma("unroll") for (int m = 0; m < NT; ++m)                                        \
                     acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].x, b[ct][q].x, acc[m][ct], 0, 0, 0); \
@@ -1400,6 +1453,111 @@ __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
                 }
         }
         // the next iteration's first barrier (tile id) also orders these reads of `red` before its next writes
+    }
+}
+
+// k_project_l2b: the multi-tile product with the L2 operand SHARED through LDS.  Measured on config 4 (asb_test_l2w_probe,
+// tools/probe_l2w.py): k_project_l2w without its MFMAs takes 0.99 / 1.08 / 1.15 ms for 2 / 3 / 4 tiles against 0.87 ms for the
+// X operand alone, and just as long with X coming from cache -- the vector memory path delivers ~8.3 TB/s in all, and every
+// wave fetching its own copy of the weights (1.2 GB per tile and launch, against 4.8 GB of X) is what fills it.  Here a
+// block of 8 waves owns 256 rows: wave w = (row tile rt = w & 3, frame half sub = w >> 2); per iteration the block stages the
+// weights of TWO frame chunks (one per frame half, all NCT column tiles) in LDS once -- a quarter of the L2 traffic -- while
+// each wave keeps its own 64 rows of X in registers one chunk ahead.  One barrier per iteration (double-buffered stage);
+// the two frame halves meet through LDS at the end of the tile, one column tile at a time.
+template <int NCT>
+__global__ __launch_bounds__(512, 2) void k_project_l2b(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
+    constexpr int NT = 4;
+    extern __shared__ double l2b_lds[];
+    double4* Bs = reinterpret_cast<double4*>(l2b_lds);                            // [2 stages][2 chunks][NCT][64 lanes]
+    typedef double (*red_t)[NT][4][64];
+    red_t red = reinterpret_cast<red_t>(l2b_lds + (size_t)2 * 2 * NCT * 64 * 4);   // [4 row tiles][NT][4][64]
+    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2b_lds + (size_t)2 * 2 * NCT * 64 * 4 + (size_t)4 * NT * 4 * 64);
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w & 3, sub = w >> 2;
+    const long long ntiles = (rows + 255) / 256;
+    const int nchunk = Fp / 16, npair = (nchunk + 1) / 2;
+    // staging: thread e < 128 NCT fetches one double4 of the pair's weights: e = (chunk of the pair, column tile, lane)
+    const bool stager = tid < 128 * NCT;
+    const int s_cc = tid / (64 * NCT), s_ct = (tid / 64) % NCT, s_l = tid & 63;
+    const double4* s_src = reinterpret_cast<const double4*>(Wq + (long long)s_ct * Fp * 16) + s_l;      // chunk c: s_src[64 * c]
+    for (;;) {
+        if (tid == 0) tile_sh = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int t = tile_sh;
+        if ((long long)t >= ntiles) break;                      // the same for every wave of the block
+        const long long base = (long long)t * 256 + 64 * rt;
+        const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            long long r = base + 16 * m + i;
+            if (r >= rows) r = rows - 1;
+            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+        }
+        d4 acc[NT][NCT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        double4 a[NT], an[NT], breg = make_double4(0, 0, 0, 0);
+        {
+            const int c = sub < nchunk ? sub : nchunk - 1;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) a[m] = xp[m][4 * c];
+            if (stager) breg = (s_cc < nchunk) ? s_src[64 * s_cc] : make_double4(0, 0, 0, 0);
+        }
+        for (int j = 0; j < npair; ++j) {
+            double4* stage = Bs + (size_t)(j & 1) * 2 * NCT * 64;
+            if (stager) stage[(s_cc * NCT + s_ct) * 64 + s_l] = breg;
+            // the next pair's operands fly while this pair's MFMAs issue
+            if (j + 1 < npair) {
+                const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
+#pragma unroll
+                for (int m = 0; m < NT; ++m) an[m] = xp[m][4 * cn];
+                const int sc = 2 * (j + 1) + s_cc;
+                if (stager) breg = (sc < nchunk) ? s_src[64 * sc] : make_double4(0, 0, 0, 0);
+            }
+            __syncthreads();            // the stage is complete; its previous readers (iteration j - 2) passed barrier j - 1
+            if (2 * j + sub < nchunk) {
+                const double4* bsrc = stage + (size_t)sub * NCT * 64 + l;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const double4 b = bsrc[ct * 64];
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].z, b.z, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].w, b.w, acc[m][ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NT; ++m) a[m] = an[m];
+        }
+        // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            __syncthreads();            // `red` is free (first round: also orders the last MFMA stage against nothing of ours)
+            if (sub == 1) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[rt][m][q][l] = acc[m][ct][q];
+            }
+            __syncthreads();
+            if (sub == 0 && i < wa.nc[ct]) {
+                const double inv = wn2[16 * ct + i];
+                double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = (acc[m][ct][q] + red[rt][m][q][l]) / inv;
+            }
+        }
+        // the next iteration's first barrier (tile id) orders the last reads of `red` and of the stages before their reuse
     }
 }
 
@@ -1637,9 +1795,9 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
 // ---- super-panels ------------------------------------------------------------------------------------------------
 static int super_alloc(asb_ctx* ctx) {
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)3 * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)3 * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)48))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->band_idx, (size_t)ctx->band_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->band_E, (size_t)ctx->band_cap))) return rc;
@@ -1687,7 +1845,9 @@ static int wide_correct_tile(asb_ctx* ctx, int ct, long long kb, int nc, bool ba
 // the band's exact energies after the sub-panel [kb, kb + nc): projection of the band's rows of X (16 columns), correction
 static int band_pass(asb_ctx* ctx, long long kb, int nc) {
     wide_build_tile(ctx, 0, kb, nc);
-    WideArgs wa{{kb, 0, 0}, {nc, 0, 0}};
+    WideArgs wa{};
+    wa.kb[0] = kb;
+    wa.nc[0] = nc;
     // 16-row tiles: the band is only ~36k rows, larger tiles would leave most waves idle
     hipLaunchKernelGGL((k_project_wide<1, 8, 1, true>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, (long long)0, (int)ctx->Fp,
                        ctx->Wq3, ctx->wn2t3, wa, ctx->comps, (long long)(3 * ctx->n_loc), ctx->tile_counter, ctx->band_idx, ctx->bstate,
@@ -1696,66 +1856,47 @@ static int band_pass(asb_ctx* ctx, long long kb, int nc) {
     return wide_correct_tile(ctx, 0, kb, nc, true);
 }
 
-// the multi-tile projection kernel (bracketed by the profiling events); tiles built by wide_build_tile
+// the multi-tile projection kernel (bracketed by the profiling events); tiles built by wide_build_tile.
+// Up to 3 tiles: compiled for two waves per SIMD (<= 256 registers: 8 waves x 8 KB of X in flight per CU); from 4 tiles on
+// the accumulators alone take 128+ registers: one wave per SIMD, the MFMA time per chunk (1024 cycles per tile) hides the
+// load latency instead.  Variants measured on config 4 (tools/wide_variants.sh): deeper prefetch (PD = 2), four waves per
+// tile, 32- and 48-row tiles, two chunks per group -- all slower than this one for 2 tiles.
+template <int NT, int G, int S, int NCT, int OCC, int PD>
+static int launch_l2w_cfg(asb_ctx* ctx, const WideArgs& wa, int blocks_per_cu) {
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT - 1) / (16 * NT);
+    const size_t lds = ((size_t)(S - 1) * NT * NCT * 4 * 64 + 2) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2w<NT, G, S, NCT, OCC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long cap = (long long)blocks_per_cu * ctx->n_cu;
+    hipLaunchKernelGGL((k_project_l2w<NT, G, S, NCT, OCC, PD>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * S), lds, ctx->stream,
+                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    return ASB_OK;
+}
 template <int NCT>
-static void launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
-    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 63) / 64;
-    if (variant == 10)         // two waves per SIMD, HBM operand two chunks ahead
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT, 2, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 11)    // the same, four waves per tile
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT, 2, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 13) {  // 48-row tiles, two waves per SIMD, HBM operand two chunks ahead
-        const long long nt3 = (rows + 47) / 48;
-        hipLaunchKernelGGL((k_project_l2w<3, 1, 2, NCT, 2, 2>), dim3((unsigned)(nt3 < 4 * ctx->n_cu ? nt3 : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 14) {  // the same, three waves per SIMD
-        const long long nt3 = (rows + 47) / 48;
-        hipLaunchKernelGGL((k_project_l2w<3, 1, 2, NCT, 3, 2>), dim3((unsigned)(nt3 < 6 * ctx->n_cu ? nt3 : 6 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 15) {  // 32-row tiles, two chunks per group, two waves per SIMD
-        const long long nt2 = (rows + 31) / 32;
-        hipLaunchKernelGGL((k_project_l2w<2, 2, 2, NCT, 2, 1>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 16) {  // 32-row tiles, three chunks per group
-        const long long nt2 = (rows + 31) / 32;
-        hipLaunchKernelGGL((k_project_l2w<2, 3, 2, NCT, 2, 1>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 12)    // one wave per SIMD, two chunks per group, HBM operand two groups ahead
-        hipLaunchKernelGGL((k_project_l2w<4, 2, 2, NCT, 1, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 6) {        // 32-row tiles, two chunks in flight, three waves per SIMD
-        const long long nt2 = (rows + 31) / 32;
-        hipLaunchKernelGGL((k_project_l2w<2, 2, 2, NCT, 3>), dim3((unsigned)(nt2 < 6 * ctx->n_cu ? nt2 : 6 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 7) {
-        const long long nt2 = (rows + 31) / 32;
-        hipLaunchKernelGGL((k_project_l2w<2, 2, 4, NCT, 3>), dim3((unsigned)(nt2 < 3 * ctx->n_cu ? nt2 : 3 * ctx->n_cu)), dim3(256), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 8) {  // 48-row tiles, two chunks in flight, two waves per SIMD
-        const long long nt3 = (rows + 47) / 48;
-        hipLaunchKernelGGL((k_project_l2w<3, 2, 2, NCT, 2>), dim3((unsigned)(nt3 < 4 * ctx->n_cu ? nt3 : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 9) {  // 32-row tiles, four chunks in flight, two waves per SIMD
-        const long long nt2 = (rows + 31) / 32;
-        hipLaunchKernelGGL((k_project_l2w<2, 4, 2, NCT, 2>), dim3((unsigned)(nt2 < 4 * ctx->n_cu ? nt2 : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    } else if (variant == 4)          // two waves per SIMD
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 5)
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT, 2>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 2)
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 4, NCT>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else if (variant == 3)
-        hipLaunchKernelGGL((k_project_l2w<4, 2, 2, NCT>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    else
-        hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0,
-                           ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 255) / 256;
+    const size_t lds = ((size_t)2 * 2 * NCT * 64 * 4 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2b<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_project_l2b<NCT>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(512), lds, ctx->stream,
+                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    return ASB_OK;
+}
+template <int NCT>
+static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
+    if (variant == 20 && NCT <= 4) return launch_l2b<(NCT <= 4 ? NCT : 2)>(ctx, wa);                               // weights shared through LDS
+    if (variant == 30 && NCT <= 4) return launch_l2w_cfg<8, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 128-row tiles: half the weight traffic
+    if (variant == 31 && NCT <= 4) return launch_l2w_cfg<6, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 96-row tiles
+    if (variant == 3 && NCT <= 5) return launch_l2w_cfg<4, 2, 2, (NCT <= 5 ? NCT : 1), 1, 1>(ctx, wa, 2);       // two chunks per group
+    if (variant == 10) return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 2>(ctx, wa, NCT <= 3 ? 4 : 2);   // HBM operand two chunks ahead
+    if (variant == 5) return launch_l2w_cfg<4, 1, 2, NCT, 1, 1>(ctx, wa, 2);                                    // one wave per SIMD throughout
+    return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 1>(ctx, wa, NCT <= 3 ? 4 : 2);
 }
 static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     const long long rows = 3 * ctx->n_loc;
@@ -1763,7 +1904,7 @@ static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     size_t slot;
     int rc;
     if ((rc = prof_begin(ctx, slot))) return rc;
-    if (variant == 0) {
+    if (variant == 0 && ntile <= 3) {          // round 1's kernel: one wave per 64-row tile
         if (ntile == 1)
             hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
                                ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
@@ -1777,19 +1918,76 @@ static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
         const long long ntiles = (rows + 63) / 64;
         hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream,
                            ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa.nc[0], ctx->comps + (size_t)wa.kb[0] * rows, rows, ctx->tile_counter);
-    } else if (ntile == 2) {
-        launch_l2w<2>(ctx, variant, wa);
     } else {
-        launch_l2w<3>(ctx, variant, wa);
+        switch (ntile) {
+            case 2: rc = launch_l2w<2>(ctx, variant, wa); break;
+            case 3: rc = launch_l2w<3>(ctx, variant, wa); break;
+            case 4: rc = launch_l2w<4>(ctx, variant, wa); break;
+            case 5: rc = launch_l2w<5>(ctx, variant, wa); break;
+            case 6: rc = launch_l2w<6>(ctx, variant, wa); break;
+            case 7: rc = launch_l2w<7>(ctx, variant, wa); break;
+            default: rc = launch_l2w<8>(ctx, variant, wa); break;
+        }
+        if (rc) return rc;
     }
     if ((rc = prof_end(ctx, slot))) return rc;
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
 
+// timing probe of the multi-tile kernel on the context's tensor (results are garbage): mode 0 = the kernel as it runs,
+// 1 = X operand from four cache-resident tiles (MFMA + L2 operand alone), 2 = no MFMAs (the loads alone)
+template <int NCT, int MODE>
+static int l2w_probe_launch(asb_ctx* ctx, const WideArgs& wa) {
+    constexpr int OCC = NCT <= 3 ? 2 : 1;
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 63) / 64;
+    const size_t lds = ((size_t)4 * NCT * 4 * 64 + 2) * sizeof(double);
+    ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2w<4, 1, 2, NCT, OCC, 1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long cap = (long long)(NCT <= 3 ? 4 : 2) * ctx->n_cu;
+    hipLaunchKernelGGL((k_project_l2w<4, 1, 2, NCT, OCC, 1, MODE>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(128), lds, ctx->stream,
+                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    return ASB_OK;
+}
+extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, double* ms_out) {
+    if (!ctx || !ctx->X || !ctx->comps || !ms_out || reps < 1 || ctx->K < 16 * nct) return ASB_ERR_ARG;
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    std::vector<double> ones((size_t)ASB_MAX_SUB * ctx->Fp * 16, 1.0e-3);
+    ASB_HIP(ctx, hipMemcpy(ctx->Wq3, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+    ASB_HIP(ctx, hipMemcpy(ctx->wn2t3, ones.data(), 16 * ASB_MAX_SUB * sizeof(double), hipMemcpyHostToDevice));
+    WideArgs wa{};
+    for (int ct = 0; ct < nct; ++ct) { wa.kb[ct] = 16 * ct; wa.nc[ct] = 16; }
+    hipEvent_t e0, e1;
+    ASB_HIP(ctx, hipEventCreate(&e0));
+    ASB_HIP(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned), ctx->stream));
+        ASB_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        rc = ASB_ERR_ARG;
+#define ASB_PROBE_CASE(N)                                                           \
+        if (nct == N) rc = mode == 0 ? l2w_probe_launch<N, 0>(ctx, wa) : (mode == 1 ? l2w_probe_launch<N, 1>(ctx, wa) : l2w_probe_launch<N, 2>(ctx, wa));
+        ASB_PROBE_CASE(2) ASB_PROBE_CASE(3) ASB_PROBE_CASE(4)
+#undef ASB_PROBE_CASE
+        if (rc) return rc;
+        ASB_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        ASB_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        ASB_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = best;
+    return ASB_OK;
+}
+
 // ONE pass over X for up to three sub-panels
 static int project_pass_wide(asb_ctx* ctx, int ntile, const long long* kb, const int* nc) {
-    WideArgs wa{{0, 0, 0}, {0, 0, 0}};
+    WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
         wide_build_tile(ctx, ct, kb[ct], nc[ct]);
         wa.kb[ct] = kb[ct];
@@ -1943,6 +2141,9 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
     StreamCfg c;
     if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    // the adaptive panel lengths start afresh: the same tensor gives the same panels, hence the same bits, on every call
+    ctx->sub_cur = 0;
+    for (int q = 0; q < 8; ++q) ctx->sub_budget[q] = ASB_PANEL_COLS;
     if (ctx->e0_valid && ctx->E0 && ctx->e0_reuse) {
         // the energies of the prepared tensor came with the sweep that wrote it (asb_snapshots_scale) or with an earlier
         // begin on the same tensor: X has not changed since, so nothing is read again
@@ -3026,51 +3227,53 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
 static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
     int rc;
     *done_out = 0;
-    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)3 * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)3 * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)48))) return rc;
+    const int nsub_lim = ctx->sub_panels < 1 ? 1 : (ctx->sub_panels > ASB_MAX_SUB ? ASB_MAX_SUB : ctx->sub_panels);
+    if (ctx->sub_cur < 1) ctx->sub_cur = nsub_lim < ctx->sub_first ? nsub_lim : ctx->sub_first;
+    const int nsub_max = ctx->sub_cur < nsub_lim ? ctx->sub_cur : nsub_lim;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
     if ((rc = panel_candidates(ctx, k, 0))) return rc;
-    // who is a candidate is decided by the energies NOW; the second tile's check runs after the first tile's update
+    // who is a candidate is decided by the energies NOW; the later tiles' checks run after the earlier tiles' updates
     ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    long long kb[2] = {k, k + ASB_PANEL_COLS};
-    int nc[2] = {0, 0}, proven[2] = {0, 0};
-    int64_t ran = 0;
-    const int stepsA = (int)((k1 - k) < ASB_PANEL_COLS ? (k1 - k) : ASB_PANEL_COLS);
-    ctx->run_writeback = 1;
-    ctx->run_spec_max = ctx->spec_panels ? ctx->spec_budget : 0;
-    rc = asb_panel_run(ctx, k, stepsA, 0, 0, &ran);
-    ctx->run_writeback = 0;
-    ctx->run_spec_max = 0;
-    if (rc) return rc;
-    if (ran == 0) return ASB_OK;                      // the caller's refresh / forced path
-    nc[0] = (int)ran;
-    proven[0] = (int)ctx->run_proven;
-    int ntile = 1;
-    if (ran == ASB_PANEL_COLS && ctx->run_coop_used && ctx->spec_panels && k + ASB_PANEL_COLS < k1) {
-        // the first sub-panel's state (winner energies, provable head) is needed again after the pass
-        ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
-        // the second sub-panel runs entirely unproven on rows chosen for the first: it is given as many steps as the last
-        // ones kept (+2), a rejected step costs a panel step and everything behind it
-        int stepsB = (int)((k1 - kb[1]) < ASB_PANEL_COLS ? (k1 - kb[1]) : ASB_PANEL_COLS);
-        if (stepsB > ctx->dbl_budget) stepsB = ctx->dbl_budget;
-        int64_t ranB = 0;
-        ctx->run_spec_max = ASB_PANEL_COLS;
-        rc = asb_panel_run(ctx, kb[1], stepsB, 0, 0, &ranB);      // same candidates, rows as the first sub-panel left them
+    long long kb[ASB_MAX_SUB];
+    int nc[ASB_MAX_SUB] = {0}, proven[ASB_MAX_SUB] = {0};
+    for (int sp = 0; sp < ASB_MAX_SUB; ++sp) kb[sp] = k + (long long)sp * ASB_PANEL_COLS;
+    int ntile = 0;
+    for (int sp = 0; sp < nsub_max && kb[sp] < k1; ++sp) {
+        int steps = (int)((k1 - kb[sp]) < ASB_PANEL_COLS ? (k1 - kb[sp]) : ASB_PANEL_COLS);
+        if (sp > 0) {
+            // the earlier sub-panel's state (winner energies, provable head) is needed again after the pass
+            ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
+            // a later sub-panel runs on rows chosen for the first, mostly unproven (the bound on the vertices outside is the
+            // stale one): it is given as many steps as the last ones kept (+2) -- a rejected step costs a panel step and
+            // everything behind it
+            if (steps > ctx->sub_budget[sp]) steps = ctx->sub_budget[sp];
+        }
+        int64_t ran = 0;
+        ctx->run_writeback = 1;
+        ctx->run_spec_max = ctx->spec_panels ? (sp == 0 ? ctx->spec_budget : ASB_PANEL_COLS) : 0;
+        rc = asb_panel_run(ctx, kb[sp], steps, 0, 0, &ran);      // sp > 0: same candidates, rows as the last sub-panel left them
+        ctx->run_writeback = 0;
         ctx->run_spec_max = 0;
         if (rc) return rc;
-        ctx->n_panels--;                                 // statistics count reads of X
-        if (ranB > 0 && ctx->run_coop_used) {
-            nc[1] = (int)ranB;
-            proven[1] = (int)ctx->run_proven;
-            ntile = 2;
-        }
+        if (sp > 0) ctx->n_panels--;                     // statistics count reads of X
+        if (sp == 0 && ran == 0) return ASB_OK;          // the caller's refresh / forced path
+        if (ran == 0 || (sp > 0 && !ctx->run_coop_used)) break;
+        nc[sp] = (int)ran;
+        proven[sp] = (int)ctx->run_proven;
+        ntile = sp + 1;
+        // another sub-panel only behind a full one that ran in the co-resident kernel (the two-kernel loop leaves the rows
+        // as they were) and may go on unproven
+        if (ran < ASB_PANEL_COLS || !ctx->run_coop_used || !ctx->spec_panels) break;
     }
-    PanelState* st[2] = {ntile == 2 ? ctx->pstate2 : ctx->pstate, ctx->pstate};
-    // one read of X for both tiles
-    WideArgs wa{{0, 0, 0}, {0, 0, 0}};
+    PanelState* st[ASB_MAX_SUB];
+    for (int ct = 0; ct < ntile; ++ct) st[ct] = ct < ntile - 1 ? ctx->pstate2 + ct : ctx->pstate;
+    // one read of X for all tiles
+    WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
         wide_build_tile(ctx, ct, kb[ct], nc[ct]);
         wa.kb[ct] = kb[ct];
@@ -3079,6 +3282,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     ASB_CHECK_LAUNCH(ctx);
     if ((rc = launch_wide(ctx, ntile, wa))) return rc;
     int64_t total = 0;
+    int full = 0;
+    bool rejected = false;
     for (int ct = 0; ct < ntile; ++ct) {
         int64_t kept = 0;
         if ((rc = spec_tile_finish(ctx, ct, kb[ct], nc[ct], st[ct], &kept))) return rc;
@@ -3086,28 +3291,21 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         ctx->n_spec_kept += kept > proven[ct] ? kept - proven[ct] : 0;
         total += kept;
         if (getenv("ASB_DEBUG_PANELS"))
-            fprintf(stderr, "[asb] double panel at k=%lld tile %d: %d proven + %lld of %d unproven steps kept\n", k, ct, proven[ct],
+            fprintf(stderr, "[asb] panel at k=%lld tile %d: %d proven + %lld of %d unproven steps kept\n", k, ct, proven[ct],
                     (long long)(kept > proven[ct] ? kept - proven[ct] : 0), nc[ct] - proven[ct]);
-        if (ct == 1) {                                // adapt the second sub-panel's length to what stands
+        if (ct >= 1) {                                // adapt the later sub-panels' lengths to what stands
             const int want = (int)kept + 2;
-            ctx->dbl_budget = want < 4 ? 4 : (want > ASB_PANEL_COLS ? ASB_PANEL_COLS : want);
+            ctx->sub_budget[ct] = want < 4 ? 4 : (want > ASB_PANEL_COLS ? ASB_PANEL_COLS : want);
         }
-        if (kept < nc[ct]) break;                    // what follows was built on a rejected step
+        if (kept < nc[ct]) { rejected = true; break; }      // what follows was built on a rejected step
+        ++full;
     }
+    // how many sub-panels the next read of X gets: twice as many after a read whose sub-panels all stood, what stood
+    // (+1) after a rejection -- a rejected sub-panel costs its panel steps and its share of the MFMA work
+    if (rejected) ctx->sub_cur = full + 1 < nsub_lim ? full + 1 : nsub_lim;
+    else if (ntile == nsub_max) ctx->sub_cur = 2 * nsub_max < nsub_lim ? 2 * nsub_max : nsub_lim;
     if (total > 0) ctx->k_done = k + total;
     *done_out = total;
-    return ASB_OK;
-}
-
-// two-level histogram threshold of the energies (E2 == NULL) or of the score E2 + g (E - E2): sc[SC_TAU] such that about
-// m_target of the n_loc values lie above it
-static int panel_threshold(asb_ctx* ctx, const double* E, const double* E2, double g, long long m_target, long long m_cap) {
-    for (int level = 1; level <= 2; ++level) {
-        hipLaunchKernelGGL(k_hist, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, E, (long long)ctx->n_loc, ctx->scalar_dev,
-                           ctx->hist, level == 1 ? 1 : 0, E2, g);
-        hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level, m_target, m_cap);
-    }
-    ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
 
@@ -3118,15 +3316,35 @@ static bool guess_possible(const asb_ctx* ctx) {
 }
 // thresholds of the scores EV + g (E - EV) into sc[SC_TAUG ..]: about mq[q] / world of this shard's vertices above each.
 // ~590 candidates on config 4 (the sets overlap), at most 830 + bin overshoot + the energies' own of the 1024 resident waves
-static int guess_thresholds(asb_ctx* ctx, int world) {
+static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3};
     static const int mq[ASB_NG] = {400, 140, 140, 90, 60};
     int rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)(ASB_NG + 1) * 8))) return rc;
+    if (!ctx->hist6_clear) {          // every k_tau_multi leaves the bins it consumed at zero again
+        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)(ASB_NG + 1) * ASB_NBINS * sizeof(int), ctx->stream));
+        ctx->hist6_clear = true;
+    }
+    GuessTargets gt;
     for (int q = 0; q < ASB_NG; ++q) {
         long long m = mq[q] * ctx->m_target / 768 / world;
         if (m < 8) m = 8;
-        if ((rc = panel_threshold(ctx, ctx->energy, ctx->EV, gq[q], m, m + m / 8))) return rc;
-        hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAUG + q, (int)SC_TAU);
+        gt.g[q] = gq[q];
+        gt.m_target[q] = m;
+        gt.m_cap[q] = m + m / 8;
+    }
+    // g = 1: the energies proper (single rank: the few that carry the provable first steps; several ranks threshold them
+    // through the usual exchange instead)
+    const long long me = ctx->m_target / 12;
+    gt.g[ASB_NG] = 1.0;
+    gt.m_target[ASB_NG] = me;
+    gt.m_cap[ASB_NG] = me + me / 2;
+    const int nq = with_energy ? ASB_NG + 1 : ASB_NG;
+    for (int level = 1; level <= 2; ++level) {
+        hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, ctx->EV, (long long)ctx->n_loc,
+                           ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, nq);
+        hipLaunchKernelGGL(k_tau_multi, dim3(nq), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt);
     }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -3146,7 +3364,7 @@ extern "C" int asb_panel_guess_begin(asb_ctx* ctx, int world) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || world < 1) return ASB_ERR_ARG;
     if (!guess_possible(ctx)) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_guess_begin: no energies without the constant direction");
     int rc;
-    if ((rc = guess_thresholds(ctx, world))) return rc;
+    if ((rc = guess_thresholds(ctx, world, false))) return rc;
     ctx->sel_e2 = ctx->EV;
     ctx->m_target_eff = ctx->m_target / 12;
     ctx->n_guess_panels++;
@@ -3173,9 +3391,7 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     int rc;
     const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
     if (guess) {
-        if ((rc = guess_thresholds(ctx, 1))) return rc;
-        const long long me = ctx->m_target / 12;
-        if ((rc = panel_threshold(ctx, ctx->energy, nullptr, 0.0, me, me + me / 2))) return rc;
+        if ((rc = guess_thresholds(ctx, 1, true))) return rc;
         ctx->sel_e2 = ctx->EV;
         ctx->n_guess_panels++;
     } else {

@@ -348,11 +348,11 @@ def main():
         # this build at this shape (tools/summarise_pmc.py), an OFFLINE measurement committed under profiles/ -- counters
         # cannot be read from inside the run
         traffic, traffic_src = None, None
-        # single rank, default settings: two 16-column sub-panels per read of X (k_project_l2w); the multi-rank protocol and
-        # ASB_DOUBLE_PANELS=0 read X once per 16-column panel (k_project_l2s)
+        # single rank, default settings: up to three 16-column sub-panels per read of X (k_project_l2w); the multi-rank protocol
+        # and ASB_DOUBLE_PANELS=0 read X once per 16-column panel (k_project_l2s)
         wide = (mode == "project" and pk == 3 and world == 1 and not forced and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0"
                 and os.environ.get("ASB_WIDE_VARIANT", "4") == "4")
-        kname = "k_project_l2w<4, 1, 2, 2, 2, 1>" if wide else {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
+        kname = "k_project_l2w<4, 1, 2, 3, 2, 1, 0>" if wide else {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
         try:
             pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
             if mode == "project" and kname in pm["kernels"] and (N, F, world) == (100000, 2000, 1) and \
@@ -366,6 +366,9 @@ def main():
         reads = launches / max(args.steps, 1) / nsweep + stats.get("energy_passes", 1)      # both per step
         step_bytes = reads * 24.0 * N * F
         step_gbs = step_bytes / (ms_step * 1e-3) / 1e9 / world
+        # f64 MFMA work of the average launch: 2 * rows * F flops per component column, K columns per step
+        flops_launch = (2.0 * 3 * n_loc * F * K * args.steps / launches) if (launches and mode == "project") else 0.0
+        tflops = flops_launch / (avg_ms * 1e-3) / 1e12 if launches else None
         out = {
             "metric": "snapshots/sec (SVD+SPLOCS) for n_verts x n_frames; basis Frobenius err vs ref",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -374,29 +377,41 @@ def main():
             "config": {"workload": "config4: synthetic U[-1,1) %d verts x %d frames, greedy-deflation PCA K=%d, "
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": (("k_project_l2w<4,1,2,2,2,1> (f64-MFMA projection on two 16-column sub-panels, 1 launch = one "
-                                     "read of X per 32 components)" if wide else
-                                     {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
-                                     " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep)
-                                    if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
-                         # the same launches against the f64 MFMA peak: 2 * rows * F flops per component column
-                         "mfma": ({"achieved": 2.0 * 3 * n_loc * F * K * args.steps / launches / (avg_ms * 1e-3) / 1e12,
-                                   "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": 2.0 * 3 * n_loc * F * K * args.steps / launches / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                                   "note": "HBM time at peak (0.60 ms) exceeds MFMA time at peak (0.49 ms for 32 columns): "
-                                           "bound stays hbm"} if (mode == "project" and launches) else None),
-                         "algorithm": mode, "panels_per_step": stats["panels"],
-                         "refreshes": stats["refreshes"], "launches": launches,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            # The dominant kernel against BOTH of its ceilings, the binding one first.  One launch reads the shard once
+            # (24 n F bytes) and does 2 * 3n * F flops per component column it projects on; at the peaks that is 0.60 ms
+            # of HBM and 0.245 ms of f64 MFMA per 16 columns, so launches with 3 sub-panels (48 columns, the usual case
+            # on a single rank) are MFMA-bound and launches with 1 or 2 HBM-bound.  `bound` follows the average launch.
+            "roofline": dict(
+                         ([("bound", "mfma"), ("achieved", tflops), ("peak", FP64_MFMA_PEAK_TFLOPS), ("unit", "TFLOP/s"),
+                           ("frac", tflops / FP64_MFMA_PEAK_TFLOPS),
+                           ("hbm", {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})]
+                          if (launches and mode == "project" and flops_launch / (FP64_MFMA_PEAK_TFLOPS * 1e12) > alg_bytes / (HBM_PEAK_GBS * 1e9)) else
+                          [("bound", "hbm"), ("achieved", achieved), ("peak", HBM_PEAK_GBS), ("unit", "GB/s"),
+                           ("frac", (achieved / HBM_PEAK_GBS) if achieved else None),
+                           ("mfma", ({"achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tflops / FP64_MFMA_PEAK_TFLOPS} if (launches and mode == "project") else None))]),
+                         traffic=traffic, traffic_source=traffic_src,
+                         kernel=(("k_project_l2w<4,1,2,NCT,2,1> (f64-MFMA projection on NCT <= 3 16-column sub-panels, 1 launch = one "
+                                  "read of X per up to 48 components; config 4: two launches with 3 sub-panels, one with 2)" if wide else
+                                  {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
+                                  " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep)
+                                 if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
+                         columns_per_launch=(K * args.steps / launches * nsweep if launches else None),
+                         algorithmic_flops_per_launch=flops_launch,
+                         algorithm=mode, panels_per_step=stats["panels"],
+                         refreshes=stats["refreshes"], launches=launches,
+                         avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
                          # the whole step against the same peak: what THIS algorithm has to read (one read of X per
                          # panel pass [+ initial energies]) / ms_per_step, per GPU
-                         "step": {"reads_of_X": reads, "bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
-                                  "dominant_kernel_share": (kern_ms / args.steps) / ms_step if launches else None},
+                         step={"reads_of_X": reads, "bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                                  "dominant_kernel_share": (kern_ms / args.steps) / ms_step if launches else None,
+                                  # and against the MFMA peak: the projections of a step are 2 * 3N * F * K flops whatever
+                                  # the number of reads
+                                  "flops": 2.0 * 3 * N * F * K, "mfma_achieved": 2.0 * 3 * N * F * K / (ms_step * 1e-3) / 1e12 / world,
+                                  "mfma_frac": 2.0 * 3 * N * F * K / (ms_step * 1e-3) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS},
                          # SURVEY.md 8(d) priced a step at 24 N F (1 + K) bytes (one read of X per component); the panel
                          # algorithm commits up to 16 components per read, so that figure is not a roofline for it
-                         "survey_step_bytes": 24.0 * N * F * (1 + K)},
+                         survey_step_bytes=24.0 * N * F * (1 + K)),
             "end_to_end": {"prepare_ms": prepare_ms, "step_ms": ms_step, "basis_download_ms": download_ms,
                            "basis_bytes": basis_bytes, "total_ms": prepare_ms + ms_step + download_ms,
                            "snapshots_per_s": F / ((prepare_ms + ms_step + download_ms) * 1e-3),

@@ -423,6 +423,10 @@ int asb_test_tridiag_eig(asb_ctx* ctx, const double* d, const double* e, int64_t
                          int64_t* n_bad);
 int asb_test_jacobi_rows(asb_ctx* ctx, const double* A, int64_t nv, int64_t m, double* U, double* sig, int64_t* sweeps);
 int asb_test_chol_tinv(asb_ctx* ctx, const double* G, int64_t K, double* Tt);
+/* timing probe of the multi-tile projection kernel on the context's tensor in projection mode (component storage is
+ * overwritten): nct tiles (2..4); mode 0 = as it runs, 1 = X operand from four cache-resident tiles, 2 = without the MFMAs;
+ * best of `reps` launches in ms.  tools/probe_l2w.py. */
+int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, double* ms_out);
 /* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
  * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */
 void asb_test_eig3(const double* a6, double* out4);
