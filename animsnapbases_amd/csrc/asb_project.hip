@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_best_energy(const double* pmax, const l
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W, const double* __restrict__ Wt,
                                                     int Fp, double* __restrict__ G, double* __restrict__ Gs = nullptr,
-                                                    const double* __restrict__ wn2 = nullptr) {
+                                                    const double* __restrict__ wn2 = nullptr, const double* __restrict__ scal = nullptr) {
     __shared__ double sh[4 * 16];
     const double* wj = W + (long long)blockIdx.x * Fp;
     double acc[16];
@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256) void k_panel_gram(const double* __restrict__ W
     }
     block_sum<16>(acc, sh);
     if (threadIdx.x < 16) {
-        G[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x];
+        // scal != NULL (k_orth_wt's operand): (w_j . w_t) / |w_j|^2 instead
+        G[(long long)blockIdx.x * 16 + threadIdx.x] = scal ? acc[threadIdx.x] / scal[(long long)blockIdx.x * 4 + 1] : acc[threadIdx.x];
         if (Gs) Gs[(long long)blockIdx.x * 16 + threadIdx.x] = acc[threadIdx.x] / wn2[threadIdx.x];      // (w_j . w_t) / |w_t|^2
     }
 }
@@ -644,7 +645,10 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                                                       double* __restrict__ pmax, long long* __restrict__ pidx,
                                                       double* __restrict__ psum, double* __restrict__ colpart,
                                                       PanelState* __restrict__ spec, const double* __restrict__ sc,
-                                                      const double* __restrict__ E2 = nullptr, const double* __restrict__ Ecl = nullptr) {
+                                                      const double* __restrict__ E2 = nullptr, const double* __restrict__ Ecl = nullptr,
+                                                      int pre_orth = 0) {
+    // pre_orth: the pass projected on weights already orthogonalised against everything before them (k_orth_wt): the
+    // coefficients are final, only energies / records / the check are left
     __shared__ double qs[16 * 192];
     const int tid = threadIdx.x;
     const long long n_rows = 3 * n_vert;
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
         double c[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) c[t] = (valid && t < ncols) ? comps[(long long)(k0 + t) * comp_stride + r] : 0.0;
-        int j = 0;
+        int j = pre_orth ? k0 : 0;
         for (; j + 8 <= k0; j += 8) {          // eight earlier components in flight
             double a[8];
 #pragma unroll
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
         // among the panel's own columns, in order (column t needs the corrected columns j < t)
 #pragma unroll
         for (int t = 1; t < 16; ++t)
-            if (t < ncols) {
+            if (t < ncols && !pre_orth) {
                 const double* g = Gs + (long long)k0 * 16 + t;
 #pragma unroll
                 for (int jj = 0; jj < t; ++jj) c[t] -= c[jj] * g[jj * 16];
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
         __syncthreads();                       // the previous group's reads of qs are done
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            if (valid && t < ncols) comps[(long long)(k0 + t) * comp_stride + r] = c[t];
+            if (valid && t < ncols && !pre_orth) comps[(long long)(k0 + t) * comp_stride + r] = c[t];
             qs[t * 192 + tid] = c[t] * c[t];
         }
         __syncthreads();
@@ -803,6 +807,30 @@ __global__ __launch_bounds__(256) void k_commit_energy(const double* __restrict_
 // --------------------------------------------------------------------------------------
 // panel weights in B-operand order: Wt[f][t] (Fp x 16), zero columns beyond ncols
 // --------------------------------------------------------------------------------------
+// Wt[f][t] -= sum_{j < kb + t} W[j][f] (w_j . w_t) / |w_j|^2: the panel's weights made orthogonal, in exact arithmetic
+// terms, to every earlier weight vector (earlier panels, earlier sub-panels of the same read, earlier columns of the
+// panel).  The w_k are orthogonal up to rounding already; what is removed here is the eps-sized leakage that k_correct
+// otherwise takes out of the COEFFICIENTS after the pass (X w~_t = X w_t - sum_j (X w_j)(w_j . w_t) / |w_j|^2, which is the
+// correction with the uncorrected c_j in place of the corrected ones: a second-order difference) -- at the cost of
+// K x 16 x F flops instead of a sweep over all earlier coefficient columns.
+__global__ __launch_bounds__(256) void k_orth_wt(const double* __restrict__ W, const double* __restrict__ G,
+                                                 long long kb, int ncols, int Fp, double* __restrict__ Wt) {
+    const long long total = (long long)Fp * ASB_PANEL_COLS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ASB_PANEL_COLS);
+        const long long f = i / ASB_PANEL_COLS;
+        if (t >= ncols) continue;
+        double s = 0.0;
+        double s2 = 0.0;
+        long long j = 0;
+        for (; j + 2 <= kb + t; j += 2) {          // G: already divided by |w_j|^2 (k_panel_gram)
+            s += W[j * Fp + f] * G[j * 16 + t];
+            s2 += W[(j + 1) * Fp + f] * G[(j + 1) * 16 + t];
+        }
+        if (j < kb + t) s += W[j * Fp + f] * G[j * 16 + t];
+        Wt[i] -= s + s2;
+    }
+}
 __global__ __launch_bounds__(256) void k_build_wt(const double* __restrict__ W, const double* __restrict__ scal,
                                                   long long k0, int ncols, int Fp, double* __restrict__ Wt,
                                                   double* __restrict__ wn2) {
@@ -3196,15 +3224,17 @@ static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_ou
 // check and energy update, and only if all of it stands the second tile's against the updated energies.
 static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelState* st, int64_t* kept) {
     const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
-    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram,
-                       ctx->gram_s, ctx->wn2t3 + 16 * ct);
+    const int pre = (ctx->pre_orth && ctx->correct_rows) ? 1 : 0;
+    if (!pre)
+        hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram,
+                           ctx->gram_s, ctx->wn2t3 + 16 * ct);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
     if (ctx->correct_rows) {
         long long cwr = (ctx->n_loc + 63) / 64;
         hipLaunchKernelGGL(k_correct_rows<true>, dim3((unsigned)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap)), dim3(192), 0, ctx->stream,
                            ctx->comps, (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)kb, nc, ctx->gram_s, ctx->wn2t3 + 16 * ct,
-                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev, ctx->sel_e2, ctx->e_class);
+                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev, ctx->sel_e2, ctx->e_class, pre);
     } else
     hipLaunchKernelGGL(k_correct<true>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                        (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
@@ -3223,6 +3253,18 @@ static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelSta
     return ASB_OK;
 }
 
+// operands of tile ct of a multi-sub-panel read; pre_orth: orthogonalised weights (k_orth_wt), see spec_tile_finish
+static void dbl_build_tile(asb_ctx* ctx, int ct, long long kb, int nc) {
+    double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
+    hipLaunchKernelGGL(k_build_wt, dim3(64), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, kb, nc, (int)ctx->Fp, Wt, ctx->wn2t3 + 16 * ct);
+    if (ctx->pre_orth && ctx->correct_rows) {
+        hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram,
+                           (double*)nullptr, (const double*)nullptr, (const double*)ctx->scal);
+        hipLaunchKernelGGL(k_orth_wt, dim3(128), dim3(256), 0, ctx->stream, ctx->W, ctx->gram, kb, nc, (int)ctx->Fp, Wt);
+    }
+    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, Wt, (int)ctx->Fp, ctx->Wq3 + (size_t)ct * ctx->Fp * 16,
+                       ctx->tile_counter);
+}
 static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
 static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
     int rc;
@@ -3275,7 +3317,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     // one read of X for all tiles
     WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
-        wide_build_tile(ctx, ct, kb[ct], nc[ct]);
+        dbl_build_tile(ctx, ct, kb[ct], nc[ct]);
         wa.kb[ct] = kb[ct];
         wa.nc[ct] = nc[ct];
     }

@@ -233,3 +233,26 @@ def test_multirank_first_panel_guess_is_a_collective_decision(monkeypatch):
         assert np.array_equal(outs[0][2], outs[1][2])
         res[on] = outs[0][3]["panels"]
     assert res["1"] <= res["0"]
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lowrank_noise"])
+def test_reads_with_several_sub_panels_project_on_orthogonalised_weights(kind, monkeypatch):
+    """Several sub-panels per read of X (default): the pass projects on weights made orthogonal to every earlier weight
+    vector beforehand (k_orth_wt) instead of correcting the coefficients against all earlier columns afterwards
+    (ASB_PRE_ORTH=0) -- a second-order difference.  Both against the oracle; the low-rank + noise case is the one where
+    the leakage matters at all (components 1e4 apart in strength inside one panel)."""
+    rng = np.random.default_rng(31)
+    F, N, K = 160, 24000, 60
+    if kind == "uniform":
+        verts = rng.uniform(-1, 1, size=(F, N, 3))
+    else:
+        verts = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=20, noise=1e-4, seed=31)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    outs = {}
+    for pre in ("1", "0"):
+        monkeypatch.setenv("ASB_PRE_ORTH", pre)
+        comp, st = _run(verts, K)
+        _check(comp, d, tol=1e-9 if kind == "uniform" else 1e-8)
+        outs[pre] = (comp.comps.copy(), comp.weigs.copy(), st[0]["panels"])
+    assert relerr(outs["1"][0], outs["0"][0]) < 1e-10 and relerr(outs["1"][1], outs["0"][1]) < 1e-12
+    assert outs["1"][2] == outs["0"][2] <= 4          # reads of X: 60 components would take four 16-column panels at the least
