@@ -89,6 +89,11 @@ PROTOTYPES = {
                                       ctypes.POINTER(c_int)]),
     "asb_panel_guess_begin": (c_int, [ctypes.c_void_p, c_int]),
     "asb_panel_guess_end": (c_int, [ctypes.c_void_p]),
+    "asb_panel_sub_run": (c_int, [ctypes.c_void_p, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
+                                  ctypes.POINTER(c_int)]),
+    "asb_panel_sub_project": (c_int, [ctypes.c_void_p, c_i64, c_int, ctypes.POINTER(c_int)]),
+    "asb_panel_sub_check": (c_int, [ctypes.c_void_p, c_int, c_i64, c_int, ctypes.c_void_p]),
+    "asb_panel_sub_commit": (c_int, [ctypes.c_void_p, c_int, c_i64, c_int, c_int]),
     "asb_test_l2w_probe": (c_int, [ctypes.c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double)]),
     "asb_deflate_download_residual": (c_int, [ctypes.c_void_p, c_dp]),
     "asb_deflate_block_argmax": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp]),

@@ -57,6 +57,12 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
         tot = comm.allreduce_sum([me, nx, 0.0 if possible else 1.0])
         guess_ok = bool(tot[2] == 0 and tot[1] > 0 and tot[0] > 0.25 * tot[1])
     guessing = False
+    # several sub-panels per read (see the loop): only with the real engine, the co-resident kernel and device-side counts
+    multi_sub = bool(spec_word is not None and hasattr(eng, "panel_sub_run") and hasattr(eng, "panel_set_coop") and
+                     os.environ.get("ASB_PANEL_COOP", "1") != "0" and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0")
+    sub_max = max(1, min(3, int(os.environ.get("ASB_SUB_PANELS", "3"))))
+    sub_cur = min(sub_max, max(1, int(os.environ.get("ASB_SUB_FIRST", "3"))))
+    sub_budget = [16] * 8
     k, stalled, forced_next = 0, 0, -1
     while k < K:
         if guessing:
@@ -113,59 +119,116 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                 comm.all_gather_into(idx_g, idx_loc[:maxc])
                 eng.panel_assemble(rows_g.data_ptr(), idx_g.data_ptr(), counts, maxc)
             steps = 1 if forced >= 0 else min(16, K - k)
-            while True:
-                if spec_budget and not take_all and stalled == 0:
-                    done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)
-                else:
-                    done = proven = eng.panel_run(k, steps, take_all)
-                if not coop_check:
-                    if done < 0:          # one rank (tests): the context has switched the timed-out kernel off; repeat
-                        continue
-                    break
-                # The co-resident panel kernel can time out on ONE rank (its GPU shared with other work).  Every rank must
-                # then redo the panel the same way -- the two-kernel loop, whose steps are the provable ones -- or the
-                # ranks fall out of lock-step.  The status rides on the min all-reduce that panels with unproven steps
-                # need anyway: a rank whose launch failed contributes -1 (and skips its pass).
-                if done > proven and done > 0:
-                    eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
-                    passed = True
-                else:
-                    spec_word.fill_(float(done))             # -1: failed here; otherwise the fully proven count
-                    passed = False
+            # Several sub-panels per read of X (what the single-rank driver does inside the library): up to three runs of
+            # the panel kernel on the same candidates, ONE pass over the shard for all their columns, the tiles checked one
+            # at a time with a min over the ranks in between.  Every rank sees the same candidates, so the runs are
+            # identical everywhere -- except that the kernel can time out on one rank: the first exchange carries the
+            # status, and on a failure all ranks switch the kernel off and repeat the panel the plain way.
+            handled = multi_sub and spec_budget and not take_all and stalled == 0 and K - k > 16
+            if handled:
+                tiles, failed = [], False
+                for sp in range(sub_cur):
+                    kb = k + 16 * sp
+                    if kb >= K:
+                        break
+                    st_ = min(16, K - kb) if sp == 0 else min(16, K - kb, sub_budget[sp])
+                    ran, proven, cont = eng.panel_sub_run(sp, kb, st_, spec_budget if sp == 0 else 16)
+                    if ran < 0:
+                        failed = True
+                        break
+                    if ran == 0:
+                        break
+                    tiles.append((kb, ran, proven))
+                    if not cont:
+                        break
+                spec_word.fill_(-1.0 if failed else float(len(tiles)))
                 comm.allreduce_min_tensor(spec_word)
                 agreed = int(read_word())
-                if agreed >= 0:
-                    break
-                eng.panel_set_coop(False)                    # somewhere the exchange timed out: all ranks leave the kernel
-                coop_check = False
-            if coop_check:
-                if passed:                                    # unproven tail: `agreed` of the steps stand on every shard
-                    done = agreed
+                if agreed < 0:                                # somewhere the exchange timed out: all ranks leave the kernel
+                    eng.panel_set_coop(False)
+                    coop_check = multi_sub = guess_ok = False     # (unproven steps, and with them the guess, need the kernel)
+                    continue                                  # the panel again, from the selection, the plain way
+                total = 0
+                if agreed > 0:
+                    eng.panel_sub_project(k, [t[1] for t in tiles])
+                    full, rejected = 0, False
+                    for ct, (kb, ran, proven) in enumerate(tiles):
+                        eng.panel_sub_check(ct, kb, ran, spec_word.data_ptr())
+                        comm.allreduce_min_tensor(spec_word)
+                        kept = int(read_word())
+                        eng.panel_sub_commit(ct, kb, ran, kept)
+                        total += kept
+                        if ct >= 1:
+                            sub_budget[ct] = min(16, max(4, kept + 2))
+                        if kept < ran:
+                            rejected = True
+                            break
+                        full += 1
+                    if rejected:
+                        sub_cur = min(sub_max, full + 1)
+                    elif len(tiles) == sub_cur:
+                        sub_cur = min(sub_max, 2 * sub_cur)
+                    gain = total - tiles[0][2]
+                    spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
+                if total > 0:
+                    stalled = 0
+                    k += total
+                    continue
+                done = 0                                      # nothing stood: the refresh below
+            if not handled:
+                while True:
+                    if spec_budget and not take_all and stalled == 0:
+                        done, proven = eng.panel_run_spec(k, steps, take_all, spec_budget)
+                    else:
+                        done = proven = eng.panel_run(k, steps, take_all)
+                    if not coop_check:
+                        if done < 0:          # one rank (tests): the context has switched the timed-out kernel off; repeat
+                            continue
+                        break
+                    # The co-resident panel kernel can time out on ONE rank (its GPU shared with other work).  Every rank must
+                    # then redo the panel the same way -- the two-kernel loop, whose steps are the provable ones -- or the
+                    # ranks fall out of lock-step.  The status rides on the min all-reduce that panels with unproven steps
+                    # need anyway: a rank whose launch failed contributes -1 (and skips its pass).
+                    if done > proven and done > 0:
+                        eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
+                        passed = True
+                    else:
+                        spec_word.fill_(float(done))             # -1: failed here; otherwise the fully proven count
+                        passed = False
+                    comm.allreduce_min_tensor(spec_word)
+                    agreed = int(read_word())
+                    if agreed >= 0:
+                        break
+                    eng.panel_set_coop(False)                    # somewhere the exchange timed out: all ranks leave the kernel
+                    coop_check = multi_sub = False
+                if coop_check:
+                    if passed:                                    # unproven tail: `agreed` of the steps stand on every shard
+                        done = agreed
+                        eng.panel_commit(k, done)
+                        gain = done - proven
+                        spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
+                        if done > 0:
+                            stalled = 0
+                            k += done
+                            continue
+                    # fully proven (or nothing ran): falls through to the plain pass / the refresh below
+                elif done > proven:                           # the tail is unproven: the pass decides how much of it stands
+                    if spec_word is not None:                 # count stays on the device: min over ranks, ONE read
+                        eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
+                        comm.allreduce_min_tensor(spec_word)
+                        done = int(read_word())
+                    else:
+                        mine = eng.panel_project_spec(k, done, proven)
+                        done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
                     eng.panel_commit(k, done)
                     gain = done - proven
+                    # a kept step saves 1/16 of a panel, a rejected one costs one step of the panel kernel: back off only
+                    # after complete failures
                     spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
                     if done > 0:
                         stalled = 0
                         k += done
                         continue
-                # fully proven (or nothing ran): falls through to the plain pass / the refresh below
-            elif done > proven:                           # the tail is unproven: the pass decides how much of it stands
-                if spec_word is not None:                 # count stays on the device: min over ranks, ONE read
-                    eng.panel_project_spec_dev(k, done, proven, spec_word.data_ptr())
-                    comm.allreduce_min_tensor(spec_word)
-                    done = int(read_word())
-                else:
-                    mine = eng.panel_project_spec(k, done, proven)
-                    done = int(-comm.allreduce_max(np.array([-float(mine)]))[0]) if comm.multi else mine
-                eng.panel_commit(k, done)
-                gain = done - proven
-                # a kept step saves 1/16 of a panel, a rejected one costs one step of the panel kernel: back off only
-                # after complete failures
-                spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
-                if done > 0:
-                    stalled = 0
-                    k += done
-                    continue
         if done == 0:
             # nothing provable (stale bound / exact ties): exact energies everywhere, retry; a second
             # failure forces the global first arg-max as the only candidate

@@ -155,6 +155,7 @@ struct asb_ctx {
                                            // the projection kernel needs more than 256 registers and loses what the saved read gains)
     int sub_first = 3;                     // sub-panels of the first read (ASB_SUB_FIRST); then adapted: sub_cur
     int sub_cur = 0;
+    int sub_ntile = 0;                     // tiles of the read in progress (multi-rank steps: asb_panel_sub_*)
     int sub_budget[8] = {16, 16, 16, 16, 16, 16, 16, 16};      // steps given to the later sub-panels (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
 

@@ -3351,6 +3351,91 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     return ASB_OK;
 }
 
+// ---- the same read of X with several sub-panels, in steps, for the multi-rank driver (_panels.py): every rank runs the
+// sub-panels on the identical assembled candidates, projects its shard once, and the tiles are checked one at a time with
+// a min over the ranks in between (the driver's all-reduce of the device word)
+static PanelState* sub_state(asb_ctx* ctx, int ct) { return ct < ctx->sub_ntile - 1 ? ctx->pstate2 + ct : ctx->pstate; }
+extern "C" int asb_panel_sub_run(asb_ctx* ctx, int sp, int64_t k0, int steps, int spec_max, int64_t* ran, int64_t* proven, int* may_continue) {
+    if (!ctx || !ctx->candR || ctx->mode != ASB_DEFLATE_PROJECT || !ran || !proven || !may_continue) return ASB_ERR_ARG;
+    if (sp < 0 || sp >= ASB_MAX_SUB || spec_max < 0) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_sub_run: bad sub-panel");
+    int rc;
+    if (sp == 0) {
+        if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->run_writeback = 1;
+    ctx->run_spec_max = ctx->spec_panels ? spec_max : 0;
+    rc = asb_panel_run(ctx, k0, steps, 0, 1, ran);
+    ctx->run_writeback = 0;
+    ctx->run_spec_max = 0;
+    if (rc) return rc;
+    if (sp > 0) ctx->n_panels--;                          // statistics count reads of X
+    *proven = ctx->run_proven;
+    *may_continue = (*ran == ASB_PANEL_COLS && ctx->run_coop_used && ctx->spec_panels) ? 1 : 0;
+    return ASB_OK;
+}
+extern "C" int asb_panel_sub_project(asb_ctx* ctx, int64_t k0, int ntile, const int* nc) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !nc || ntile < 1 || ntile > ASB_MAX_SUB) return ASB_ERR_ARG;
+    WideArgs wa{};
+    for (int ct = 0; ct < ntile; ++ct) {
+        if (nc[ct] < 1 || nc[ct] > ASB_PANEL_COLS || k0 + 16 * ct + nc[ct] > ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_sub_project: bad range");
+        dbl_build_tile(ctx, ct, k0 + 16 * ct, nc[ct]);
+        wa.kb[ct] = k0 + 16 * ct;
+        wa.nc[ct] = nc[ct];
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->sub_ntile = ntile;
+    return launch_wide(ctx, ntile, wa);
+}
+extern "C" int asb_panel_sub_check(asb_ctx* ctx, int ct, int64_t kb, int nc, double* first_rejected_dev) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !first_rejected_dev || ct < 0 || ct >= ctx->sub_ntile) return ASB_ERR_ARG;
+    PanelState* st = sub_state(ctx, ct);
+    const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
+    const int pre = (ctx->pre_orth && ctx->correct_rows) ? 1 : 0;
+    if (!pre)
+        hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram,
+                           ctx->gram_s, ctx->wn2t3 + 16 * ct);
+    if (ctx->correct_rows) {
+        long long cwr = (ctx->n_loc + 63) / 64;
+        hipLaunchKernelGGL(k_correct_rows<true>, dim3((unsigned)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap)), dim3(192), 0, ctx->stream,
+                           ctx->comps, (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)kb, nc, ctx->gram_s, ctx->wn2t3 + 16 * ct,
+                           ctx->energy, ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, st, ctx->scalar_dev, ctx->sel_e2, ctx->e_class, pre);
+    } else {
+        long long cw = (ctx->n_loc + 255) / 256;
+        hipLaunchKernelGGL(k_correct<true>, dim3((unsigned)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap)), dim3(256), 0, ctx->stream, ctx->comps,
+                           (long long)(3 * ctx->n_loc), (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy,
+                           ctx->pmax, ctx->pidx, ctx->psum, ctx->colpart, (const long long*)nullptr, (const PanelState*)nullptr,
+                           (long long)0, st, ctx->scalar_dev, ctx->sel_e2, ctx->e_class);
+    }
+    hipLaunchKernelGGL(k_spec_count, dim3(1), dim3(1), 0, ctx->stream, st, nc, first_rejected_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+extern "C" int asb_panel_sub_commit(asb_ctx* ctx, int ct, int64_t kb, int nc, int kept) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || ct < 0 || ct >= ctx->sub_ntile || kept < 0 || kept > nc) return ASB_ERR_ARG;
+    PanelState* st = sub_state(ctx, ct);
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                       (long long)ctx->n_loc, (int)kb, st, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
+                       ctx->colpart, kept);
+    ctx->nblk = cgrid;
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, kept, (long long)kb, ctx->scal,
+                       (PanelState*)nullptr);
+    ASB_CHECK_LAUNCH(ctx);
+    if (kept > 0) ctx->k_done = kb + kept;
+    ctx->n_spec_steps += nc;
+    ctx->n_spec_kept += kept;
+    return ASB_OK;
+}
+
 // ---- guessed candidates of a first panel (see asb_project_run)
 static bool guess_possible(const asb_ctx* ctx) {
     return ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop && ctx->Fp <= 2048 && ctx->EV && ctx->e0_valid &&

@@ -207,6 +207,22 @@ class HipEngine(object):
     def panel_guess_end(self):
         self._ck(self.lib.asb_panel_guess_end(self.h))
 
+    def panel_sub_run(self, sp, k0, steps, spec_max):
+        ran, proven, cont = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        self._ck(self.lib.asb_panel_sub_run(self.h, int(sp), int(k0), int(steps), int(spec_max), ctypes.byref(ran), ctypes.byref(proven),
+                                            ctypes.byref(cont)))
+        return ran.value, proven.value, bool(cont.value)
+
+    def panel_sub_project(self, k0, ncs):
+        arr = (ctypes.c_int * len(ncs))(*[int(x) for x in ncs])
+        self._ck(self.lib.asb_panel_sub_project(self.h, int(k0), len(ncs), arr))
+
+    def panel_sub_check(self, ct, kb, nc, out_dev_ptr):
+        self._ck(self.lib.asb_panel_sub_check(self.h, int(ct), int(kb), int(nc), ctypes.c_void_p(out_dev_ptr)))
+
+    def panel_sub_commit(self, ct, kb, nc, kept):
+        self._ck(self.lib.asb_panel_sub_commit(self.h, int(ct), int(kb), int(nc), int(kept)))
+
     def panel_hist(self, level, hist_ptr=None):
         self._ck(self.lib.asb_panel_hist(self.h, int(level), ctypes.c_void_p(hist_ptr) if hist_ptr else None))
 

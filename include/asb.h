@@ -226,6 +226,21 @@ int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
 int asb_panel_guess_stats(asb_ctx* ctx, double* mean_energy_local, double* normx2_local, int* possible);
 int asb_panel_guess_begin(asb_ctx* ctx, int world);
 int asb_panel_guess_end(asb_ctx* ctx);
+/* Several sub-panels per read of X, in steps, for the multi-rank driver (what asb_deflate_run does by itself on one rank):
+ * asb_panel_sub_run      sub-panel sp = 0, 1, 2 of the read: up to `steps` greedy steps of the co-resident panel kernel on the
+ *                        assembled candidates (sp = 0) or on the rows the previous sub-panel left behind (sp > 0), up to
+ *                        spec_max of them unproven; *ran = -1: the kernel's record exchange timed out (as asb_panel_run_spec
+ *                        in assembled mode: the driver redoes the read with the kernel off on every rank); *may_continue:
+ *                        another sub-panel may follow (this one was full and ran in the co-resident kernel);
+ * asb_panel_sub_project  ONE pass over the shard for the ntile sub-panels [k0 + 16 ct, + nc[ct]);
+ * asb_panel_sub_check    tile ct against this shard's vertices: first rejected step (nc: none) into the caller's device
+ *                        double -- min-all-reduce it over the ranks;
+ * asb_panel_sub_commit   energies / column sums of the first `kept` columns of tile ct; tiles behind a tile that was not
+ *                        kept in full are dropped by the driver. */
+int asb_panel_sub_run(asb_ctx* ctx, int sp, int64_t k0, int steps, int spec_max, int64_t* ran, int64_t* proven, int* may_continue);
+int asb_panel_sub_project(asb_ctx* ctx, int64_t k0, int ntile, const int* nc);
+int asb_panel_sub_check(asb_ctx* ctx, int ct, int64_t kb, int nc, double* first_rejected_dev);
+int asb_panel_sub_commit(asb_ctx* ctx, int ct, int64_t kb, int nc, int kept);
 /* Multi-rank runs (assembled candidate buffer): a timed-out exchange is NOT redone locally -- the ranks must stay in
  * lock-step -- asb_panel_run / asb_panel_run_spec then return *committed = -1 with the kernel switched off for this context;
  * the driver min-reduces that over the ranks, switches it off everywhere (asb_panel_set_coop, returns the old setting) and
