@@ -60,8 +60,8 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     # several sub-panels per read (see the loop): only with the real engine, the co-resident kernel and device-side counts
     multi_sub = bool(spec_word is not None and hasattr(eng, "panel_sub_run") and hasattr(eng, "panel_set_coop") and
                      os.environ.get("ASB_PANEL_COOP", "1") != "0" and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0")
-    sub_max = max(1, min(3, int(os.environ.get("ASB_SUB_PANELS", "3"))))
-    sub_cur = min(sub_max, max(1, int(os.environ.get("ASB_SUB_FIRST", "3"))))
+    sub_max = max(1, min(4, int(os.environ.get("ASB_SUB_PANELS", "4"))))
+    sub_cur = min(sub_max, max(1, int(os.environ.get("ASB_SUB_FIRST", "4"))))
     sub_budget = [16] * 8
     k, stalled, forced_next = 0, 0, -1
     while k < K:

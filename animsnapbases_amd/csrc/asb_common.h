@@ -151,9 +151,9 @@ struct asb_ctx {
     int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     int pre_orth = 1;                      // multi-sub-panel reads project on pre-orthogonalised weights (ASB_PRE_ORTH=0: correct after)
-    int sub_panels = 3;                    // most sub-panels per read of X with double_panels (ASB_SUB_PANELS, 1..8; from 4 on
+    int sub_panels = 4;                    // most sub-panels per read of X with double_panels (ASB_SUB_PANELS, 1..8; from 5 on
                                            // the projection kernel needs more than 256 registers and loses what the saved read gains)
-    int sub_first = 3;                     // sub-panels of the first read (ASB_SUB_FIRST); then adapted: sub_cur
+    int sub_first = 4;                     // sub-panels of the first read (ASB_SUB_FIRST); then adapted: sub_cur
     int sub_cur = 0;
     int sub_ntile = 0;                     // tiles of the read in progress (multi-rank steps: asb_panel_sub_*)
     int sub_budget[8] = {16, 16, 16, 16, 16, 16, 16, 16};      // steps given to the later sub-panels (adapted to what the last ones kept)

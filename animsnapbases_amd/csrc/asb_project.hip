@@ -1589,6 +1589,125 @@ __global__ __launch_bounds__(512, 2) void k_project_l2b(
     }
 }
 
+// k_project_l2c: the multi-tile product with the weights staged in LDS by DIRECT loads (global_load_lds_dwordx4: no
+// registers), P chunk pairs per stage, ONE barrier per stage.  k_project_l2b showed that sharing the weights pays only if the
+// waves are not put in lock-step chunk by chunk: here a wave drifts by up to P iterations between barriers.  Block = 8 waves =
+// (row tile rt = w & 3 of 64 rows) x (frame half sub = w >> 2: chunk 2 j + sub of pair j), 256 rows per block tile; stage s
+// holds the weights of pairs [s P, s P + P) for all NCT column tiles: 4 P NCT wave-instructions of 1 KB, 1/8 of them per
+// wave, issued right behind the barrier that opens stage s - 1 -- so a whole stage of MFMAs hides them.  Their completion
+// needs no extra wait: loads retire in order, and before the barrier that opens stage s every wave has waited for X chunks
+// it requested AFTER those instructions.  LDS: 2 stages x 4 P NCT KB + 32 KB for the meeting of the two frame halves.
+template <int NCT, int P>
+__global__ __launch_bounds__(512, 2) void k_project_l2c(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
+    constexpr int NT = 4, NI = 4 * P * NCT, PER = NI / 8;       // 1-KB instructions per stage / per wave
+    static_assert(NI % 8 == 0, "stage instructions must divide over the 8 waves");
+    extern __shared__ double l2c_lds[];
+    constexpr int STAGE_D = NI * 128;                           // doubles per stage
+    typedef double (*red_t)[NT][4][64];
+    red_t red = reinterpret_cast<red_t>(l2c_lds + 2 * STAGE_D);
+    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + 2 * STAGE_D + 4 * NT * 4 * 64);
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w & 3, sub = w >> 2;
+    const long long ntiles = (rows + 255) / 256;
+    const int nchunk = Fp / 16, npair = (nchunk + 1) / 2, nstage = (npair + P - 1) / P;
+    // instruction q of a stage = ((chunk cc of the stage, column tile ct), half h of the lane's double4): lane l's 16 bytes
+    auto issue_stage = [&](int s) {
+        double* base = l2c_lds + (size_t)(s & 1) * STAGE_D;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = w * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
+            const int c = 2 * s * P + cc;
+            if (c < nchunk) {
+                const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)(base + q * 128), 16, 0, 0);
+            }
+        }
+    };
+    for (;;) {
+        if (tid == 0) tile_sh = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int t = tile_sh;
+        if ((long long)t >= ntiles) break;                      // the same for every wave of the block
+        const long long base = (long long)t * 256 + 64 * rt;
+        const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            long long r = base + 16 * m + i;
+            if (r >= rows) r = rows - 1;
+            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+        }
+        d4 acc[NT][NCT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        double4 a[NT], an[NT];
+        issue_stage(0);
+        {
+            const int c = sub < nchunk ? sub : nchunk - 1;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) a[m] = xp[m][4 * c];
+        }
+        __builtin_amdgcn_s_waitcnt(0);                          // first stage (and first X chunk) of the tile: one exposed latency
+        for (int s = 0; s < nstage; ++s) {
+            __syncthreads();            // stage s is complete in LDS (see above); the readers of stage s - 1 are done
+            if (s + 1 < nstage) issue_stage(s + 1);
+            const double* stage = l2c_lds + (size_t)(s & 1) * STAGE_D;
+            const int j1 = (s + 1) * P < npair ? (s + 1) * P : npair;
+            for (int j = s * P; j < j1; ++j) {
+                if (j + 1 < npair) {                            // the next pair's X chunk flies while this pair's MFMAs issue
+                    const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) an[m] = xp[m][4 * cn];
+                }
+                if (2 * j + sub < nchunk) {
+                    const int cc = 2 * (j - s * P) + sub;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const double* bp = stage + (size_t)((cc * NCT + ct) * 2) * 128 + l * 2;
+                        const double2 b0 = *reinterpret_cast<const double2*>(bp);
+                        const double2 b1 = *reinterpret_cast<const double2*>(bp + 128);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b0.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b0.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].z, b1.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].w, b1.y, acc[m][ct], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NT; ++m) a[m] = an[m];
+            }
+        }
+        // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            __syncthreads();
+            if (sub == 1) {
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[rt][m][q][l] = acc[m][ct][q];
+            }
+            __syncthreads();
+            if (sub == 0 && i < wa.nc[ct]) {
+                const double inv = wn2[16 * ct + i];
+                double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = (acc[m][ct][q] + red[rt][m][q][l]) / inv;
+            }
+        }
+        // the next iteration's first barrier (tile id) orders the last reads of `red` and of the stages before their reuse
+    }
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 // scal[(k0 + t) * 4 + 3] = sum over the blocks' partial column sums; one wave per column (launch with 1024 threads)
 __global__ __launch_bounds__(1024) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
@@ -1916,14 +2035,35 @@ static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
                        ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
     return ASB_OK;
 }
+template <int NCT, int P>
+static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 255) / 256;
+    const size_t lds = ((size_t)2 * 4 * P * NCT * 128 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_project_l2c<NCT, P>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(512), lds, ctx->stream,
+                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    return ASB_OK;
+}
 template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
+    if (variant == 40 && NCT <= 5)       // weights staged in LDS by direct loads, one barrier per P chunk pairs
+        return launch_l2c<(NCT <= 5 ? NCT : 2), (NCT <= 3 ? 4 : (NCT == 4 ? 3 : 2))>(ctx, wa);
+    if (variant == 41 && NCT <= 5)       // the same with shorter stages
+        return launch_l2c<(NCT <= 5 ? NCT : 2), 2>(ctx, wa);
     if (variant == 20 && NCT <= 4) return launch_l2b<(NCT <= 4 ? NCT : 2)>(ctx, wa);                               // weights shared through LDS
     if (variant == 30 && NCT <= 4) return launch_l2w_cfg<8, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 128-row tiles: half the weight traffic
     if (variant == 31 && NCT <= 4) return launch_l2w_cfg<6, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 96-row tiles
     if (variant == 3 && NCT <= 5) return launch_l2w_cfg<4, 2, 2, (NCT <= 5 ? NCT : 1), 1, 1>(ctx, wa, 2);       // two chunks per group
     if (variant == 10) return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 2>(ctx, wa, NCT <= 3 ? 4 : 2);   // HBM operand two chunks ahead
     if (variant == 5) return launch_l2w_cfg<4, 1, 2, NCT, 1, 1>(ctx, wa, 2);                                    // one wave per SIMD throughout
+    // default: up to 3 sub-panels every wave fetches its own weights (two waves per SIMD); 4 sub-panels only fit two waves per
+    // SIMD with the weights in LDS (1.83 ms against 1.96 ms with one wave per SIMD; for 2 and 3 sub-panels the LDS form loses:
+    // 1.15 / 1.32 against 1.07 / 1.22 ms)
+    if (NCT == 4) return launch_l2c<(NCT == 4 ? 4 : 2), 3>(ctx, wa);
     return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 1>(ctx, wa, NCT <= 3 ? 4 : 2);
 }
 static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {

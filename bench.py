@@ -348,7 +348,7 @@ def main():
         # this build at this shape (tools/summarise_pmc.py), an OFFLINE measurement committed under profiles/ -- counters
         # cannot be read from inside the run
         traffic, traffic_src = None, None
-        # single rank, default settings: up to three 16-column sub-panels per read of X (k_project_l2w); the multi-rank protocol
+        # default settings: up to four 16-column sub-panels per read of X (k_project_l2c / l2w); the multi-rank protocol
         # and ASB_DOUBLE_PANELS=0 read X once per 16-column panel (k_project_l2s)
         wide = (mode == "project" and pk == 3 and world == 1 and not forced and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0"
                 and os.environ.get("ASB_WIDE_VARIANT", "4") == "4")
@@ -356,8 +356,8 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
             if mode == "project" and (N, F, world) == (100000, 2000, 1) and os.environ.get("ASB_L2_VARIANT", "4") == "4":
-                if wide:        # launches with 3 and with 2 sub-panels: the average launch, as `achieved` is
-                    ks = [v for k, v in pm["kernels"].items() if k.startswith("k_project_l2w<4, 1, 2, ")]
+                if wide:        # the multi-tile launches of a step: the average launch, as `achieved` is
+                    ks = [v for k, v in pm["kernels"].items() if k.startswith("k_project_l2w<4, 1, 2, ") or k.startswith("k_project_l2c<")]
                     if ks:
                         traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 elif kname in pm["kernels"]:
@@ -384,8 +384,8 @@ def main():
                        "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
             # The dominant kernel against BOTH of its ceilings, the binding one first.  One launch reads the shard once
             # (24 n F bytes) and does 2 * 3n * F flops per component column it projects on; at the peaks that is 0.60 ms
-            # of HBM and 0.245 ms of f64 MFMA per 16 columns, so launches with 3 sub-panels (48 columns, the usual case
-            # on a single rank) are MFMA-bound and launches with 1 or 2 HBM-bound.  `bound` follows the average launch.
+            # of HBM and 0.245 ms of f64 MFMA per 16 columns, so launches with 3 or 4 sub-panels (48 / 64 columns, the usual
+            # case) are MFMA-bound and launches with 1 or 2 HBM-bound.  `bound` follows the average launch.
             "roofline": dict(
                          ([("bound", "mfma"), ("achieved", tflops), ("peak", FP64_MFMA_PEAK_TFLOPS), ("unit", "TFLOP/s"),
                            ("frac", tflops / FP64_MFMA_PEAK_TFLOPS),
@@ -396,8 +396,9 @@ def main():
                            ("mfma", ({"achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_MFMA_PEAK_TFLOPS} if (launches and mode == "project") else None))]),
                          traffic=traffic, traffic_source=traffic_src,
-                         kernel=(("k_project_l2w<4,1,2,NCT,2,1> (f64-MFMA projection on NCT <= 3 16-column sub-panels, 1 launch = one "
-                                  "read of X per up to 48 components; config 4: two launches with 3 sub-panels, one with 2)" if wide else
+                         kernel=(("k_project_l2c<4,3> / k_project_l2w<4,1,2,NCT,2,1> (f64-MFMA projection on 4 / NCT <= 3 sixteen-column "
+                                  "sub-panels, 1 launch = one read of X per up to 64 components; config 4: two launches with 4 "
+                                  "sub-panels)" if wide else
                                   {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
                                   " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep)
                                  if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
