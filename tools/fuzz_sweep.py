@@ -1,5 +1,7 @@
 """Long seeded sweep (not part of the test suite): random shapes / data kinds, both device algorithms against the
-oracle.  python tools/fuzz_sweep.py [first_seed] [count]"""
+oracle.  python tools/fuzz_sweep.py [first_seed] [count] [--big] [--prep]
+--big: shards of 20 000 .. 70 000 vertices (several sub-panels per read of X); --prep: through posSnapshots / posComponents
+(rest shape, standardisation sweep: the guessed first panel) instead of a bare upload."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -35,6 +37,49 @@ for seed in range(first, first + count):
     if kind == "scaled":
         X *= 10.0 ** rng.integers(-140, 140)
     K = int(max(1, min(rng.integers(1, 70), (min(F, 3 * N) + 1) // 2)))
+    if "--prep" in sys.argv:
+        import contextlib, io, types
+        from animsnapbases_amd import posComponents, posSnapshots
+        rest = ["first", "average"][seed % 2]
+        if kind == "scaled":
+            X = X / np.abs(X).max()               # (the reference's np.std overflows on 1e140)
+        X = X + rng.uniform(-1, 1, size=(1, N, 3)) * float(np.abs(X).max() + 1e-300) * (seed % 3)      # per-vertex offsets of varying weight
+        pre = orc.prepare_snapshots(X, rest, True)
+        if not np.all(np.isfinite(pre["snapTensor"])) or F < 3:
+            continue
+        K = int(max(1, min(K, (min(F - 1, 3 * N) + 1) // 2)))
+        ref = orc.extract_k_components(pre["snapTensor"], K)
+        if not np.all(np.isfinite(ref["comps"])):
+            continue
+        sig = ref["measures"][:, 1]
+        good = int(np.argmax(sig < 1e-9 * sig[0])) if np.any(sig < 1e-9 * sig[0]) else K
+        param = types.SimpleNamespace(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                                      q_support="global", vertPos_numComponents=K, store_vertPos_PCA_sing_val=False,
+                                      vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25, vertPos_rest_shape=rest, name="t",
+                                      vertPos_output_directory=".")
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                snaps = posSnapshots.from_arrays(X, None, rest, standarize=True, massWeight=False)
+                comp = posComponents(param, snaps)
+                comp.deflate_mode = "project"
+                comp.extract_k_components(None)
+            st = snaps._engine.deflate_stats()
+            ok_idx = comp.selected_vertices[:good].tolist() == ref["idx"][:good].tolist()
+            err = np.inf
+            if ok_idx and good:
+                comps, weigs = align_signs(comp.comps[:good], comp.weigs[:, :good], ref["comps"][:good])
+                err = max(relerr(comps, ref["comps"][:good]), relerr(weigs, ref["weigs"][:, :good]))
+            if not ok_idx or not err < 1e-7:
+                bad += 1
+                print("seed", seed, kind, rest, X.shape, K, "good", good, "idx_ok", ok_idx, "err %.2e" % err, st, flush=True)
+            elif "-v" in sys.argv:
+                print("seed", seed, kind, rest, X.shape, K, "ok %.1e" % err, st, flush=True)
+        except Exception as ex:
+            bad += 1
+            print("seed", seed, kind, rest, X.shape, K, "RAISED", repr(ex)[:200], flush=True)
+        if (seed - first) % 20 == 19:
+            print("... %d cases, %d bad, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+        continue
     ref = orc.extract_k_components(X, K)
     if not np.all(np.isfinite(ref["comps"])):
         continue
