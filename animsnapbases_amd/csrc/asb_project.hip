@@ -1597,31 +1597,34 @@ __global__ __launch_bounds__(512, 2) void k_project_l2b(
 // wave, issued right behind the barrier that opens stage s - 1 -- so a whole stage of MFMAs hides them.  Their completion
 // needs no extra wait: loads retire in order, and before the barrier that opens stage s every wave has waited for X chunks
 // it requested AFTER those instructions.  LDS: 2 stages x 4 P NCT KB + 32 KB for the meeting of the two frame halves.
-template <int NCT, int P>
-__global__ __launch_bounds__(512, 2) void k_project_l2c(
+template <int NCT, int P, int NT = 4, int RT = 4, int OCC = 2, int MODE = 0>      // RT row tiles of 16 NT rows per block, 2 RT waves; MODE: probes
+__global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
     const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
     WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
-    constexpr int NT = 4, NI = 4 * P * NCT, PER = NI / 8;       // 1-KB instructions per stage / per wave
-    static_assert(NI % 8 == 0, "stage instructions must divide over the 8 waves");
+    constexpr int NI = 4 * P * NCT, PER = NI / (2 * RT), TR = 16 * NT, BR = TR * RT;       // 1-KB instructions per stage / per wave; rows
+    static_assert(NI % (2 * RT) == 0, "stage instructions must divide over the waves");
     extern __shared__ double l2c_lds[];
     constexpr int STAGE_D = NI * 128;                           // doubles per stage
     typedef double (*red_t)[NT][4][64];
     red_t red = reinterpret_cast<red_t>(l2c_lds + 2 * STAGE_D);
-    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + 2 * STAGE_D + 4 * NT * 4 * 64);
-    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w & 3, sub = w >> 2;
-    const long long ntiles = (rows + 255) / 256;
+    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + 2 * STAGE_D + RT * NT * 4 * 64);
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w % RT, sub = w / RT;
+    const long long ntiles = (rows + BR - 1) / BR;
     const int nchunk = Fp / 16, npair = (nchunk + 1) / 2, nstage = (npair + P - 1) / P;
     // instruction q of a stage = ((chunk cc of the stage, column tile ct), half h of the lane's double4): lane l's 16 bytes
     auto issue_stage = [&](int s) {
-        double* base = l2c_lds + (size_t)(s & 1) * STAGE_D;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = w * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
             const int c = 2 * s * P + cc;
             if (c < nchunk) {
+                // by hand (m0 = LDS byte address of the instruction's 1 KB, each lane's 16 bytes behind one another): a direct
+                // load the compiler knows about is a second kind of pending vector-memory event, and with two kinds pending
+                // its waitcnt pass no longer counts -- every wait for an X chunk becomes vmcnt(0), which also waits for the
+                // chunk requested a moment ago (1.76 ms; the X prefetch then overlaps with nothing)
                 const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                 (void __attribute__((address_space(3)))*)(base + q * 128), 16, 0, 0);
+                const unsigned lds_byte = __builtin_amdgcn_readfirstlane((unsigned)(((s & 1) * STAGE_D + q * 128) * 8));
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_byte) : "m0", "memory");
             }
         }
     };
@@ -1630,7 +1633,7 @@ __global__ __launch_bounds__(512, 2) void k_project_l2c(
         __syncthreads();
         const unsigned int t = tile_sh;
         if ((long long)t >= ntiles) break;                      // the same for every wave of the block
-        const long long base = (long long)t * 256 + 64 * rt;
+        const long long base = (long long)t * BR + TR * rt;
         const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
@@ -1643,45 +1646,66 @@ __global__ __launch_bounds__(512, 2) void k_project_l2c(
         for (int m = 0; m < NT; ++m)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
-        double4 a[NT], an[NT];
+        // X chunks in two register sets used alternately (pair j computes from one while pair j + 1's chunk lands in the other):
+        // NO copy between them -- a rotation "a = an" at the end of the iteration makes the compiler spread the copies through
+        // the MFMA block, each waiting for the chunk requested a moment ago, and the prefetch overlaps with nothing.
+        double4 a0[NT], a1[NT];
         issue_stage(0);
         {
             const int c = sub < nchunk ? sub : nchunk - 1;
 #pragma unroll
-            for (int m = 0; m < NT; ++m) a[m] = xp[m][4 * c];
+            for (int m = 0; m < NT; ++m) a0[m] = xp[m][4 * c];
         }
         __builtin_amdgcn_s_waitcnt(0);                          // first stage (and first X chunk) of the tile: one exposed latency
-        for (int s = 0; s < nstage; ++s) {
-            __syncthreads();            // stage s is complete in LDS (see above); the readers of stage s - 1 are done
-            if (s + 1 < nstage) issue_stage(s + 1);
-            const double* stage = l2c_lds + (size_t)(s & 1) * STAGE_D;
-            const int j1 = (s + 1) * P < npair ? (s + 1) * P : npair;
-            for (int j = s * P; j < j1; ++j) {
-                if (j + 1 < npair) {                            // the next pair's X chunk flies while this pair's MFMAs issue
-                    const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
+        auto pair_step = [&](int j, double4 (&cur)[NT], double4 (&nxt)[NT]) {
+            const int s = j / P;
+            if (j == s * P && MODE != 5) __syncthreads();      // stage s is complete in LDS (see above); the readers of stage s - 1 are done
+            if (MODE == 3 || MODE == 4) {                       // probes: no X traffic inside the loop
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) an[m] = xp[m][4 * cn];
-                }
-                if (2 * j + sub < nchunk) {
-                    const int cc = 2 * (j - s * P) + sub;
+                for (int m = 0; m < NT; ++m) nxt[m] = cur[m];
+            } else {
+                // the next pair's X chunk flies while this pair's MFMAs issue -- UNCONDITIONALLY (behind the last pair: the last
+                // chunk once more): only if every path issues the same number of loads can the compiler wait for the
+                // current chunk with vmcnt(8) instead of vmcnt(0), which would wait for this prefetch as well
+                const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const double* bp = stage + (size_t)((cc * NCT + ct) * 2) * 128 + l * 2;
-                        const double2 b0 = *reinterpret_cast<const double2*>(bp);
-                        const double2 b1 = *reinterpret_cast<const double2*>(bp + 128);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b0.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b0.y, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].z, b1.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].w, b1.y, acc[m][ct], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < NT; ++m) a[m] = an[m];
+                for (int m = 0; m < NT; ++m) nxt[m] = xp[m][4 * cn];
             }
+            if (2 * j + sub < nchunk) {
+                const int cc = 2 * (j - s * P) + sub;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    // The weights come out of LDS by hand-written ds_read_b128: a compiler-visible LDS load behind a direct load
+                    // into the same LDS array makes the waitcnt pass wait for ALL outstanding vector loads (vmcnt(0)) in front
+                    // of it.  That the stage is complete is guaranteed by the barrier that opened it (see the header).
+                    double2 b0, b1;
+                    if (MODE == 4) {                            // probe 4: no LDS reads either
+                        b0 = make_double2(cur[0].x, cur[0].y);
+                        b1 = make_double2(cur[0].z, cur[0].w);
+                    } else {
+                        const unsigned lds_addr = (unsigned)(((s & 1) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=v"(b0), "=v"(b1) : "v"(lds_addr));
+                    }
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].x, b0.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].y, b0.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].z, b1.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].w, b1.y, acc[m][ct], 0, 0, 0);
+                    // the next stage's direct loads go out BEHIND the wait for the current X chunk (the first MFMA above): in front
+                    // of it they would be among the "newest 8" that wait lets pass, and the next X chunk would be waited for instead
+                    if (ct == 0 && j == s * P && s + 1 < nstage) issue_stage(s + 1);
+                }
+            } else if (j == s * P && s + 1 < nstage) {
+                issue_stage(s + 1);
+            }
+        };
+        for (int j = 0; j < npair; j += 2) {
+            pair_step(j, a0, a1);
+            if (j + 1 < npair) pair_step(j + 1, a1, a0);
         }
         // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
 #pragma unroll
@@ -2035,17 +2059,17 @@ static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
                        ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
     return ASB_OK;
 }
-template <int NCT, int P>
+template <int NCT, int P, int NT = 4, int RT = 4, int OCC = 2>
 static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
-    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 255) / 256;
-    const size_t lds = ((size_t)2 * 4 * P * NCT * 128 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
+    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT * RT - 1) / (16 * NT * RT);
+    const size_t lds = ((size_t)2 * 4 * P * NCT * 128 + (size_t)RT * NT * 4 * 64 + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P, NT, RT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_project_l2c<NCT, P>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(512), lds, ctx->stream,
-                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+    hipLaunchKernelGGL((k_project_l2c<NCT, P, NT, RT, OCC>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(128 * RT), lds,
+                       ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
     return ASB_OK;
 }
 template <int NCT>
@@ -2054,6 +2078,12 @@ static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
         return launch_l2c<(NCT <= 5 ? NCT : 2), (NCT <= 3 ? 4 : (NCT == 4 ? 3 : 2))>(ctx, wa);
     if (variant == 41 && NCT <= 5)       // the same with shorter stages
         return launch_l2c<(NCT <= 5 ? NCT : 2), 2>(ctx, wa);
+    if (variant == 42 && NCT == 4)       // 32-row tiles per wave, 12 waves per block: three waves per SIMD
+        return launch_l2c<4, 3, 2, 6, 3>(ctx, wa);
+    if (variant == 43 && NCT == 4)       // 48-row tiles per wave, 8 waves
+        return launch_l2c<4, 3, 3, 4, 2>(ctx, wa);
+    if (variant == 44 && NCT == 4)       // 32-row tiles per wave, 16 waves per block: four waves per SIMD
+        return launch_l2c<4, 3, 2, 8, 4>(ctx, wa);
     if (variant == 20 && NCT <= 4) return launch_l2b<(NCT <= 4 ? NCT : 2)>(ctx, wa);                               // weights shared through LDS
     if (variant == 30 && NCT <= 4) return launch_l2w_cfg<8, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 128-row tiles: half the weight traffic
     if (variant == 31 && NCT <= 4) return launch_l2w_cfg<6, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 96-row tiles
@@ -2123,8 +2153,20 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
     if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    // weights: constants (mode < 100) or pseudo-random in (-0.05, 0.05) (mode >= 100: mode - 100 is the mode proper) -- the
+    // f64 MFMA rate of this part depends on how many operand bits toggle
+    const bool random_w = mode >= 100;
+    if (random_w) mode -= 100;
     std::vector<double> ones((size_t)ASB_MAX_SUB * ctx->Fp * 16, 1.0e-3);
+    if (random_w) {
+        unsigned long long z = 0x9E3779B97F4A7C15ull;
+        for (double& v : ones) {
+            z = z * 6364136223846793005ull + 1442695040888963407ull;
+            v = ((double)(z >> 11) / 9007199254740992.0 - 0.5) * 0.1;
+        }
+    }
     ASB_HIP(ctx, hipMemcpy(ctx->Wq3, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (double& v : ones) v = 1.0e-3;
     ASB_HIP(ctx, hipMemcpy(ctx->wn2t3, ones.data(), 16 * ASB_MAX_SUB * sizeof(double), hipMemcpyHostToDevice));
     WideArgs wa{};
     for (int ct = 0; ct < nct; ++ct) { wa.kb[ct] = 16 * ct; wa.nc[ct] = 16; }
@@ -2137,9 +2179,23 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
         ASB_HIP(ctx, hipEventRecord(e0, ctx->stream));
         rc = ASB_ERR_ARG;
 #define ASB_PROBE_CASE(N)                                                           \
-        if (nct == N) rc = mode == 0 ? l2w_probe_launch<N, 0>(ctx, wa) : (mode == 1 ? l2w_probe_launch<N, 1>(ctx, wa) : l2w_probe_launch<N, 2>(ctx, wa));
+        if (nct == N && mode < 10) rc = mode == 0 ? l2w_probe_launch<N, 0>(ctx, wa) : (mode == 1 ? l2w_probe_launch<N, 1>(ctx, wa) : l2w_probe_launch<N, 2>(ctx, wa));
         ASB_PROBE_CASE(2) ASB_PROBE_CASE(3) ASB_PROBE_CASE(4)
 #undef ASB_PROBE_CASE
+        if (nct == 4 && mode >= 10) {          // k_project_l2c<4, 3>: 10 = as it runs, 13 = no X loads in the loop, 14 = nor LDS reads
+            const long long rows = 3 * ctx->n_loc, ntl = (rows + 255) / 256;
+            const size_t lds = ((size_t)2 * 4 * 3 * 4 * 128 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
+            const unsigned grid = (unsigned)(ntl < ctx->n_cu ? ntl : ctx->n_cu);
+#define ASB_L2C_PROBE(M)                                                                                                        \
+            {                                                                                                                   \
+                ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<4, 3, 4, 4, 2, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((k_project_l2c<4, 3, 4, 4, 2, M>), dim3(grid), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, \
+                                   ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);                                     \
+            }
+            if (mode == 10) ASB_L2C_PROBE(0) else if (mode == 13) ASB_L2C_PROBE(3) else if (mode == 15) ASB_L2C_PROBE(5) else ASB_L2C_PROBE(4)
+#undef ASB_L2C_PROBE
+            rc = ASB_OK;
+        }
         if (rc) return rc;
         ASB_HIP(ctx, hipEventRecord(e1, ctx->stream));
         ASB_HIP(ctx, hipEventSynchronize(e1));

@@ -24,3 +24,22 @@ for nct in (2, 3, 4):
         eng._ck(eng.lib.asb_test_l2w_probe(eng.h, nct, mode, 5, ctypes.byref(ms)))
         out.append(ms.value)
     print("tiles %d: as it runs %.3f ms | X from cache %.3f ms | loads alone %.3f ms" % (nct, *out), flush=True)
+out = []
+for mode in (10, 13, 14):
+    ms = ctypes.c_double()
+    eng._ck(eng.lib.asb_test_l2w_probe(eng.h, 4, mode, 5, ctypes.byref(ms)))
+    out.append(ms.value)
+print("k_project_l2c<4,3>: as it runs %.3f ms | no X loads inside the loop %.3f ms | nor LDS reads of the weights %.3f ms" % tuple(out), flush=True)
+out = []
+for mode in (110, 113, 114):
+    ms = ctypes.c_double()
+    eng._ck(eng.lib.asb_test_l2w_probe(eng.h, 4, mode, 5, ctypes.byref(ms)))
+    out.append(ms.value)
+print("the same with pseudo-random weights instead of constants: %.3f | %.3f | %.3f ms" % tuple(out), flush=True)
+for nct in (2, 3):
+    ms = ctypes.c_double()
+    eng._ck(eng.lib.asb_test_l2w_probe(eng.h, nct, 100, 5, ctypes.byref(ms)))
+    print("k_project_l2w, %d tiles, pseudo-random weights: as it runs %.3f ms" % (nct, ms.value), flush=True)
+ms = ctypes.c_double()
+eng._ck(eng.lib.asb_test_l2w_probe(eng.h, 4, 15, 5, ctypes.byref(ms)))
+print("k_project_l2c<4,3> without the barrier per stage (wrong results, timing only): %.3f ms" % ms.value, flush=True)
