@@ -1606,8 +1606,11 @@ __global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
     extern __shared__ double l2c_lds[];
     constexpr int STAGE_D = NI * 128;                           // doubles per stage
     typedef double (*red_t)[NT][4][64];
-    red_t red = reinterpret_cast<red_t>(l2c_lds + 2 * STAGE_D);
-    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + 2 * STAGE_D + RT * NT * 4 * 64);
+    // the meeting place of the two frame halves shares the stages' memory: it is used only behind the tile's last MFMA
+    // (a barrier in between), when no stage is being read or filled
+    constexpr int RED_D = RT * NT * 4 * 64, BODY_D = 2 * STAGE_D > RED_D ? 2 * STAGE_D : RED_D;
+    red_t red = reinterpret_cast<red_t>(l2c_lds);
+    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + BODY_D);
     const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w % RT, sub = w / RT;
     const long long ntiles = (rows + BR - 1) / BR;
     const int nchunk = Fp / 16, npair = (nchunk + 1) / 2, nstage = (npair + P - 1) / P;
@@ -1624,7 +1627,9 @@ __global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
                 // chunk requested a moment ago (1.76 ms; the X prefetch then overlaps with nothing)
                 const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
                 const unsigned lds_byte = __builtin_amdgcn_readfirstlane((unsigned)(((s & 1) * STAGE_D + q * 128) * 8));
-                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_byte) : "m0", "memory");
+                unsigned m0_keep;                                // m0 is the compiler's: put back what it held
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_keep) : "v"(src), "s"(lds_byte) : "memory");
             }
         }
     };
@@ -2062,7 +2067,8 @@ static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
 template <int NCT, int P, int NT = 4, int RT = 4, int OCC = 2>
 static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
     const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT * RT - 1) / (16 * NT * RT);
-    const size_t lds = ((size_t)2 * 4 * P * NCT * 128 + (size_t)RT * NT * 4 * 64 + 2) * sizeof(double);
+    const size_t stage2 = (size_t)2 * 4 * P * NCT * 128, redd = (size_t)RT * NT * 4 * 64;
+    const size_t lds = ((stage2 > redd ? stage2 : redd) + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P, NT, RT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2184,7 +2190,7 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
 #undef ASB_PROBE_CASE
         if (nct == 4 && mode >= 10) {          // k_project_l2c<4, 3>: 10 = as it runs, 13 = no X loads in the loop, 14 = nor LDS reads
             const long long rows = 3 * ctx->n_loc, ntl = (rows + 255) / 256;
-            const size_t lds = ((size_t)2 * 4 * 3 * 4 * 128 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
+            const size_t lds = ((size_t)2 * 4 * 3 * 4 * 128 + 2) * sizeof(double);
             const unsigned grid = (unsigned)(ntl < ctx->n_cu ? ntl : ctx->n_cu);
 #define ASB_L2C_PROBE(M)                                                                                                        \
             {                                                                                                                   \
