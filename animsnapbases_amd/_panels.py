@@ -149,7 +149,8 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
                     coop_check = multi_sub = guess_ok = False     # (unproven steps, and with them the guess, need the kernel)
                     continue                                  # the panel again, from the selection, the plain way
                 total = 0
-                if agreed > 0:
+                tiles = tiles[:agreed]                        # (identical on every rank by construction; the agreed count keeps the
+                if agreed > 0:                                # number of collectives below identical in any case)
                     eng.panel_sub_project(k, [t[1] for t in tiles])
                     full, rejected = 0, False
                     for ct, (kb, ran, proven) in enumerate(tiles):

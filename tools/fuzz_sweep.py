@@ -1,5 +1,5 @@
 """Long seeded sweep (not part of the test suite): random shapes / data kinds, both device algorithms against the
-oracle.  python tools/fuzz_sweep.py [first_seed] [count] [--big] [--prep]
+oracle.  python tools/fuzz_sweep.py [first_seed] [count] [--big] [--bigk] [--prep]
 --big: shards of 20 000 .. 70 000 vertices (several sub-panels per read of X); --prep: through posSnapshots / posComponents
 (rest shape, standardisation sweep: the guessed first panel) instead of a bare upload."""
 import sys, time
@@ -18,6 +18,8 @@ for seed in range(first, first + count):
     big = "--big" in sys.argv                 # shards large enough for super-panels (ASB_SUPER_PANELS=1)
     N = int(rng.integers(20000, 70000)) if big else int(rng.integers(1, 6000))
     F = int(rng.integers(8, 150)) if big else int(rng.integers(1, 700))
+    if "--bigk" in sys.argv:                  # reads with four sub-panels (K >= 64): odd frame counts, ragged shards
+        F = int(rng.integers(130, 330))
     kind = rng.choice(["uniform", "lowrank", "dupes", "zeros", "scaled", "smooth"])
     if kind == "lowrank":
         r = int(rng.integers(1, 20))
@@ -37,6 +39,8 @@ for seed in range(first, first + count):
     if kind == "scaled":
         X *= 10.0 ** rng.integers(-140, 140)
     K = int(max(1, min(rng.integers(1, 70), (min(F, 3 * N) + 1) // 2)))
+    if "--bigk" in sys.argv:
+        K = int(max(1, min(rng.integers(60, 150), (min(F, 3 * N) + 1) // 2)))
     if "--prep" in sys.argv:
         import contextlib, io, types
         from animsnapbases_amd import posComponents, posSnapshots
