@@ -107,7 +107,7 @@ struct asb_ctx {
     double *band_E = nullptr, *bpmax = nullptr, *bpsum = nullptr;
     long long* bpidx = nullptr;
     PanelState* bstate = nullptr;
-    double *Wt3 = nullptr, *wn2t3 = nullptr, *Wq3 = nullptr;
+    double *Wt3 = nullptr, *wn2t3 = nullptr, *Wq3 = nullptr, *gram3 = nullptr;
     int64_t forced_row = -1;      // asb_deflate_force_next: global row the next pick must take
     double* bam_val = nullptr;    // asb_deflate_block_argmax partials
     long long* bam_idx = nullptr;

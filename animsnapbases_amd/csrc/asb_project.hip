@@ -3455,6 +3455,78 @@ static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelSta
     return ASB_OK;
 }
 
+// ---- the operands of ALL tiles of a read in four launches (blockIdx.y = tile) instead of four per tile: these kernels are
+// a few microseconds of work each, their cost is the launch
+__global__ __launch_bounds__(256) void k_build_wt_tiles(const double* __restrict__ W, const double* __restrict__ scal, WideArgs wa, int Fp,
+                                                        double* __restrict__ Wt3, double* __restrict__ wn2t3) {
+    const int ct = blockIdx.y, ncols = wa.nc[ct];
+    const long long k0 = wa.kb[ct], total = (long long)Fp * ASB_PANEL_COLS;
+    double* Wt = Wt3 + (size_t)ct * Fp * 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ASB_PANEL_COLS);
+        const long long f = i / ASB_PANEL_COLS;
+        Wt[i] = (t < ncols) ? W[(k0 + t) * Fp + f] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ASB_PANEL_COLS)
+        wn2t3[16 * ct + threadIdx.x] = (threadIdx.x < ncols) ? scal[(k0 + threadIdx.x) * 4 + 1] : 1.0;
+}
+// G3[ct][j][t] = (w_j . w_t) / |w_j|^2 for j < kb[ct] + nc[ct] (k_panel_gram with scal; K rows of 16 per tile)
+__global__ __launch_bounds__(256) void k_panel_gram_tiles(const double* __restrict__ W, const double* __restrict__ Wt3, int Fp, long long K,
+                                                          WideArgs wa, const double* __restrict__ scal, double* __restrict__ G3) {
+    __shared__ double sh[4 * 16];
+    const int ct = blockIdx.y;
+    if ((long long)blockIdx.x >= wa.kb[ct] + wa.nc[ct]) return;
+    const double* wj = W + (long long)blockIdx.x * Fp;
+    const double* Wt = Wt3 + (size_t)ct * Fp * 16;
+    double acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+    for (int f = threadIdx.x; f < Fp; f += blockDim.x) {
+        const double a = wj[f];
+        const double* wt = Wt + (long long)f * ASB_PANEL_COLS;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] += a * wt[t];
+    }
+    block_sum<16>(acc, sh);
+    if (threadIdx.x < 16)
+        G3[((long long)ct * K + blockIdx.x) * 16 + threadIdx.x] = acc[threadIdx.x] / scal[(long long)blockIdx.x * 4 + 1];
+}
+__global__ __launch_bounds__(256) void k_orth_wt_tiles(const double* __restrict__ W, const double* __restrict__ G3, long long K, WideArgs wa,
+                                                       int Fp, double* __restrict__ Wt3) {
+    const int ct = blockIdx.y, ncols = wa.nc[ct];
+    const long long kb = wa.kb[ct], total = (long long)Fp * ASB_PANEL_COLS;
+    const double* G = G3 + (long long)ct * K * 16;
+    double* Wt = Wt3 + (size_t)ct * Fp * 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ASB_PANEL_COLS);
+        const long long f = i / ASB_PANEL_COLS;
+        if (t >= ncols) continue;
+        double s = 0.0, s2 = 0.0;
+        long long j = 0;
+        for (; j + 2 <= kb + t; j += 2) {
+            s += W[j * Fp + f] * G[j * 16 + t];
+            s2 += W[(j + 1) * Fp + f] * G[(j + 1) * 16 + t];
+        }
+        if (j < kb + t) s += W[j * Fp + f] * G[j * 16 + t];
+        Wt[i] -= s + s2;
+    }
+}
+__global__ __launch_bounds__(256) void k_build_wq_tiles(const double* __restrict__ Wt3, int Fp, double* __restrict__ Wq3,
+                                                        unsigned* __restrict__ tile_counter) {
+    const int ct = blockIdx.y;
+    if (blockIdx.x == 0 && ct == 0 && threadIdx.x < 16) tile_counter[threadIdx.x] = 0u;      // the projection kernel's work queue
+    const double* Wt = Wt3 + (size_t)ct * Fp * 16;
+    double* Wq = Wq3 + (size_t)ct * Fp * 16;
+    const long long total = (long long)Fp * 16;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 3), i = (int)((e >> 2) & 15), g = (int)((e >> 6) & 3);
+        const long long chunk = e >> 8;
+        Wq[e] = Wt[(chunk * 16 + 4 * g + j) * ASB_PANEL_COLS + i];
+    }
+}
+// the same through the per-tile kernels when the weights are not orthogonalised beforehand (ASB_PRE_ORTH=0 / ASB_CORRECT_ROWS=0)
+static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa);
+
 // operands of tile ct of a multi-sub-panel read; pre_orth: orthogonalised weights (k_orth_wt), see spec_tile_finish
 static void dbl_build_tile(asb_ctx* ctx, int ct, long long kb, int nc) {
     double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
@@ -3466,6 +3538,24 @@ static void dbl_build_tile(asb_ctx* ctx, int ct, long long kb, int nc) {
     }
     hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, Wt, (int)ctx->Fp, ctx->Wq3 + (size_t)ct * ctx->Fp * 16,
                        ctx->tile_counter);
+}
+static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa) {
+    if (!(ctx->pre_orth && ctx->correct_rows)) {
+        for (int ct = 0; ct < ntile; ++ct) dbl_build_tile(ctx, ct, wa.kb[ct], wa.nc[ct]);
+        ASB_CHECK_LAUNCH(ctx);
+        return ASB_OK;
+    }
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->gram3, (size_t)ASB_MAX_SUB * ctx->K * 16))) return rc;
+    const long long rows_g = wa.kb[ntile - 1] + wa.nc[ntile - 1];
+    hipLaunchKernelGGL(k_build_wt_tiles, dim3(64, ntile), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, wa, (int)ctx->Fp, ctx->Wt3, ctx->wn2t3);
+    hipLaunchKernelGGL(k_panel_gram_tiles, dim3((unsigned)rows_g, ntile), dim3(256), 0, ctx->stream, ctx->W, ctx->Wt3, (int)ctx->Fp,
+                       (long long)ctx->K, wa, ctx->scal, ctx->gram3);
+    hipLaunchKernelGGL(k_orth_wt_tiles, dim3(128, ntile), dim3(256), 0, ctx->stream, ctx->W, ctx->gram3, (long long)ctx->K, wa, (int)ctx->Fp,
+                       ctx->Wt3);
+    hipLaunchKernelGGL(k_build_wq_tiles, dim3(64, ntile), dim3(256), 0, ctx->stream, ctx->Wt3, (int)ctx->Fp, ctx->Wq3, ctx->tile_counter);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
 }
 static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
 static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
@@ -3519,11 +3609,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     // one read of X for all tiles
     WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
-        dbl_build_tile(ctx, ct, kb[ct], nc[ct]);
         wa.kb[ct] = kb[ct];
         wa.nc[ct] = nc[ct];
     }
-    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = dbl_build_tiles(ctx, ntile, wa))) return rc;
     if ((rc = launch_wide(ctx, ntile, wa))) return rc;
     int64_t total = 0;
     int full = 0;
@@ -3588,11 +3677,11 @@ extern "C" int asb_panel_sub_project(asb_ctx* ctx, int64_t k0, int ntile, const 
     WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
         if (nc[ct] < 1 || nc[ct] > ASB_PANEL_COLS || k0 + 16 * ct + nc[ct] > ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_sub_project: bad range");
-        dbl_build_tile(ctx, ct, k0 + 16 * ct, nc[ct]);
         wa.kb[ct] = k0 + 16 * ct;
         wa.nc[ct] = nc[ct];
     }
-    ASB_CHECK_LAUNCH(ctx);
+    int rc;
+    if ((rc = dbl_build_tiles(ctx, ntile, wa))) return rc;
     ctx->sub_ntile = ntile;
     return launch_wide(ctx, ntile, wa);
 }
