@@ -150,6 +150,9 @@ struct asb_ctx {
     PanelState* pstate2 = nullptr;         // double panels: the first sub-panel's state, kept for its check after the pass
     int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
+    double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
+    long long* tile_res = nullptr;         // per tile: columns kept (-1: not reached); [ASB_MAX_SUB]: the chain flag
+    int tile_chain = 1;                    // tiles of a read finished without host reads in between (ASB_TILE_CHAIN=0: one read per tile)
     int pre_orth = 1;                      // multi-sub-panel reads project on pre-orthogonalised weights (ASB_PRE_ORTH=0: correct after)
     int sub_panels = 4;                    // most sub-panels per read of X with double_panels (ASB_SUB_PANELS, 1..8; from 5 on
                                            // the projection kernel needs more than 256 registers and loses what the saved read gains)

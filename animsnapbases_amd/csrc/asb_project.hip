@@ -646,7 +646,9 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                                                       double* __restrict__ psum, double* __restrict__ colpart,
                                                       PanelState* __restrict__ spec, const double* __restrict__ sc,
                                                       const double* __restrict__ E2 = nullptr, const double* __restrict__ Ecl = nullptr,
-                                                      int pre_orth = 0) {
+                                                      int pre_orth = 0, double* __restrict__ Etmp = nullptr) {
+    // Etmp (SPEC only): besides the check, the energies AS IF every column stood go to Etmp and the block records / column
+    // sums are written as in the plain case -- k_tile_decide / k_apply_tmp adopt them if the check finds nothing
     // pre_orth: the pass projected on weights already orthogonalised against everything before them (k_orth_wt): the
     // coefficients are final, only energies / records / the check are left
     __shared__ double qs[16 * 192];
@@ -707,12 +709,24 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                     const bool outside = !(es > sc[SC_TAU]) && !(E2 && in_guess(es, E2[v], sc));
                     const double margin = spec->margin;
                     const int proven = (int)spec->proven;
+                    const double e_start = e;
+                    double loss = 0.0;
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
                         if (t < ncols) {
                             if (outside && t >= proven && t < viol && !(spec->e_win[t] > e + margin)) viol = t;
-                            e -= ((qs[t * 192 + 3 * tid] + qs[t * 192 + 3 * tid + 1]) + qs[t * 192 + 3 * tid + 2]) * wn2[t];
+                            const double q = ((qs[t * 192 + 3 * tid] + qs[t * 192 + 3 * tid + 1]) + qs[t * 192 + 3 * tid + 2]) * wn2[t];
+                            e -= q;
+                            loss += q;
+                            csum[t] += q;
                         }
+                    if (Etmp) {                                  // exactly k_commit_energy's arithmetic
+                        double en = e_start - loss;
+                        if (en < 0.0) en = 0.0;
+                        Etmp[v] = en;
+                        bsum += en;
+                        if (am_better(en, v, bmax, bidx)) { bmax = en; bidx = v; }
+                    }
                 } else {
                     double loss = 0.0;
 #pragma unroll
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
             viol = ov < viol ? ov : viol;
         }
         if (tid == 0 && viol < ASB_PANEL_COLS) atomicMin(reinterpret_cast<long long*>(&spec->spec_ok), (long long)viol);
-        return;
+        if (!Etmp) return;
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) csum[t] = wave_sum(csum[t]);
@@ -3424,6 +3438,38 @@ static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_ou
 // panel kernel writes the deflated rows back), then ONE read of X for their up to 32 columns.  The second sub-panel's
 // steps are unproven almost by construction; they are checked like any unproven step, tile by tile: the first tile's
 // check and energy update, and only if all of it stands the second tile's against the updated energies.
+// ---- tiles of a read finished WITHOUT a host read in between: the check kernel also leaves the energies as if every column
+// stood (Etmp) and the plain records / column sums; k_tile_decide (one block) looks at the check's verdict and at the chain --
+// a tile counts only if every tile before it stood in full --, writes the column sums and res[ct] = columns kept (-1: not
+// reached); k_apply_tmp adopts Etmp if the tile stood in full.  The host reads res[] once per read of X; a tile that did not
+// stand in full (rare) is then committed the slow way (k_commit_energy), its energies being untouched.
+__global__ __launch_bounds__(1024) void k_tile_decide(const double* __restrict__ colpart, int nblk, int ct, long long kb,
+                                                      double* __restrict__ scal, PanelState* __restrict__ st, long long* __restrict__ res) {
+    __shared__ int full_sh;
+    if (threadIdx.x == 0) {
+        const bool chain = ct == 0 || res[ASB_MAX_SUB] != 0;            // res[ASB_MAX_SUB]: every tile so far stood in full
+        const int ran = (int)st->committed, ok = (int)(st->spec_ok < st->committed ? st->spec_ok : st->committed);
+        const int full = chain && ok == ran;
+        res[ct] = chain ? ok : -1;
+        res[ASB_MAX_SUB] = full;
+        st->committed = chain ? ok : 0;
+        full_sh = full ? ran : 0;
+    }
+    __syncthreads();
+    const int ncols = full_sh;
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (t >= ncols) return;
+    double v = 0.0;
+    for (int b = lane; b < nblk; b += 64) v += colpart[(long long)b * 16 + t];
+    v = wave_sum(v);
+    if (lane == 0) scal[(kb + t) * 4 + 3] = v;
+}
+__global__ __launch_bounds__(256) void k_apply_tmp(double* __restrict__ E, const double* __restrict__ Etmp, long long n,
+                                                   const long long* __restrict__ res) {
+    if (res[ASB_MAX_SUB] == 0) return;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) E[v] = Etmp[v];
+}
+
 static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelState* st, int64_t* kept) {
     const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
     const int pre = (ctx->pre_orth && ctx->correct_rows) ? 1 : 0;
@@ -3617,7 +3663,54 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     int64_t total = 0;
     int full = 0;
     bool rejected = false;
-    for (int ct = 0; ct < ntile; ++ct) {
+    const bool chained = ctx->pre_orth && ctx->correct_rows && ctx->tile_chain;
+    if (chained) {
+        // all tiles enqueued back to back, ONE host read
+        if ((rc = asb_alloc(ctx, &ctx->e_tmp, (size_t)ctx->n_loc))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
+        long long cwr = (ctx->n_loc + 63) / 64;
+        const int rgrid = (int)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap);
+        long long cw = (ctx->n_loc + 255) / 256;
+        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+        for (int ct = 0; ct < ntile; ++ct) {
+            hipLaunchKernelGGL(k_correct_rows<true>, dim3(rgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                               (long long)ctx->n_loc, (int)kb[ct], nc[ct], ctx->gram_s, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
+                               ctx->psum, ctx->colpart, st[ct], ctx->scalar_dev, ctx->sel_e2, ctx->e_class, 1, ctx->e_tmp);
+            hipLaunchKernelGGL(k_tile_decide, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, rgrid, ct, (long long)kb[ct], ctx->scal, st[ct],
+                               ctx->tile_res);
+            hipLaunchKernelGGL(k_apply_tmp, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->energy, ctx->e_tmp, (long long)ctx->n_loc, ctx->tile_res);
+        }
+        ASB_CHECK_LAUNCH(ctx);
+        long long res[ASB_MAX_SUB + 1];
+        if ((rc = fetch_words(ctx, ctx->tile_res, ASB_MAX_SUB + 1, res))) return rc;
+        ctx->nblk = rgrid;                           // the records of the last tile that stood in full
+        for (int ct = 0; ct < ntile; ++ct) {
+            int64_t kept = res[ct] < 0 ? 0 : res[ct];
+            if (res[ct] >= 0 && kept < nc[ct]) {     // this tile did not stand in full: its energies are untouched, commit the head
+                hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                                   (long long)ctx->n_loc, (int)kb[ct], st[ct], ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
+                                   ctx->psum, ctx->colpart, (int)kept);
+                ctx->nblk = cgrid;
+                hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, (int)kept, kb[ct], ctx->scal,
+                                   (PanelState*)nullptr);
+                ASB_CHECK_LAUNCH(ctx);
+            }
+            if (res[ct] < 0) break;                  // behind a tile that did not stand
+            ctx->n_spec_steps += nc[ct] - proven[ct];
+            ctx->n_spec_kept += kept > proven[ct] ? kept - proven[ct] : 0;
+            total += kept;
+            if (getenv("ASB_DEBUG_PANELS"))
+                fprintf(stderr, "[asb] panel at k=%lld tile %d: %d proven + %lld of %d unproven steps kept\n", k, ct, proven[ct],
+                        (long long)(kept > proven[ct] ? kept - proven[ct] : 0), nc[ct] - proven[ct]);
+            if (ct >= 1) {
+                const int want = (int)kept + 2;
+                ctx->sub_budget[ct] = want < 4 ? 4 : (want > ASB_PANEL_COLS ? ASB_PANEL_COLS : want);
+            }
+            if (kept < nc[ct]) { rejected = true; break; }
+            ++full;
+        }
+    }
+    for (int ct = 0; ct < ntile && !chained; ++ct) {
         int64_t kept = 0;
         if ((rc = spec_tile_finish(ctx, ct, kb[ct], nc[ct], st[ct], &kept))) return rc;
         ctx->n_spec_steps += nc[ct] - proven[ct];
