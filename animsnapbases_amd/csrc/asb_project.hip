@@ -3669,7 +3669,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if ((rc = asb_alloc(ctx, &ctx->e_tmp, (size_t)ctx->n_loc))) return rc;
         if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
         long long cwr = (ctx->n_loc + 63) / 64;
-        const int rgrid = (int)(cwr < ctx->nblk_cap ? cwr : ctx->nblk_cap);
+        // (two blocks per CU, grid-strided: the one-block k_tile_decide sums a partial per block and column)
+        const int rgrid = (int)(cwr < 2 * ctx->n_cu ? cwr : 2 * ctx->n_cu);
         long long cw = (ctx->n_loc + 255) / 256;
         const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
         for (int ct = 0; ct < ntile; ++ct) {
