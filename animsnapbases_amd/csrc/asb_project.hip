@@ -386,13 +386,20 @@ __global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ 
 __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
                             long long n_slots, double margin_rel, unsigned* __restrict__ coop_flags,
                             unsigned long long* __restrict__ coop_rec, int n_rec, int theta_from_band = 0,
-                            long long spec_max = 0) {
-    // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4)
-    if (coop_flags && threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
+                            long long spec_max = 0, const PanelState* __restrict__ prev = nullptr) {
+    // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4).
+    // prev: this sub-panel was enqueued behind another one without a host read in between (sub_chain_run): the flags stay as
+    // they are, and unless that one ran its 16 steps in the kernel the launch that follows is given nothing to do
+    if (coop_flags && threadIdx.x < 4 && prev == nullptr) coop_flags[threadIdx.x] = 0u;
     if (coop_rec)
         for (int r = threadIdx.x; r < n_rec; r += blockDim.x) coop_rec[(size_t)r * 8 + 4] = 0ull;
     if (threadIdx.x != 0) return;
     if (n_slots >= 0) panel->n_cand = n_slots;
+    // (bit 1 of `pad` = "nothing to do": like an overflowed selection it makes every step unprovable and forbids unproven ones,
+    // so the kernel commits nothing and writes nothing back; a launch that is not chained clears it)
+    if (prev == nullptr) panel->pad &= 1;
+    else if (prev->committed < ASB_PANEL_COLS || prev->proven < 0 || (prev->pad & 2) || (coop_flags && (coop_flags[1] | coop_flags[2])))
+        panel->pad |= 2;
     // later sub-panels of a super-panel: every vertex outside candidates and band is below tau2 (stale but valid), the
     // band's energies are exact (k_correct on the band after every sub-panel)
     panel->theta = global_all ? -1.0e300
@@ -3603,6 +3610,67 @@ static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
+// The sub-panels of a read enqueued back to back -- arm + panel kernel per sub-panel, no host read in between: a later one is
+// given nothing to do (k_panel_arm with `prev`) unless the one before it ran its 16 steps in the kernel.  The states are read
+// afterwards, all at once.  *ntile = -1: the first launch did not run (record exchange timed out / more candidates than
+// resident waves): nothing has been written back, the caller takes the one-by-one path with its fallbacks.
+static int sub_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven) {
+    int rc;
+    *ntile = -1;
+    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ASB_PANEL_COLS * ctx->m_cap * 3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->slab_scratch, (size_t)3 * ctx->Fp))) return rc;
+    const int cgrid_all = (int)((ctx->m_cap + 3) / 4);
+    if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 12))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid_all * 8))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid_all * ctx->Fp))) return rc;
+    int nrun = 0;
+    for (int sp = 0; sp < nsub_max && k + (long long)sp * ASB_PANEL_COLS < k1; ++sp) {
+        const long long kb = k + (long long)sp * ASB_PANEL_COLS;
+        int steps = (int)((k1 - kb) < ASB_PANEL_COLS ? (k1 - kb) : ASB_PANEL_COLS);
+        if (sp > 0) {
+            if (steps > ctx->sub_budget[sp]) steps = ctx->sub_budget[sp];
+            ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, 0, (long long)-1, ASB_MARGIN_REL,
+                           ctx->coop_bar, (unsigned long long*)ctx->coop_rec, 2 * cgrid_all, 0,
+                           (long long)(sp == 0 ? ctx->spec_budget : ASB_PANEL_COLS), sp > 0 ? ctx->pstate2 + (sp - 1) : (const PanelState*)nullptr);
+        bool launched = false;
+        rc = launch_panel_coop<32>(ctx, cgrid_all, kb, steps, &launched, true);
+        if (rc) return rc;
+        if (!launched) return ASB_OK;                  // (no occupancy: the one-by-one path decides)
+        ++nrun;
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    PanelState h[ASB_MAX_SUB];
+    unsigned flags[4] = {0, 0, 0, 0};
+    for (int sp = 0; sp < nrun; ++sp) {
+        const bool last = sp == nrun - 1;
+        if ((rc = read_panel_state_from(ctx, last ? ctx->pstate : ctx->pstate2 + sp, &h[sp], last ? flags : nullptr))) return rc;
+    }
+    ctx->n_panels++;
+    ctx->run_coop_used = 1;
+    ctx->sub_nrun = nrun;
+    int nt = 0;
+    for (int sp = 0; sp < nrun; ++sp) {
+        if (h[sp].proven < 0) {                          // this launch did not finish (the flags say why)
+            if (sp == 0) return ASB_OK;                  // *ntile = -1
+            // a later one timed out: the sub-panels before it stand (their rows were written back); the context leaves the
+            // kernel like asb_panel_run does
+            ctx->panel_coop = 0;
+            ctx->coop_test_stall = 0;
+            ctx->n_coop_fallbacks++;
+            break;
+        }
+        if (h[sp].committed <= 0) break;
+        nc[nt] = (int)h[sp].committed;
+        proven[nt] = (int)((h[sp].proven > h[sp].committed) ? h[sp].committed : h[sp].proven);
+        ++nt;
+        if (h[sp].committed < ASB_PANEL_COLS) break;
+    }
+    (void)flags;
+    *ntile = nt;
+    return ASB_OK;
+}
 static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
 static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
     int rc;
@@ -3623,7 +3691,14 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     int nc[ASB_MAX_SUB] = {0}, proven[ASB_MAX_SUB] = {0};
     for (int sp = 0; sp < ASB_MAX_SUB; ++sp) kb[sp] = k + (long long)sp * ASB_PANEL_COLS;
     int ntile = 0;
-    for (int sp = 0; sp < nsub_max && kb[sp] < k1; ++sp) {
+    bool chained_runs = false;
+    if (ctx->sub_chain && ctx->panel_coop && ctx->spec_panels && ctx->Fp > 1024 && ctx->Fp <= 2048 && nsub_max > 1) {
+        int nt = -1;
+        if ((rc = sub_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven))) return rc;
+        if (nt == 0) return ASB_OK;                      // nothing committed: the caller's refresh / forced path
+        if (nt > 0) { ntile = nt; chained_runs = true; }
+    }
+    for (int sp = 0; !chained_runs && sp < nsub_max && kb[sp] < k1; ++sp) {
         int steps = (int)((k1 - kb[sp]) < ASB_PANEL_COLS ? (k1 - kb[sp]) : ASB_PANEL_COLS);
         if (sp > 0) {
             // the earlier sub-panel's state (winner energies, provable head) is needed again after the pass
@@ -3651,7 +3726,9 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if (ran < ASB_PANEL_COLS || !ctx->run_coop_used || !ctx->spec_panels) break;
     }
     PanelState* st[ASB_MAX_SUB];
-    for (int ct = 0; ct < ntile; ++ct) st[ct] = ct < ntile - 1 ? ctx->pstate2 + ct : ctx->pstate;
+    // (chained runs: sub-panel sp's state was copied aside iff another launch followed it, whether or not that one did anything)
+    const int nlaunch = chained_runs ? ctx->sub_nrun : ntile;
+    for (int ct = 0; ct < ntile; ++ct) st[ct] = ct < nlaunch - 1 ? ctx->pstate2 + ct : ctx->pstate;
     // one read of X for all tiles
     WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
