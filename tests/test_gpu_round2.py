@@ -258,3 +258,30 @@ def test_reads_with_several_sub_panels_project_on_orthogonalised_weights(kind, m
     assert outs["1"][2] == outs["0"][2]               # the same panels either way
     if kind == "uniform":
         assert outs["1"][2] <= 4                      # reads of X: 60 components would take four 16-column panels at the least
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lowrank_noise"])
+def test_reads_finished_on_the_device_match_the_step_by_step_path(kind, monkeypatch):
+    """By default the sub-panel runs and the tiles of a read are enqueued back to back and read once (ASB_SUB_CHAIN /
+    ASB_TILE_CHAIN); with both off every sub-panel run and every tile costs a host read.  Same panels, same basis --
+    on data where every tile stands (uniform) and on data where reads are cut short by rejections (low rank + noise: the
+    tile that does not stand in full is committed the slow way from untouched energies)."""
+    rng = np.random.default_rng(41)
+    F, N, K = 1100, 9000, 70                     # F > 1024: the panel kernel's NJ = 32 form, which the chained runs use
+    if kind == "uniform":
+        verts = rng.uniform(-1, 1, size=(F, N, 3))
+    else:
+        verts = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=24, noise=1e-4, seed=41)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    outs = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("ASB_SUB_CHAIN", chain)
+        monkeypatch.setenv("ASB_TILE_CHAIN", chain)
+        comp, st = _run(verts, K)
+        _check(comp, d, tol=1e-9 if kind == "uniform" else 1e-8)
+        outs[chain] = (comp.comps.copy(), comp.weigs.copy(), comp.measures_at_largeDeforVerts.copy(), st[0])
+    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert relerr(outs["1"][2][:, 1:], outs["0"][2][:, 1:]) < 1e-12          # (column sums: other block partials)
+    assert outs["1"][3]["panels"] == outs["0"][3]["panels"]
+    if kind == "uniform":
+        assert outs["1"][3]["panels"] <= 3
