@@ -1,5 +1,5 @@
 """Long seeded sweeps of the other paths (not part of the test suite):
-   python tools/fuzz_sweep_more.py multirank|local|constraints|linalg [first_seed] [count]"""
+   python tools/fuzz_sweep_more.py multirank|local|constraints|linalg [first_seed] [count] [--big]"""
 import contextlib, io, sys, time, types
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -35,6 +35,10 @@ for seed in range(first, first + count):
             N, F = int(rng.integers(world, 4000)), int(rng.integers(2, 300))
             K = int(max(1, min(rng.integers(1, 40), (min(F - 1, 3 * N) + 1) // 2)))
             mode = ["project", "residual"][seed % 2]
+            if "--big" in sys.argv:               # shards above the candidate capacity: guessed first panel, several sub-panels per read
+                N, F = int(rng.integers(4000, 30000)), int(rng.integers(40, 300))
+                K = int(max(1, min(rng.integers(20, 90), (F - 1) // 2)))
+                mode = "project"
             rest = str(rng.choice(["first", "average"]))
             verts = rng.uniform(-1, 1, size=(F, N, 3)) * rng.uniform(0.2, 1, size=(1, N, 1))
             param = pparam(vertPos_numComponents=K, vertPos_rest_shape=rest)
