@@ -3635,7 +3635,10 @@ static int sub_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, 
                            ctx->coop_bar, (unsigned long long*)ctx->coop_rec, 2 * cgrid_all, 0,
                            (long long)(sp == 0 ? ctx->spec_budget : ASB_PANEL_COLS), sp > 0 ? ctx->pstate2 + (sp - 1) : (const PanelState*)nullptr);
         bool launched = false;
-        rc = launch_panel_coop<32>(ctx, cgrid_all, kb, steps, &launched, true);
+        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid_all, kb, steps, &launched, true);
+        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid_all, kb, steps, &launched, true);
+        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid_all, kb, steps, &launched, true);
+        else rc = launch_panel_coop<32>(ctx, cgrid_all, kb, steps, &launched, true);
         if (rc) return rc;
         if (!launched) return ASB_OK;                  // (no occupancy: the one-by-one path decides)
         ++nrun;
@@ -3692,7 +3695,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     for (int sp = 0; sp < ASB_MAX_SUB; ++sp) kb[sp] = k + (long long)sp * ASB_PANEL_COLS;
     int ntile = 0;
     bool chained_runs = false;
-    if (ctx->sub_chain && ctx->panel_coop && ctx->spec_panels && ctx->Fp > 1024 && ctx->Fp <= 2048 && nsub_max > 1) {
+    if (ctx->sub_chain && ctx->panel_coop && ctx->spec_panels && ctx->Fp <= 2048 && nsub_max > 1) {
         int nt = -1;
         if ((rc = sub_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven))) return rc;
         if (nt == 0) return ASB_OK;                      // nothing committed: the caller's refresh / forced path

@@ -267,7 +267,7 @@ def test_reads_finished_on_the_device_match_the_step_by_step_path(kind, monkeypa
     on data where every tile stands (uniform) and on data where reads are cut short by rejections (low rank + noise: the
     tile that does not stand in full is committed the slow way from untouched energies)."""
     rng = np.random.default_rng(41)
-    F, N, K = 1100, 9000, 70                     # F > 1024: the panel kernel's NJ = 32 form, which the chained runs use
+    F, N, K = (1100, 9000, 70) if kind == "uniform" else (300, 16000, 70)      # both register layouts of the panel kernel
     if kind == "uniform":
         verts = rng.uniform(-1, 1, size=(F, N, 3))
     else:
