@@ -42,7 +42,9 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     packed_ok = hasattr(eng, "panel_assemble_packed")
     spec_word = torch.zeros(1, dtype=torch.float64, device=dev) if (hasattr(eng, "panel_project_spec_dev") and dev.type != "cpu") else None
     # the reduced word comes back through the engine's polled pinned slot when the collective ran on the engine's stream
-    same_stream = spec_word is not None and hasattr(eng, "fetch_double") and getattr(comm, "on_engine_stream", True)
+    # (a communicator that cannot say so -- or an engine on another stream -- gets the synchronising read)
+    oes = getattr(comm, "on_engine_stream", None)
+    same_stream = spec_word is not None and hasattr(eng, "fetch_double") and bool(oes(eng) if callable(oes) else oes)
     read_word = (lambda: eng.fetch_double(spec_word.data_ptr())) if same_stream else (lambda: spec_word.item())
     # lock-step protection of the co-resident panel kernel (see below): only with the real engine, several ranks, kernel on
     coop_check = bool(spec_word is not None and comm.multi and hasattr(eng, "panel_set_coop") and

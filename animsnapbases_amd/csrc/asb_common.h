@@ -64,6 +64,8 @@ struct asb_ctx {
     int first_panel_mean = 1;   // ASB_FIRST_PANEL_MEAN=0: first panel from the initial energies alone
     const double* sel_e2 = nullptr;      // != NULL while a panel's candidates are { E > tau } u { sel_e2 > tau_v }
     bool e0_valid = false;
+    bool ev_valid = false;          // EV / mean_energy / prep_normx2 describe the CURRENT tensor (set by asb_snapshots_scale only; every
+                                    // writer of X and asb_project_begin's own energy pass clear it)
     int64_t n_energy_pass = 0;  // reads of X the last asb_deflate_begin spent on initial energies (statistics)
 
     // ---- reduction scratch ----
@@ -78,9 +80,8 @@ struct asb_ctx {
     int64_t K = 0;
     int mode = 0, local = 0;
     int64_t k_done = 0;
-    unsigned* coop_bar = nullptr;     // k_panel_coop: [arrivals, abort flag]
+    unsigned* coop_bar = nullptr;     // k_panel_multi: flags [-, abort, too many candidates, -] + debug timestamps
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
-    double* coop_w = nullptr;         // (2, grid, Fp) tentative weights
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
     int e0_reuse = 1;                 // ASB_E0_REUSE=0 -> asb_project_begin always re-reads X for the initial energies
     int correct_rows = 1;             // ASB_CORRECT_ROWS=0 -> the one-thread-per-vertex correction kernel (k_correct)
@@ -152,7 +153,6 @@ struct asb_ctx {
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
     long long* tile_res = nullptr;         // per tile: columns kept (-1: not reached); [ASB_MAX_SUB]: the chain flag
-    int sub_nrun = 0;                      // launches of the last chained run
     int sub_chain = 1;                     // the sub-panels of a read enqueued without host reads in between (ASB_SUB_CHAIN=0: one by one)
     int tile_chain = 1;                    // tiles of a read finished without host reads in between (ASB_TILE_CHAIN=0: one read per tile)
     int pre_orth = 1;                      // multi-sub-panel reads project on pre-orthogonalised weights (ASB_PRE_ORTH=0: correct after)
@@ -294,6 +294,68 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Wave-wide reductions without the LDS crossbar (gfx950): four DPP stages inside a row of 16 lanes (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror), then v_permlane16_swap / v_permlane32_swap across rows -- a stage is two 32-bit moves and an
+// add instead of two ds_bpermute round trips (~6 x 120 cycles for a butterfly of __shfl_xor).  Every stage combines two
+// values that are each identical in the lanes they come from, so all 64 lanes end with bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// the two values a lane sees after the swap: (own, partner) for rows (16) / halves (32)
+__device__ __forceinline__ void swap16_f64(double v, double& a, double& b) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void swap32_f64(double v, double& a, double& b) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+template <int NV>
+__device__ __forceinline__ void wave_sum_dpp(double (&v)[NV]) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] += dpp_mov_f64<0xB1>(v[q]);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] += dpp_mov_f64<0x4E>(v[q]);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] += dpp_mov_f64<0x141>(v[q]);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] += dpp_mov_f64<0x140>(v[q]);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { double a, b; swap16_f64(v[q], a, b); v[q] = a + b; }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { double a, b; swap32_f64(v[q], a, b); v[q] = a + b; }
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    double a, b;
+    swap16_f64(v, a, b); v = fmax(a, b);
+    swap32_f64(v, a, b); v = fmax(a, b);
+    return v;
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
+    auto s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)s[0], (int)s[1]);
+    s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return min((int)s[0], (int)s[1]);
 }
 
 // Block-wide sum of NV values per thread; result valid in every thread.

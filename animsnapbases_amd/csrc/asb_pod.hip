@@ -98,7 +98,7 @@ extern "C" int asb_snapshots_affine(asb_ctx* ctx, double inv_scale, int add_mean
     }
     long long want = (ctx->n_loc * 3 + 3) / 4;
     const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
-    ctx->e0_valid = false;
+    { ctx->e0_valid = false; ctx->ev_valid = false; }
     hipLaunchKernelGGL(k_affine_rows, dim3(grid), dim3(256), 0, ctx->stream, ctx->X, (long long)ctx->n_loc * 3, (int)ctx->F,
                        (int)ctx->Fp, inv_scale, add_mean ? ctx->mean : nullptr, rs);
     ASB_CHECK_LAUNCH(ctx);

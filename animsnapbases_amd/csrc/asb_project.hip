@@ -385,21 +385,16 @@ __global__ __launch_bounds__(64) void k_compact_b(const long long* __restrict__ 
 // arms the panel: every vertex outside the candidate buffer has energy <= theta
 __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ panel, const double* __restrict__ sc, int global_all,
                             long long n_slots, double margin_rel, unsigned* __restrict__ coop_flags,
-                            unsigned long long* __restrict__ coop_rec, int n_rec, int theta_from_band = 0,
-                            long long spec_max = 0, const PanelState* __restrict__ prev = nullptr) {
-    // the co-resident panel kernel's flags and record sequence numbers (CoopRec = 8 words, seq = word 4).
-    // prev: this sub-panel was enqueued behind another one without a host read in between (sub_chain_run): the flags stay as
-    // they are, and unless that one ran its 16 steps in the kernel the launch that follows is given nothing to do
-    if (coop_flags && threadIdx.x < 4 && prev == nullptr) coop_flags[threadIdx.x] = 0u;
-    if (coop_rec)
-        for (int r = threadIdx.x; r < n_rec; r += blockDim.x) coop_rec[(size_t)r * 8 + 4] = 0ull;
+                            unsigned long long* __restrict__ coop_words, int n_words, int theta_from_band = 0,
+                            long long spec_max = 0) {
+    // the co-resident panel kernel's flags; its exchange words (records + weight buffers) start out as "not written"
+    // (k_panel_multi: all bits set -- a NaN no energy or weight can be, -1 for slots)
+    if (coop_flags && threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
+    if (coop_words)
+        for (int r = threadIdx.x; r < n_words; r += blockDim.x) coop_words[r] = 0xFFFFFFFFFFFFFFFFull;
     if (threadIdx.x != 0) return;
     if (n_slots >= 0) panel->n_cand = n_slots;
-    // (bit 1 of `pad` = "nothing to do": like an overflowed selection it makes every step unprovable and forbids unproven ones,
-    // so the kernel commits nothing and writes nothing back; a launch that is not chained clears it)
-    if (prev == nullptr) panel->pad &= 1;
-    else if (prev->committed < ASB_PANEL_COLS || prev->proven < 0 || (prev->pad & 2) || (coop_flags && (coop_flags[1] | coop_flags[2])))
-        panel->pad |= 2;
+    panel->pad &= 1;
     // later sub-panels of a super-panel: every vertex outside candidates and band is below tau2 (stale but valid), the
     // band's energies are exact (k_correct on the band after every sub-panel)
     panel->theta = global_all ? -1.0e300
@@ -1624,6 +1619,10 @@ __global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
     WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
     constexpr int NI = 4 * P * NCT, PER = NI / (2 * RT), TR = 16 * NT, BR = TR * RT;       // 1-KB instructions per stage / per wave; rows
     static_assert(NI % (2 * RT) == 0, "stage instructions must divide over the waves");
+    // the direct loads of stage s + 1 are never waited for explicitly: they are complete at the barrier that opens stage s + 1
+    // because every wave waits for an X chunk it requested AFTER them -- which needs a later pair in the same stage
+    static_assert(P >= 2, "a stage must hold at least two chunk pairs (completion of the direct loads, see the header)");
+    static_assert(2 * NI * 128 * 8 <= 160 * 1024, "both stages must fit the LDS range M0 addresses (gfx950: 160 KB)");
     extern __shared__ double l2c_lds[];
     constexpr int STAGE_D = NI * 128;                           // doubles per stage
     typedef double (*red_t)[NT][4][64];
@@ -1711,7 +1710,7 @@ __global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
                     } else {
                         const unsigned lds_addr = (unsigned)(((s & 1) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
                         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=v"(b0), "=v"(b1) : "v"(lds_addr));
+                                     : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));      // early-clobber: neither may share the address register
                     }
 #pragma unroll
                     for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].x, b0.x, acc[m][ct], 0, 0, 0);
@@ -1911,6 +1910,48 @@ static int fetch_words(asb_ctx* ctx, const void* dev, int n, void* host) {
     return ASB_OK;
 }
 
+// the summary of a k_panel_multi launch in ONE read: word sp = committed | (proven + 1) << 32 of sub-panel sp
+// (proven + 1 = 0: that sub-panel did not finish), word 8 = the kernel's flags [1] | [2] << 1
+__global__ __launch_bounds__(64) void k_publish_multi(const PanelState* __restrict__ sub, const unsigned* __restrict__ flags,
+                                                      unsigned char* __restrict__ pin, unsigned long long seq) {
+    const int l = threadIdx.x;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(pin + 512);
+    if (l < 8) dst[l] = (unsigned long long)sub[l].committed | ((unsigned long long)(sub[l].proven + 1) << 32);
+    if (l == 8) dst[8] = (unsigned long long)(flags[1] ? 1u : 0u) | ((unsigned long long)(flags[2] ? 1u : 0u) << 1);
+    __threadfence_system();
+    __syncthreads();
+    if (l == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(pin + 648), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int fetch_multi(asb_ctx* ctx, unsigned long long* out9) {
+    int rc = asb_pin_alloc(ctx);
+    if (rc) return rc;
+    if (ctx->host_poll && ctx->host_pin_dev) {
+        const unsigned long long seq = ++ctx->pin_seq;
+        hipLaunchKernelGGL(k_publish_multi, dim3(1), dim3(64), 0, ctx->stream, ctx->pstate2, ctx->coop_bar, ctx->host_pin_dev, seq);
+        ASB_CHECK_LAUNCH(ctx);
+        volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->host_pin + 648);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (*word == seq) { arrived = true; break; }
+            if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!arrived) ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out9, ctx->host_pin + 512, 9 * 8);
+        return ASB_OK;
+    }
+    PanelState h[8];
+    unsigned fl[4];
+    ASB_HIP(ctx, hipMemcpyAsync(h, ctx->pstate2, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(fl, ctx->coop_bar, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < 8; ++l) out9[l] = (unsigned long long)h[l].committed | ((unsigned long long)(h[l].proven + 1) << 32);
+    out9[8] = (unsigned long long)(fl[1] ? 1u : 0u) | ((unsigned long long)(fl[2] ? 1u : 0u) << 1);
+    return ASB_OK;
+}
+
 // second half of a pass with unproven steps: energies of the columns that stood (force_ncols < 0: the count the check
 // left on the device; otherwise the host's value, e.g. the minimum over the ranks), column sums, *kept
 static int project_commit(asb_ctx* ctx, long long k0, int force_ncols, int64_t* kept) {
@@ -2062,7 +2103,8 @@ template <int NT, int G, int S, int NCT, int OCC, int PD>
 static int launch_l2w_cfg(asb_ctx* ctx, const WideArgs& wa, int blocks_per_cu) {
     const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT - 1) / (16 * NT);
     const size_t lds = ((size_t)(S - 1) * NT * NCT * 4 * 64 + 2) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
     if (!attr_set) {
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2w<NT, G, S, NCT, OCC, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -2076,7 +2118,8 @@ template <int NCT>
 static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
     const long long rows = 3 * ctx->n_loc, ntiles = (rows + 255) / 256;
     const size_t lds = ((size_t)2 * 2 * NCT * 64 * 4 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
     if (!attr_set) {
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2b<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -2090,7 +2133,8 @@ static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
     const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT * RT - 1) / (16 * NT * RT);
     const size_t stage2 = (size_t)2 * 4 * P * NCT * 128, redd = (size_t)RT * NT * 4 * 64;
     const size_t lds = ((stage2 > redd ? stage2 : redd) + 2) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
     if (!attr_set) {
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P, NT, RT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -2261,7 +2305,8 @@ static int launch_project_lds(asb_ctx* ctx, int ncols, double* out) {
     if (nsweep > 1 && (rc = asb_alloc(ctx, &ctx->ypart, (size_t)((rows + 15) / 16) * 256))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     const size_t lds = (size_t)cs * 16 * 16 * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
     if (!attr_set) {
         ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 63 * 256 * 8));
         attr_set = true;
@@ -2417,6 +2462,7 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     ASB_CHECK_LAUNCH(ctx);
     ctx->n_energy_pass = 1;
     ctx->mean_frac = 0.0;          // EV comes with the standardisation sweep only
+    ctx->ev_valid = false;
     if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)4))) return rc;
     ASB_HIP(ctx, hipMemcpyAsync(ctx->E0, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2883,43 +2929,76 @@ extern "C" int asb_panel_global_tau(asb_ctx* ctx, const double* tab_dev, int wor
     return ASB_OK;
 }
 
-// --------------------------------------------------------------------------------------
-// k_panel_coop: the whole inner loop of a panel (up to 16 greedy steps) in ONE launch of co-resident blocks.
-// Every candidate row triple lives in the REGISTERS of one wave for the whole panel (lane l holds frames
-// l + 64 j: 3 x NJ doubles), so a step touches no HBM:
-//   1. each block takes its best candidate (exact energy = sum of squares of the registers); that wave does the 3 x 3
-//      Gram / eigen-pair / w = u^T slab and publishes the record [energy, slot, lambda, |w|^2, w] -- like the per-rank
-//      records of the multi-GPU residual mode -- followed by its sequence number;
-//   2. every block polls ALL records (thread i <-> record i) until they carry this step's sequence number: the
-//      exchange is the barrier, one memory round trip, no read-modify-write contention;
-//   3. every block reduces the records to the same winner, checks the commit condition (energy > theta + margin),
-//      stages the winner's w in LDS and each wave deflates its own row explicitly: c = row . w / |w|^2, row -= c w.
-// Everything that crosses blocks goes through relaxed agent-scope atomic loads / stores (they bypass the per-XCD L2s,
-// which are not coherent with each other) ordered by plain s_waitcnt, so the loop needs no cache write-back or
-// invalidate.  Records and weights are double-buffered by step parity: a block can run at most one step ahead.
-// Block 0 also writes W[k], scal[k] and the committed count.  All blocks take identical decisions from identical
-// data, so they leave the loop together; a poll that does not complete within ~1 s raises the abort flag instead
-// of hanging the GPU.
-// --------------------------------------------------------------------------------------
-struct CoopRec { double e, lam, wn2; long long slot; unsigned long long seq; unsigned long long pad[3]; };
-
 __device__ __forceinline__ void coop_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double coop_load(const double* p) {
     return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// --------------------------------------------------------------------------------------
+// k_panel_multi (round 3): ALL sub-panels of a read of X in ONE launch (up to ASB_MAX_SUB x 16 greedy steps), and a
+// shorter step.  Rows live in registers as in k_panel_coop; what changed is the exchange:
+//   * every word that crosses blocks is SELF-VALIDATING: it is reset to a bit pattern no payload can take (a NaN for
+//     doubles, -1 for slots) two steps before it is written again, so a reader spins on the payload itself -- one memory
+//     round trip per exchange instead of "poll the sequence number, then load the payload";
+//   * a block publishes only (best energy, slot) -- 16 bytes -- not its tentative weights: the 3 x 3 eigen-pair of the
+//     block's best candidate is computed WHILE the records travel (that wave does not poll), and only the block that
+//     wins writes its w (16 KB instead of 256 x 16 KB of write-through traffic per step), straight from LDS, which the
+//     other blocks read with the same spin-on-payload loads;
+//   * every wave keeps the 3 x 3 Gram matrix of its own row current (six sums behind the deflation it does anyway), so
+//     the energy is its trace and the winner's eigen-problem needs no further reduction.
+// Rings of three (records: per block; weights: one buffer per step mod 3).  Reset protocol: a block that has passed the
+// poll of step g's records knows that every block has finished step g - 1 (a block publishes step g only behind it), so
+// it resets its own record of step g - 1, and block 0 the weight buffer of step g - 1; every wave drains its stores
+// (s_waitcnt) in front of the barrier that precedes the next publication, so a reset is visible before anything that
+// could lead another block to write or read that word again.  Hand-off form as in k_panel_coop: agent-scope (write-
+// through) stores, agent-scope loads, no cache maintenance.
+// Per sub-panel the kernel leaves what k_panel_coop left in a PanelState (sub[sp]: committed, proven, e_win, done); a
+// sub-panel starts only behind one that ran its 16 steps.  Blocks without candidates leave at once.
+// --------------------------------------------------------------------------------------
+struct MultiArgs { long long kb[ASB_MAX_SUB]; int steps[ASB_MAX_SUB]; int spec_max[ASB_MAX_SUB]; int nsub; };
+#define ASB_SENT_D 0xFFFFFFFFFFFFFFFFull          // quiet NaN with every payload bit set: never an energy or a weight
+#define ASB_SENT_I (-1LL)                         // never a slot
+
+__device__ __forceinline__ unsigned long long coop_load_u64(const unsigned long long* p) {
+    return __hip_atomic_load(const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_store_u64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_panel_arm_multi(PanelState* __restrict__ panel, PanelState* __restrict__ sub,
+                                                         const double* __restrict__ sc, double margin_rel, unsigned* __restrict__ coop_flags,
+                                                         unsigned long long* __restrict__ words, int n_words, MultiArgs ma) {
+    for (int r = threadIdx.x; r < n_words; r += blockDim.x) words[r] = ASB_SENT_D;     // (ASB_SENT_I has the same bits)
+    if (threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
+    if (threadIdx.x != 0) return;
+    panel->pad &= 1;
+    panel->theta = panel->pad ? 1.0e300 : sc[SC_TAU];
+    panel->margin = margin_rel * sc[SC_E0MAX];
+    panel->done = 0;
+    panel->committed = 0;
+    panel->proven = -1;
+    panel->spec_max = ma.spec_max[0];
+    panel->spec_ok = ASB_PANEL_COLS;
+    for (int sp = 0; sp < ASB_MAX_SUB; ++sp) {
+        sub[sp] = *panel;
+        sub[sp].spec_max = sp < ma.nsub ? ma.spec_max[sp] : 0;
+    }
+}
+
 template <int NJ>
-__global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const double* R0, long long m_cap, int F, int Fp,
-                                                       double* __restrict__ W, double* __restrict__ scal, long long k0, int steps,
-                                                       PanelState* __restrict__ panel, const long long* __restrict__ cand_idx,
-                                                       unsigned* __restrict__ bar, CoopRec* rec, double* rec_w, double* rows_out,
-                                                       int test_stall) {
-    __shared__ double w_sh[NJ * 64];
-    __shared__ double sh_e[4];
-    __shared__ long long sh_i[4];
-    __shared__ int sh_b[4];
+__global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const double* __restrict__ R0, int F, int Fp,
+                                                        double* __restrict__ W, double* __restrict__ scal, MultiArgs ma,
+                                                        const PanelState* panel, PanelState* sub,
+                                                        const long long* __restrict__ cand_idx, unsigned* __restrict__ bar,
+                                                        unsigned long long* rec, unsigned long long* wbuf, double* rows_out,
+                                                        int test_stall) {
+    constexpr int NQ = NJ / 4;                                   // weight words per thread
+    __shared__ double w_sh[NJ * 64 + 8];                         // [NJ * 64] = |w|^2, [NJ * 64 + 1] = lambda
     __shared__ double wv_e[4];
     __shared__ long long wv_i[4];
+    __shared__ double sh_e[4];
+    __shared__ int sh_i[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = gridDim.x;
     const long long n_cand = panel->n_cand;
@@ -2927,11 +3006,11 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
         if (blockIdx.x == 0 && tid == 0) bar[2] = 1u;
         return;
     }
-    const double thr = panel->theta + panel->margin;
-    // steps beyond the provable ones (only with the complete candidate set): checked after the projection pass
-    const int spec_max = panel->pad ? 0 : (int)panel->spec_max;
-    const double e_floor = panel->margin;
-    int proven = -1, nrun = 0;
+    const int Gact = n_cand > 0 ? (int)((n_cand + 3) / 4) : 1;  // blocks that hold candidates
+    if ((int)blockIdx.x >= Gact) return;
+    const int WROW = Fp + 8;                                     // a weight buffer: Fp words, |w|^2, lambda
+    const double thr = panel->theta + panel->margin, e_floor = panel->margin;
+    const bool overflow = panel->pad != 0;
     const long long s = (long long)blockIdx.x * 4 + wv;          // this wave's candidate slot
     const bool have = s < n_cand && cand_idx[s] >= 0;
     double x[3][NJ];
@@ -2945,171 +3024,215 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
                 x[d][j] = (have && f < Fp) ? row[(long long)d * Fp + f] : 0.0;
             }
     }
-    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(bar + 4);      // [16][12] timestamps of block 0 (debug)
-    for (int t = 0; t < steps; ++t) {
-        const unsigned long long seq = (unsigned long long)t + 1;
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 0] = wall_clock64();
-        // ---- 1. block-local best and its record
-        double e = 0.0;
+    double g[6] = {0, 0, 0, 0, 0, 0};                            // Gram matrix of the wave's row (00 01 02 11 12 22), every lane
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) e += x[d][j] * x[d][j];
-        e = wave_sum(e);
-        if (lane == 0) { wv_e[wv] = have ? e : -1.0; wv_i[wv] = have ? s : 0x7fffffffffffffffLL; }
-        __syncthreads();
-        int ow = 0;
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (am_better(wv_e[q], wv_i[q], wv_e[ow], wv_i[ow])) ow = q;
-        CoopRec* myrec = rec + (size_t)(t & 1) * G + blockIdx.x;
-        double* myw = rec_w + ((size_t)(t & 1) * G + blockIdx.x) * Fp;
-        if (wv == ow) {
-            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 6] = wall_clock64();
-            double g[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const double a = x[0][j], b = x[1][j], c = x[2][j];
-                g[0] += a * a; g[1] += a * b; g[2] += a * c; g[3] += b * b; g[4] += b * c; g[5] += c * c;
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
-            double lam, u0, u1, u2;
-            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 7] = wall_clock64();
-            eig3_top_fast(g[0], g[1], g[2], g[3], g[4], g[5], lam, u0, u1, u2);     // every lane: identical inputs and result
-            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 8] = wall_clock64();
-            double wn = 0.0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int f = lane + 64 * j;
-                const double wvv = (f < F) ? (u0 * x[0][j] + u1 * x[1][j] + u2 * x[2][j]) : 0.0;
-                w_sh[f] = wvv;                          // staged in LDS (free until the winner's w arrives): all four waves store it
-                wn += wvv * wvv;
-            }
-            wn = wave_sum(wn);
-            if (lane == 0) {
-                coop_store(&myrec->e, wv_e[ow]);
-                coop_store(&myrec->lam, lam);
-                coop_store(&myrec->wn2, wn);
-                __hip_atomic_store(&myrec->slot, wv_i[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 9] = wall_clock64();
-        }
-        __syncthreads();
-        // a wave's write-through stores are the slow part of the record (32 of them took 3 us from one wave): 8 per wave
-#pragma unroll
-        for (int q = 0; q < NJ / 4; ++q) {
-            const int f = tid + 256 * q;
-            if (f < Fp) coop_store(myw + f, w_sh[f]);
-        }
-        __builtin_amdgcn_s_waitcnt(0);                  // every store of this wave has been acknowledged ...
-        __syncthreads();                                // ... and of the other three
-        if (wv == ow) {
-            if (blockIdx.x == 0 && lane == 0) tlog[t * 12 + 10] = wall_clock64();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            // ... before the flag (test_stall, tests only: the last block never signals, so every block runs into the poll limit)
-            if (lane == 0 && !(test_stall && blockIdx.x == G - 1))
-                __hip_atomic_store(&myrec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 1] = wall_clock64();
-        // ---- 2. + 3. poll every record until it is this step's, reduce to the same winner in every block
-        const CoopRec* recs = rec + (size_t)(t & 1) * G;
-        double be = -1.0;
-        long long bi = 0x7fffffffffffffffLL;
-        int bb = 0;
-        int dead = 0;
-        for (int b = tid; b < G; b += 256) {
-            CoopRec* r = const_cast<CoopRec*>(recs) + b;
-            long long spins = 0;
-            while (__hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (test_stall ? (1LL << 10) : (1LL << 20)) ||
-                    __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { dead = 1; break; }
-            }
-            if (dead) break;
-            // Ordering of the hand-off (MI355X guide, "valid forms"): the record's payload was stored with agent-scope
-            // (write-through, sc1) stores, every storing wave drained them (s_waitcnt 0) in front of the workgroup barrier
-            // that precedes the sequence-number store; here EVERY load of the payload is an agent-scope (sc1) load issued
-            // after the poll has matched -- loads of one wave return in order, and the compiler barrier keeps them from
-            // being hoisted above the poll loop.  No cache invalidate / write-back is needed in this form.
-            asm volatile("" ::: "memory");
-            const double eb = coop_load(&r->e);
-            const long long ib = __hip_atomic_load(&r->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (am_better(eb, ib, be, bi)) { be = eb; bi = ib; bb = b; }
-        }
-        if (__syncthreads_or(dead)) {
-            if (tid == 0) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 2] = wall_clock64();
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double oe = __shfl_xor(be, o, 64);
-            const long long oi = __shfl_xor(bi, o, 64);
-            const int ob = __shfl_xor(bb, o, 64);
-            if (am_better(oe, oi, be, bi)) { be = oe; bi = oi; bb = ob; }
-        }
-        if (lane == 0) { sh_e[wv] = be; sh_i[wv] = bi; sh_b[wv] = bb; }
-        __syncthreads();
-        be = sh_e[0]; bi = sh_i[0]; bb = sh_b[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (am_better(sh_e[q], sh_i[q], be, bi)) { be = sh_e[q]; bi = sh_i[q]; bb = sh_b[q]; }
-        if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max ...
-            if (proven < 0) proven = t;
-            // ... the panel ends here, unless it may go on unproven: the winner among the candidates is exact, whether
-            // a vertex outside beats it is decided once the projection pass has every vertex's energy
-            if (bi >= n_cand || !(be > e_floor) || t - proven >= spec_max) {
-                if (blockIdx.x == 0 && tid == 0) panel->done = 1;
-                break;
-            }
-        }
-        nrun = t + 1;
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 3] = wall_clock64();
-        const double wn2 = coop_load(&recs[bb].wn2);
-        const double* ww = rec_w + ((size_t)(t & 1) * G + bb) * Fp;
-        {       // all loads of a thread first, then the LDS stores: one memory round trip instead of NJ / 4 dependent ones
-            double tmp[NJ / 4];
-#pragma unroll
-            for (int q = 0; q < NJ / 4; ++q) {
-                const int f = tid + 256 * q;
-                tmp[q] = (f < Fp) ? coop_load(ww + f) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < NJ / 4; ++q) w_sh[tid + 256 * q] = tmp[q];
-        }
-        __syncthreads();
-        if (blockIdx.x == 0) {
-            const long long k = k0 + t;
-            for (int f = tid; f < Fp; f += 256) W[k * (long long)Fp + f] = w_sh[f];
-            if (tid == 0) {
-                scal[k * 4 + 0] = sqrt(fmax(coop_load(&recs[bb].lam), 0.0));
-                scal[k * 4 + 1] = wn2;
-                scal[k * 4 + 2] = __longlong_as_double(cand_idx[bi]);
-                panel->committed = t + 1;
-                panel->e_win[t] = be;
-            }
-        }
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 4] = wall_clock64();
-        if (t + 1 < steps || rows_out != nullptr) {          // explicit deflation of this wave's row
-            double acc[3] = {0.0, 0.0, 0.0}, wr[NJ];       // w once from LDS (four waves read all of it), then from registers
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                wr[j] = w_sh[lane + 64 * j];
-                acc[0] += x[0][j] * wr[j]; acc[1] += x[1][j] * wr[j]; acc[2] += x[2][j] * wr[j];
-            }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) acc[d] = wave_sum(acc[d]) / wn2;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                x[0][j] -= acc[0] * wr[j]; x[1][j] -= acc[1] * wr[j]; x[2][j] -= acc[2] * wr[j];
-            }
-        }
-        __syncthreads();              // w_sh and the wave records are rewritten in the next step
-        if (blockIdx.x == 0 && tid == 0) tlog[t * 12 + 5] = wall_clock64();
+    for (int j = 0; j < NJ; ++j) {
+        const double a = x[0][j], b = x[1][j], c = x[2][j];
+        g[0] += a * a; g[1] += a * b; g[2] += a * c; g[3] += b * b; g[4] += b * c; g[5] += c * c;
     }
-    if (blockIdx.x == 0 && tid == 0) panel->proven = proven < 0 ? nrun : proven;
-    // super-panels run several of these launches on the same candidates: the deflated rows become the next start rows
+    wave_sum_dpp<6>(g);
+    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(bar + 4);      // [64][6] timestamps of block 0 (debug)
+    const long long spin_max = test_stall ? (1LL << 10) : (1LL << 20);
+    int gstep = 0;
+    bool aborted = false, ended = false;
+    int sp = 0;
+    for (; sp < ma.nsub && !ended; ++sp) {
+        const long long k0 = ma.kb[sp];
+        const int steps = ma.steps[sp], spec_max = overflow ? 0 : ma.spec_max[sp];
+        PanelState* st = sub + sp;
+        int proven = -1, nrun = 0;
+        for (int t = 0; t < steps; ++t, ++gstep) {
+            const int ring = gstep % 3, ring_prev = (gstep + 2) % 3;
+            if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 0] = wall_clock64();
+            // ---- 1. block-local best; its (energy, slot) goes out at once
+            const double e = (g[0] + g[3]) + g[5];
+            if (lane == 0) { wv_e[wv] = have ? e : -1.0; wv_i[wv] = have ? s : 0x7fffffffffffffffLL; }
+            __builtin_amdgcn_s_waitcnt(0);              // this wave's stores of the last step (resets, weights) are acknowledged
+            __syncthreads();
+            int ow = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (am_better(wv_e[q], wv_i[q], wv_e[ow], wv_i[ow])) ow = q;
+            unsigned long long* myrec = rec + ((size_t)ring * G + blockIdx.x) * 2;
+            if (tid == 0 && !(test_stall && (int)blockIdx.x == Gact - 1)) {      // (tests: the last block never signals)
+                coop_store(reinterpret_cast<double*>(myrec), wv_e[ow]);
+                coop_store_u64(myrec + 1, (unsigned long long)wv_i[ow]);
+            }
+            if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 1] = wall_clock64();
+            // ---- 2. the best wave solves its 3 x 3 eigen-problem while the other three poll the records
+            double lam = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+            double be = -2.0;                            // (records carry -1 at the least)
+            int bi = 0x7fffffff, dead = 0;               // slots fit 31 bits (4 G <= 4096)
+            if (wv == ow) {
+                // the eigen-pair AND w = u^T row of the block's best candidate, into LDS, while the records travel: should
+                // the block win, its w only has to be stored (w_sh is free here: the last reads of it -- the deflation of
+                // step gstep - 1 -- lie in front of this step's first barrier)
+                if (wv_e[ow] > 0.0) {
+                    eig3_top_fast(g[0], g[1], g[2], g[3], g[4], g[5], lam, u0, u1, u2);     // every lane: identical
+                    double wn1[1] = {0.0};
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const double wvv = u0 * x[0][j] + u1 * x[1][j] + u2 * x[2][j];      // (frames >= F are zero in the rows)
+                        w_sh[lane + 64 * j] = wvv;
+                        wn1[0] += wvv * wvv;
+                    }
+                    wave_sum_dpp<1>(wn1);
+                    if (lane == 0) { w_sh[NJ * 64] = wn1[0]; w_sh[NJ * 64 + 1] = lam; }
+                }
+            } else {
+                const unsigned long long* recs = rec + (size_t)ring * G * 2;
+                const int p = (wv - (wv > ow ? 1 : 0)) * 64 + lane;
+                for (int b = p; b < Gact; b += 192) {
+                    unsigned long long eb, ib;
+                    long long spins = 0;
+                    for (;;) {
+                        eb = coop_load_u64(recs + 2 * b);
+                        ib = coop_load_u64(recs + 2 * b + 1);
+                        if (eb != ASB_SENT_D && ib != (unsigned long long)ASB_SENT_I) break;
+                        // (the abort flag and the limit every 64 rounds: the fast path is the two loads alone)
+                        if ((++spins & 63) == 0 &&
+                            (spins > spin_max || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { dead = 1; break; }
+                    }
+                    if (dead) break;
+                    const double ebd = __longlong_as_double((long long)eb);
+                    const int ibs = ib > 0x7ffffffeull ? 0x7fffffff : (int)ib;
+                    if (ebd > be || (ebd == be && ibs < bi)) { be = ebd; bi = ibs; }
+                }
+                // arg-max over the wave: largest energy, then lowest slot among the lanes that hold it (NumPy's first max)
+                const double em = wave_max_dpp(be);
+                bi = wave_min_dpp(be == em ? bi : 0x7fffffff);
+                be = em;
+            }
+            if (lane == 0) { sh_e[wv] = be; sh_i[wv] = bi; }
+            if (__syncthreads_or(dead)) { aborted = true; break; }
+            be = sh_e[0]; bi = sh_i[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (sh_e[q] > be || (sh_e[q] == be && sh_i[q] < bi)) { be = sh_e[q]; bi = sh_i[q]; }
+            const int bb = bi >> 2;                      // the winner's block (slot = 4 block + wave)
+            if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 2] = wall_clock64();
+            // every block is past step gstep - 1: its words can be reset (see the header)
+            if (tid == 0) {
+                unsigned long long* old = rec + ((size_t)ring_prev * G + blockIdx.x) * 2;
+                coop_store_u64(old, ASB_SENT_D);
+                coop_store_u64(old + 1, (unsigned long long)ASB_SENT_I);
+            }
+            {   // the weight buffer of step gstep - 1: every block resets its slice (same argument block by block: a block's
+                // reset is visible before its next record, and whoever writes or reads the buffer again has seen ALL records)
+                unsigned long long* wold = wbuf + (size_t)ring_prev * WROW;
+                const int per = (WROW + Gact - 1) / Gact;
+                const int f = (int)blockIdx.x * per + tid;
+                if (tid < per && f < WROW) coop_store_u64(wold + f, ASB_SENT_D);
+            }
+            if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max ...
+                if (proven < 0) proven = t;
+                // ... the panel ends here, unless it may go on unproven (checked after the projection pass)
+                if (bi >= n_cand || !(be > e_floor) || t - proven >= spec_max) {
+                    if (blockIdx.x == 0 && tid == 0) st->done = 1;
+                    ended = true;
+                    break;
+                }
+            }
+            nrun = t + 1;
+            // ---- 3. the winner's w: its block writes it (LDS -> write-through stores by all four waves), the others spin on it
+            unsigned long long* wb = wbuf + (size_t)ring * WROW;
+            dead = 0;
+            if (bb == (int)blockIdx.x) {             // (w_sh holds this block's w since the barrier behind the poll)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int f = tid + 256 * q;
+                    if (f < Fp) coop_store(reinterpret_cast<double*>(wb) + f, w_sh[f]);
+                }
+                if (tid < 2) coop_store(reinterpret_cast<double*>(wb) + Fp + tid, w_sh[NJ * 64 + tid]);
+            } else {
+                unsigned long long tmp[NQ], hd = 0ull;
+                long long spins = 0;
+                for (;;) {
+                    bool all = true;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int f = tid + 256 * q;
+                        tmp[q] = (f < Fp) ? coop_load_u64(wb + f) : 0ull;
+                        all = all && tmp[q] != ASB_SENT_D;
+                    }
+                    if (tid < 2) { hd = coop_load_u64(wb + Fp + tid); all = all && hd != ASB_SENT_D; }
+                    if (all) break;
+                    if ((++spins & 63) == 0 &&
+                        (spins > spin_max || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { dead = 1; break; }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) w_sh[tid + 256 * q] = __longlong_as_double((long long)tmp[q]);
+                if (tid < 2) w_sh[NJ * 64 + tid] = __longlong_as_double((long long)hd);
+            }
+            if (__syncthreads_or(dead)) { aborted = true; break; }
+            if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 3] = wall_clock64();
+            const double wn2 = w_sh[NJ * 64];
+            if (bb == (int)blockIdx.x) {                 // the winner's block has w first and nothing to wait for: it writes the results
+                const long long k = k0 + t;
+                for (int f = tid; f < Fp; f += 256) W[k * (long long)Fp + f] = w_sh[f];
+                if (tid == 0) {
+                    scal[k * 4 + 0] = sqrt(fmax(w_sh[NJ * 64 + 1], 0.0));
+                    scal[k * 4 + 1] = wn2;
+                    scal[k * 4 + 2] = __longlong_as_double(cand_idx[bi]);
+                    st->e_win[t] = be;
+                }
+            }
+            // (words written once, by whichever block won; the running count is block 0's alone: one writer per address --
+            // the XCDs' L2s are not coherent with each other for plain stores)
+            if (blockIdx.x == 0 && tid == 0) st->committed = t + 1;
+            // ---- 4. explicit deflation of this wave's row, and its new Gram matrix
+            if (have) {
+                // (w is read from LDS twice, for the dots and for the update: holding it in registers beside the row -- 64 + 192
+                // VGPRs at F = 2000 -- pushes the loop into scratch memory, 9 us per step instead of 3)
+                double acc[3] = {0.0, 0.0, 0.0};
+                constexpr int JB = NJ < 8 ? NJ : 8;              // w in groups of JB values: the scheduler must not gather all NJ reads first
+#pragma unroll
+                for (int jb = 0; jb < NJ; jb += JB) {
+                    double wj[JB];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) wj[u] = w_sh[lane + 64 * (jb + u)];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) {
+                        acc[0] += x[0][jb + u] * wj[u]; acc[1] += x[1][jb + u] * wj[u]; acc[2] += x[2][jb + u] * wj[u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_sum_dpp<3>(acc);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc[d] /= wn2;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) g[q] = 0.0;
+#pragma unroll
+                for (int jb = 0; jb < NJ; jb += JB) {
+                    double wj[JB];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) wj[u] = w_sh[lane + 64 * (jb + u)];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) {
+                        const int j = jb + u;
+                        const double a = x[0][j] - acc[0] * wj[u], b = x[1][j] - acc[1] * wj[u], c = x[2][j] - acc[2] * wj[u];
+                        x[0][j] = a; x[1][j] = b; x[2][j] = c;
+                        g[0] += a * a; g[1] += a * b; g[2] += a * c; g[3] += b * b; g[4] += b * c; g[5] += c * c;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_sum_dpp<6>(g);
+            }
+            if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 4] = wall_clock64();
+        }
+        if (aborted) break;
+        if (blockIdx.x == 0 && tid == 0) st->proven = proven < 0 ? nrun : proven;
+        if (nrun < ASB_PANEL_COLS) ended = true;        // a later sub-panel runs only behind a full one
+    }
+    if (aborted) {
+        if (tid == 0) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // sub-panels that were not reached: "ran, committed nothing" (proven = -1 would read as a launch that did not finish)
+    if (blockIdx.x == 0 && tid == 0)
+        for (int q = sp; q < ma.nsub; ++q) { sub[q].proven = 0; sub[q].done = 1; }
+    // launches that continue on the same candidates (one sub-panel per launch: the multi-rank driver, ASB_SUB_CHAIN=0):
+    // the deflated rows become the next start rows -- behind the last step, past every abort exit
     if (rows_out != nullptr && have) {
         double* row = rows_out + s * 3 * (long long)Fp;
 #pragma unroll
@@ -3122,22 +3245,44 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_coop(const dou
     }
 }
 
+// the kernel's flags + debug timestamps, and its exchange words: records (3 rings x blocks x 2) then weight buffers (3 x (Fp + 8))
+static int coop_buffers(asb_ctx* ctx, int* cgrid_all, size_t* n_words) {
+    int rc;
+    *cgrid_all = (int)((ctx->m_cap + 3) / 4);
+    *n_words = (size_t)3 * *cgrid_all * 2 + (size_t)3 * (ctx->Fp + 8);
+    if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 64 * 6))) return rc;
+    return asb_alloc(ctx, &ctx->coop_rec, *n_words);
+}
+static int launch_panel_multi_any(asb_ctx* ctx, int grid, const MultiArgs& ma, bool* launched, PanelState* sub, bool writeback);
+
 template <int NJ>
-static int launch_panel_coop(asb_ctx* ctx, int grid, long long k0, int steps, bool* launched, bool writeback) {
+static int launch_panel_multi(asb_ctx* ctx, int grid, const MultiArgs& ma, bool* launched, PanelState* sub, bool writeback) {
     int per_cu = 0;
-    ASB_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_panel_coop<NJ>, 256, 0));
+    ASB_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_panel_multi<NJ>, 256, 0));
     if (per_cu < 1) { *launched = false; return ASB_OK; }
     if ((long long)per_cu * ctx->n_cu < grid) grid = per_cu * ctx->n_cu;      // the kernel refuses panels with more candidates
-    // A plain launch: the grid is no larger than what the occupancy query says is resident at once on this device, and
-    // nothing these blocks wait for depends on other work, so they all become resident (a cooperative launch would
-    // assert the same thing but is not usable on every stream, e.g. torch's null stream).  The barrier's poll limit
-    // turns any surprise into an error instead of a hang.
-    hipLaunchKernelGGL(k_panel_coop<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (long long)ctx->m_cap, (int)ctx->F,
-                       (int)ctx->Fp, ctx->W, ctx->scal, k0, steps, ctx->pstate, ctx->cand_idx, ctx->coop_bar,
-                       (CoopRec*)ctx->coop_rec, ctx->coop_w, writeback ? ctx->candR : (double*)nullptr, ctx->coop_test_stall);
+    unsigned long long* words = (unsigned long long*)ctx->coop_rec;
+    hipLaunchKernelGGL(k_panel_multi<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal,
+                       ma, ctx->pstate, sub, ctx->cand_idx, ctx->coop_bar, words, words + (size_t)3 * grid * 2,
+                       writeback ? ctx->candR : (double*)nullptr, ctx->coop_test_stall);
     ASB_CHECK_LAUNCH(ctx);
     *launched = true;
     return ASB_OK;
+}
+
+static int launch_panel_multi_any(asb_ctx* ctx, int grid, const MultiArgs& ma, bool* launched, PanelState* sub, bool writeback) {
+    if (ctx->Fp <= 256) return launch_panel_multi<4>(ctx, grid, ma, launched, sub, writeback);
+    if (ctx->Fp <= 512) return launch_panel_multi<8>(ctx, grid, ma, launched, sub, writeback);
+    if (ctx->Fp <= 1024) return launch_panel_multi<16>(ctx, grid, ma, launched, sub, writeback);
+    return launch_panel_multi<32>(ctx, grid, ma, launched, sub, writeback);
+}
+static void print_multi_timeline(asb_ctx* ctx, int nsteps) {
+    unsigned long long tl[64 * 6];
+    (void)hipMemcpy(tl, ctx->coop_bar + 4, sizeof(tl), hipMemcpyDeviceToHost);
+    for (int t = 0; t < 64 && t < nsteps; t += (nsteps > 16 ? 5 : 1))
+        fprintf(stderr, "[asb]   step %2d: best+publish %.2f | poll+eigen %.2f | winner w %.2f | deflate+Gram %.2f | total %.2f us\n", t,
+                (tl[t * 6 + 1] - tl[t * 6 + 0]) * 0.01, (tl[t * 6 + 2] - tl[t * 6 + 1]) * 0.01, (tl[t * 6 + 3] - tl[t * 6 + 2]) * 0.01,
+                (tl[t * 6 + 4] - tl[t * 6 + 3]) * 0.01, (tl[t * 6 + 4] - tl[t * 6 + 0]) * 0.01);
 }
 
 // up to `steps` greedy steps on the context's candidate buffer (asb_panel_select with NULL
@@ -3150,26 +3295,24 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ASB_PANEL_COLS * ctx->m_cap * 3))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->slab_scratch, (size_t)3 * ctx->Fp))) return rc;
-    const int cgrid_all = (int)((ctx->m_cap + 3) / 4);
+    int cgrid_all = 0;
+    size_t n_words = 0;
     const bool want_coop = ctx->panel_coop && ctx->Fp <= 2048;
-    if (want_coop) {
-        if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 12))) return rc;
-        if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid_all * 8))) return rc;
-        if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid_all * ctx->Fp))) return rc;
-    }
+    if (want_coop && (rc = coop_buffers(ctx, &cgrid_all, &n_words))) return rc;
+    const long long spec_max = want_coop && !global_all ? ctx->run_spec_max : 0;
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
-                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, 2 * cgrid_all,
-                       ctx->run_theta_band, (long long)(want_coop && !global_all ? ctx->run_spec_max : 0));
+                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, (int)n_words,
+                       ctx->run_theta_band, spec_max);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     bool coop = false;
-    if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers
-        const int cgrid = cgrid_all;
-        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
-        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
-        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
-        else rc = launch_panel_coop<32>(ctx, cgrid, k0, steps, &coop, ctx->run_writeback != 0);
-        if (rc) return rc;
+    if (want_coop) {      // the whole inner loop in one launch of co-resident blocks, rows in registers (one sub-panel)
+        MultiArgs ma{};
+        ma.kb[0] = k0;
+        ma.steps[0] = steps;
+        ma.spec_max[0] = (int)spec_max;
+        ma.nsub = 1;
+        if ((rc = launch_panel_multi_any(ctx, cgrid_all, ma, &coop, ctx->pstate, ctx->run_writeback != 0))) return rc;
     }
     if (assembled && !coop) {      // two-kernel loop: energies / partial records of the assembled buffer (rows came from other ranks)
         StreamArgs a{ctx->candR, nullptr, nullptr, nullptr, nullptr, ctx->cand_e, ctx->cpmax, ctx->cpidx, ctx->cpsum,
@@ -3229,17 +3372,7 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
             return rc;
         }
     }
-    if (coop && getenv("ASB_DEBUG_PANELS")) {
-        unsigned long long tl[16 * 12];
-        (void)hipMemcpy(tl, ctx->coop_bar + 4, sizeof(tl), hipMemcpyDeviceToHost);
-        for (int t = 0; t < (int)h.committed && t < 16; ++t)
-            fprintf(stderr, "[asb]   step %2d: record %.2f us (energy+select %.2f, Gram %.2f, eigen %.2f, w+stores %.2f, acks %.2f) | poll %.2f | "
-                            "reduce %.2f | w_sh+publish %.2f | deflate %.2f\n", t,
-                    (tl[t * 12 + 1] - tl[t * 12 + 0]) * 0.01, (tl[t * 12 + 6] - tl[t * 12 + 0]) * 0.01, (tl[t * 12 + 7] - tl[t * 12 + 6]) * 0.01,
-                    (tl[t * 12 + 8] - tl[t * 12 + 7]) * 0.01, (tl[t * 12 + 9] - tl[t * 12 + 8]) * 0.01, (tl[t * 12 + 10] - tl[t * 12 + 9]) * 0.01,
-                    (tl[t * 12 + 2] - tl[t * 12 + 1]) * 0.01, (tl[t * 12 + 3] - tl[t * 12 + 2]) * 0.01,
-                    (tl[t * 12 + 4] - tl[t * 12 + 3]) * 0.01, (tl[t * 12 + 5] - tl[t * 12 + 4]) * 0.01);
-    }
+    if (coop && getenv("ASB_DEBUG_PANELS")) print_multi_timeline(ctx, (int)h.committed);
     if (getenv("ASB_DEBUG_PANELS")) {
         double sc[8];
         (void)hipMemcpy(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost);
@@ -3610,67 +3743,53 @@ static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
-// The sub-panels of a read enqueued back to back -- arm + panel kernel per sub-panel, no host read in between: a later one is
-// given nothing to do (k_panel_arm with `prev`) unless the one before it ran its 16 steps in the kernel.  The states are read
-// afterwards, all at once.  *ntile = -1: the first launch did not run (record exchange timed out / more candidates than
-// resident waves): nothing has been written back, the caller takes the one-by-one path with its fallbacks.
-static int sub_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven) {
+// The sub-panels of a read in ONE launch (k_panel_multi): arm, kernel, one read of the summary.
+// *ntile = -1: the launch did not run to the end of its first sub-panel (exchange timed out / too many candidates): nothing
+// was committed, the caller takes the one-by-one path with its fallbacks.
+static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven) {
     int rc;
     *ntile = -1;
-    if ((rc = asb_alloc(ctx, &ctx->cand_c, (size_t)ASB_PANEL_COLS * ctx->m_cap * 3))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->slab_scratch, (size_t)3 * ctx->Fp))) return rc;
-    const int cgrid_all = (int)((ctx->m_cap + 3) / 4);
-    if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 16 * 12))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->coop_rec, (size_t)2 * cgrid_all * 8))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->coop_w, (size_t)2 * cgrid_all * ctx->Fp))) return rc;
-    int nrun = 0;
-    for (int sp = 0; sp < nsub_max && k + (long long)sp * ASB_PANEL_COLS < k1; ++sp) {
+    int cgrid_all = 0;
+    size_t n_words = 0;
+    if ((rc = coop_buffers(ctx, &cgrid_all, &n_words))) return rc;
+    MultiArgs ma{};
+    int n = 0;
+    for (int sp = 0; sp < nsub_max && sp < ASB_MAX_SUB && k + (long long)sp * ASB_PANEL_COLS < k1; ++sp) {
         const long long kb = k + (long long)sp * ASB_PANEL_COLS;
         int steps = (int)((k1 - kb) < ASB_PANEL_COLS ? (k1 - kb) : ASB_PANEL_COLS);
-        if (sp > 0) {
-            if (steps > ctx->sub_budget[sp]) steps = ctx->sub_budget[sp];
-            ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, 0, (long long)-1, ASB_MARGIN_REL,
-                           ctx->coop_bar, (unsigned long long*)ctx->coop_rec, 2 * cgrid_all, 0,
-                           (long long)(sp == 0 ? ctx->spec_budget : ASB_PANEL_COLS), sp > 0 ? ctx->pstate2 + (sp - 1) : (const PanelState*)nullptr);
-        bool launched = false;
-        if (ctx->Fp <= 256) rc = launch_panel_coop<4>(ctx, cgrid_all, kb, steps, &launched, true);
-        else if (ctx->Fp <= 512) rc = launch_panel_coop<8>(ctx, cgrid_all, kb, steps, &launched, true);
-        else if (ctx->Fp <= 1024) rc = launch_panel_coop<16>(ctx, cgrid_all, kb, steps, &launched, true);
-        else rc = launch_panel_coop<32>(ctx, cgrid_all, kb, steps, &launched, true);
-        if (rc) return rc;
-        if (!launched) return ASB_OK;                  // (no occupancy: the one-by-one path decides)
-        ++nrun;
+        if (sp > 0 && steps > ctx->sub_budget[sp]) steps = ctx->sub_budget[sp];
+        ma.kb[n] = kb;
+        ma.steps[n] = steps;
+        ma.spec_max[n] = sp == 0 ? ctx->spec_budget : ASB_PANEL_COLS;
+        ++n;
     }
-    ASB_CHECK_LAUNCH(ctx);
-    PanelState h[ASB_MAX_SUB];
-    unsigned flags[4] = {0, 0, 0, 0};
-    for (int sp = 0; sp < nrun; ++sp) {
-        const bool last = sp == nrun - 1;
-        if ((rc = read_panel_state_from(ctx, last ? ctx->pstate : ctx->pstate2 + sp, &h[sp], last ? flags : nullptr))) return rc;
-    }
+    ma.nsub = n;
+    hipLaunchKernelGGL(k_panel_arm_multi, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->pstate2, ctx->scalar_dev, ASB_MARGIN_REL,
+                       ctx->coop_bar, (unsigned long long*)ctx->coop_rec, (int)n_words, ma);
+    bool launched = false;
+    if ((rc = launch_panel_multi_any(ctx, cgrid_all, ma, &launched, ctx->pstate2, false))) return rc;
+    if (!launched) return ASB_OK;
+    unsigned long long sum[9];
+    if ((rc = fetch_multi(ctx, sum))) return rc;
     ctx->n_panels++;
     ctx->run_coop_used = 1;
-    ctx->sub_nrun = nrun;
+    if (getenv("ASB_DEBUG_PANELS")) print_multi_timeline(ctx, (int)(sum[0] & 0xffffffffu) + 16 * (n - 1));
     int nt = 0;
-    for (int sp = 0; sp < nrun; ++sp) {
-        if (h[sp].proven < 0) {                          // this launch did not finish (the flags say why)
-            if (sp == 0) return ASB_OK;                  // *ntile = -1
-            // a later one timed out: the sub-panels before it stand (their rows were written back); the context leaves the
-            // kernel like asb_panel_run does
-            ctx->panel_coop = 0;
+    for (int sp = 0; sp < n; ++sp) {
+        const long long committed = (long long)(sum[sp] & 0xffffffffu), prov = (long long)(sum[sp] >> 32) - 1;
+        if (prov < 0) {                                  // the launch did not finish this sub-panel (sum[8] says why)
+            if (sp == 0) return ASB_OK;                  // *ntile = -1: the one-by-one path meets the same and falls back
+            ctx->panel_coop = 0;                         // a later one timed out: what stands stands, the context leaves the kernel
             ctx->coop_test_stall = 0;
             ctx->n_coop_fallbacks++;
             break;
         }
-        if (h[sp].committed <= 0) break;
-        nc[nt] = (int)h[sp].committed;
-        proven[nt] = (int)((h[sp].proven > h[sp].committed) ? h[sp].committed : h[sp].proven);
+        if (committed <= 0) break;
+        nc[nt] = (int)committed;
+        proven[nt] = (int)(prov > committed ? committed : prov);
         ++nt;
-        if (h[sp].committed < ASB_PANEL_COLS) break;
+        if (committed < ASB_PANEL_COLS) break;
     }
-    (void)flags;
     *ntile = nt;
     return ASB_OK;
 }
@@ -3697,15 +3816,13 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     bool chained_runs = false;
     if (ctx->sub_chain && ctx->panel_coop && ctx->spec_panels && ctx->Fp <= 2048 && nsub_max > 1) {
         int nt = -1;
-        if ((rc = sub_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven))) return rc;
+        if ((rc = multi_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven))) return rc;
         if (nt == 0) return ASB_OK;                      // nothing committed: the caller's refresh / forced path
         if (nt > 0) { ntile = nt; chained_runs = true; }
     }
     for (int sp = 0; !chained_runs && sp < nsub_max && kb[sp] < k1; ++sp) {
         int steps = (int)((k1 - kb[sp]) < ASB_PANEL_COLS ? (k1 - kb[sp]) : ASB_PANEL_COLS);
         if (sp > 0) {
-            // the earlier sub-panel's state (winner energies, provable head) is needed again after the pass
-            ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
             // a later sub-panel runs on rows chosen for the first, mostly unproven (the bound on the vertices outside is the
             // stale one): it is given as many steps as the last ones kept (+2) -- a rejected step costs a panel step and
             // everything behind it
@@ -3718,6 +3835,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         ctx->run_writeback = 0;
         ctx->run_spec_max = 0;
         if (rc) return rc;
+        // this sub-panel's state (winner energies, provable head) is needed again after the pass; a later launch re-arms pstate
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + sp, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
         if (sp > 0) ctx->n_panels--;                     // statistics count reads of X
         if (sp == 0 && ran == 0) return ASB_OK;          // the caller's refresh / forced path
         if (ran == 0 || (sp > 0 && !ctx->run_coop_used)) break;
@@ -3729,9 +3848,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if (ran < ASB_PANEL_COLS || !ctx->run_coop_used || !ctx->spec_panels) break;
     }
     PanelState* st[ASB_MAX_SUB];
-    // (chained runs: sub-panel sp's state was copied aside iff another launch followed it, whether or not that one did anything)
-    const int nlaunch = chained_runs ? ctx->sub_nrun : ntile;
-    for (int ct = 0; ct < ntile; ++ct) st[ct] = ct < nlaunch - 1 ? ctx->pstate2 + ct : ctx->pstate;
+    for (int ct = 0; ct < ntile; ++ct) st[ct] = ctx->pstate2 + ct;      // (k_panel_multi writes them there; the one-by-one loop copies)
     // one read of X for all tiles
     WideArgs wa{};
     for (int ct = 0; ct < ntile; ++ct) {
@@ -3819,7 +3936,9 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
 // ---- the same read of X with several sub-panels, in steps, for the multi-rank driver (_panels.py): every rank runs the
 // sub-panels on the identical assembled candidates, projects its shard once, and the tiles are checked one at a time with
 // a min over the ranks in between (the driver's all-reduce of the device word)
-static PanelState* sub_state(asb_ctx* ctx, int ct) { return ct < ctx->sub_ntile - 1 ? ctx->pstate2 + ct : ctx->pstate; }
+// (every sub-panel's state is copied to pstate2[sp] right behind its run: what a later launch -- which re-arms pstate --
+// does or does not commit cannot change which record a tile is checked against)
+static PanelState* sub_state(asb_ctx* ctx, int ct) { return ctx->pstate2 + ct; }
 extern "C" int asb_panel_sub_run(asb_ctx* ctx, int sp, int64_t k0, int steps, int spec_max, int64_t* ran, int64_t* proven, int* may_continue) {
     if (!ctx || !ctx->candR || ctx->mode != ASB_DEFLATE_PROJECT || !ran || !proven || !may_continue) return ASB_ERR_ARG;
     if (sp < 0 || sp >= ASB_MAX_SUB || spec_max < 0) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_sub_run: bad sub-panel");
@@ -3832,8 +3951,6 @@ extern "C" int asb_panel_sub_run(asb_ctx* ctx, int sp, int64_t k0, int steps, in
         if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
         if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
         ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + (sp - 1), ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
     }
     ctx->run_writeback = 1;
     ctx->run_spec_max = ctx->spec_panels ? spec_max : 0;
@@ -3841,6 +3958,7 @@ extern "C" int asb_panel_sub_run(asb_ctx* ctx, int sp, int64_t k0, int steps, in
     ctx->run_writeback = 0;
     ctx->run_spec_max = 0;
     if (rc) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->pstate2 + sp, ctx->pstate, sizeof(PanelState), hipMemcpyDeviceToDevice, ctx->stream));
     if (sp > 0) ctx->n_panels--;                          // statistics count reads of X
     *proven = ctx->run_proven;
     *may_continue = (*ran == ASB_PANEL_COLS && ctx->run_coop_used && ctx->spec_panels) ? 1 : 0;
@@ -3903,7 +4021,7 @@ extern "C" int asb_panel_sub_commit(asb_ctx* ctx, int ct, int64_t kb, int nc, in
 
 // ---- guessed candidates of a first panel (see asb_project_run)
 static bool guess_possible(const asb_ctx* ctx) {
-    return ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop && ctx->Fp <= 2048 && ctx->EV && ctx->e0_valid &&
+    return ctx->first_panel_mean && ctx->spec_panels && ctx->panel_coop && ctx->Fp <= 2048 && ctx->EV && ctx->ev_valid && ctx->e0_valid &&
            ctx->n_energy_pass == 0 && ctx->m_target >= 256 && ctx->n_loc > ctx->m_cap;
 }
 // thresholds of the scores EV + g (E - EV) into sc[SC_TAUG ..]: about mq[q] / world of this shard's vertices above each.

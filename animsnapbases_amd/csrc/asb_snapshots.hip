@@ -366,7 +366,7 @@ static int set_shape(asb_ctx* ctx, int64_t F, int64_t N_glob, int64_t v0, int64_
     ctx->v0 = v0;
     ctx->n_loc = n_loc;
     ctx->have_mean = false;
-    ctx->e0_valid = false;
+    { ctx->e0_valid = false; ctx->ev_valid = false; }
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->X, (size_t)n_loc * 3 * ctx->Fp))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->mean, (size_t)n_loc * 3))) return rc;
@@ -448,7 +448,7 @@ static int transpose_rest(asb_ctx* ctx, const double* stage_dev, const double* m
     hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(1024), 0, ctx->stream, ctx->tr_part, nb, ctx->scalar_dev);
     ASB_CHECK_LAUNCH(ctx);
     ctx->have_mean = true;
-    ctx->e0_valid = false;
+    { ctx->e0_valid = false; ctx->ev_valid = false; }
     ASB_HIP(ctx, hipMemcpyAsync(sums_out, ctx->scalar_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
@@ -522,7 +522,7 @@ extern "C" int asb_snapshots_center(asb_ctx* ctx, int rest_shape, int subtract, 
                        (int)ctx->F, (int)ctx->Fp, rest_shape, subtract, ctx->mean, ctx->psum);
     ASB_CHECK_LAUNCH(ctx);
     ctx->have_mean = true;
-    if (subtract) ctx->e0_valid = false;
+    if (subtract) { ctx->e0_valid = false; ctx->ev_valid = false; }
     double tmp;
     return finish_sum(ctx, grid, local_sum ? local_sum : &tmp);
 }
@@ -553,6 +553,7 @@ extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     hipLaunchKernelGGL(k_e0_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->psum, ctx->pmax, ctx->mean_part, grid, ctx->e0_sc);
     ASB_CHECK_LAUNCH(ctx);
     ctx->e0_valid = true;
+    ctx->ev_valid = true;
     // share of |X|^2 along the constant-in-time direction (this sweep is part of the preparation, not of a deflation step)
     double h[3];
     ASB_HIP(ctx, hipMemcpyAsync(h, ctx->e0_sc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -49,12 +49,27 @@ class Comm(object):
         self._torch = None
         self._dev = None
         self._bufs = {}
+        # the stream RCCL collectives are enqueued on (torch's current stream when the communicator was made): a consumer
+        # may rely on stream order between a collective and an engine's kernels only if the engine runs on this very stream
+        self.stream_handle = None
         if self.multi:
             import torch
 
             self._torch = torch
             backend = self.dist.get_backend(group)
             self._dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+            if backend == "nccl":
+                self.stream_handle = int(torch.cuda.current_stream().cuda_stream)
+
+    def on_engine_stream(self, eng):
+        """True iff collectives issued now are stream-ordered against ``eng``'s kernels (same HIP stream)."""
+        if self.stream_handle is None or getattr(eng, "stream_handle", None) is None:
+            return False
+        try:
+            cur = int(self._torch.cuda.current_stream().cuda_stream)
+        except Exception:
+            return False
+        return cur == self.stream_handle == eng.stream_handle
 
     # ------------------------------------------------------------ partition
     def shards(self, N):

@@ -42,6 +42,8 @@ class HipEngine(object):
                                   "required; there is no CPU fallback" % (device_id, rc, msg))
         self.h = h
         self.device_id = int(device_id)
+        # the stream the context enqueues on, as torch would name it: None = private, 0 = the null stream, else the handle
+        self.stream_handle = None if stream is None else (0 if stream in (0, self.STREAM_DEFAULT) else int(stream))
         self.F = self.n_loc = self.v0 = self.N_glob = self.K = 0
 
     # ------------------------------------------------------------------ plumbing

@@ -124,10 +124,33 @@ class GeodesicDistanceComputation(object):
         SuperLU like the reference.  backend (with an engine): "dense" = the two SPD matrices are inverted once on the
         device (blocked Gauss-Jordan on f64 MFMA, N <= 46 000) and a query is a gather plus one dense product;
         "pcg" = batched Jacobi-PCG to relative residual ``tol`` (experimental)."""
-        verts = np.asarray(verts, dtype=np.float64)
-        tris = np.asarray(tris, dtype=np.int64)
+        # LAZY (round 3): the reference factorises both systems eagerly inside posSnapshots (:96-99, 0.27 s of SuperLU on the
+        # bunny) although only support='local' / SPLOCS ever query them; here construction only records its arguments and
+        # ``prepare()`` -- operator assembly + the device set-up (two N x N inverses in the dense mode) -- runs on the first
+        # query or the first access to one of the prepared attributes, so support='global' pays nothing.
+        self._args = (np.asarray(verts, dtype=np.float64), np.asarray(tris, dtype=np.int64), m, engine, tol, backend)
+        self.n = self._args[0].shape[0]
+        self.last_iterations = None
+        self._cache = {}                    # source vertex -> its distance field (solve_many)
+        self.cache_bytes = 2 << 30
+        self._ready = False
+
+    _PREPARED = frozenset(("G", "D", "_A_heat", "_L", "_engine", "_heat", "_poisson", "n_aggregates", "_tol"))
+
+    def __getattr__(self, name):            # only reached for attributes that are not set (yet)
+        if name in GeodesicDistanceComputation._PREPARED and not self.__dict__.get("_ready", True):
+            self.prepare()
+            return getattr(self, name)
+        raise AttributeError(name)
+
+    def prepare(self):
+        """Operator assembly and solver set-up (idempotent)."""
+        if self._ready:
+            return self
+        self._ready = True
+        verts, tris, m, engine, tol, backend = self._args
+        self._args = None
         n, M = verts.shape[0], tris.shape[0]
-        self.n = n
         p0, p1, p2 = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
         e01, e12, e20 = p1 - p0, p2 - p1, p0 - p2
         area = 0.5 * _vlen(np.cross(e01, e12))
@@ -164,9 +187,6 @@ class GeodesicDistanceComputation(object):
         self._A_heat = (sparse.diags(vert_area) - t * L).tocsr()
         self._L = L
         self._engine = None
-        self.last_iterations = None
-        self._cache = {}                    # source vertex -> its distance field (solve_many)
-        self.cache_bytes = 2 << 30
         if engine is not None:          # device backend instead of the SuperLU factorisations
             coarse = None
             if backend != "dense" and n >= 512:      # sparse mode: aggregates + dense coarse operators (two-level PCG)
@@ -182,7 +202,7 @@ class GeodesicDistanceComputation(object):
             engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D, dense=(backend == "dense"), coarse=coarse)
             self._engine = engine
             self._tol = tol
-            return
+            return self
         # both matrices are symmetric: the minimum-degree ordering on A + A^T halves SuperLU's fill against the
         # default COLAMD (2.2M -> 1.05M non-zeros on a 15k-vertex mesh), i.e. 2-4x faster triangular solves; the
         # solutions agree with the default ordering (what the reference uses) to 4e-13
@@ -192,6 +212,7 @@ class GeodesicDistanceComputation(object):
             self._poisson = splu(L.tocsc(), **kw)
         except RuntimeError:            # L is singular (constants): on some (tiny) meshes this ordering meets an exact
             self._poisson = splu(L.tocsc())     # zero pivot; the default ordering is what the reference factorises
+        return self
 
     def _field(self, U):
         """U: (n,) or (n,k) heat solutions -> distances, same shape."""
@@ -208,6 +229,7 @@ class GeodesicDistanceComputation(object):
         """Distances from each vertex in ``idxs``: (len(idxs), n).  One multi-RHS solve for the vertices not asked
         for before: the field of a source never changes, and SPLOCS asks for the same centres again in every outer
         iteration once they have settled (posComponents.py:158-165), so solved fields are kept (<= ``cache_bytes``)."""
+        self.prepare()
         idxs = np.asarray(idxs, dtype=np.int64)
         uniq = np.unique(idxs)
         new = np.array([i for i in uniq.tolist() if i not in self._cache], dtype=np.int64)

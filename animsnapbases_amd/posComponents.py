@@ -145,6 +145,8 @@ class posComponents:  # Components == bases
             if comm.multi:
                 rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
             geo = snaps.compute_geodesic_distance
+            if local and hasattr(geo, "prepare"):
+                geo.prepare()                         # (lazy: built on first use, posSnapshots only records mesh and backend)
             on_device_maps = local and getattr(geo, "_engine", None) is eng and getattr(eng, "geodesic_dense", False) \
                 and type(self).compute_support_map is posComponents.compute_support_map
             for k in range(K):

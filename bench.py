@@ -125,6 +125,9 @@ def other_config_pos(tag, fixture, support, kind, cpu=True):
 
     def prep():
         holder["snaps"] = posSnapshots.from_arrays(verts, tris, "first", standarize=True, massWeight=False)
+        if support == "local":      # the geodesic set-up is lazy (global support never pays it): here it belongs to the preparation
+            holder["snaps"].compute_geodesic_distance.prepare()
+            holder["snaps"]._engine.sync()
     t_prep, _ = _timed(prep, lambda: None)
     snaps = holder["snaps"]
     comp = posComponents(_pos_param(K, support, kind), snaps)
@@ -145,8 +148,8 @@ def other_config_pos(tag, fixture, support, kind, cpu=True):
            "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "prepare_ms": t_prep,
            "roofline": {"bound": "hbm", "level": "call", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
-                        "note": "SURVEY 8(d) algorithmic bytes of the whole call / its wall time; the %.0f MB tensor is "
-                                "Infinity-Cache resident, so this is a nominal HBM figure" % (24.0 * N * F / 1e6)}}
+                        "note": "SURVEY 8(d) algorithmic bytes of the whole call / its wall time; the %.0f MB tensor %s the 256 MB "
+                                "Infinity Cache, so this is a nominal HBM figure" % (24.0 * N * F / 1e6, "fits" if 24.0 * N * F <= 256e6 else "exceeds")}}
     if cpu:
         cores, model = _cpu_info()
         geo = orc.Geodesics(verts[0], tris) if support == "local" else None

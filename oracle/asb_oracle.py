@@ -522,6 +522,29 @@ def synth_snapshots(rest, F, rank=10, noise=1e-4, seed=0, mode_scale=0.02, decay
     return X
 
 
+def synth_uniform_snapshots(F, N, seed):
+    """Config 4's input ("throughput on pure random"): U[-1,1) frames from ONE ``default_rng(seed).uniform``
+    call, plus a triangle strip over the vertices -- global support never queries the geodesics, but the reference
+    factorises the two heat-method systems eagerly (posSnapshots.py:96-99) and needs some triangle list to do so."""
+    verts = np.random.default_rng(seed).uniform(-1.0, 1.0, size=(F, N, 3))
+    i = np.arange(N - 2, dtype=np.int32)
+    return verts, np.stack([i, i + 1, i + 2], axis=1)
+
+
+def synth_constraint_frames(F, ep, rank, decay, noise, seed, chunk=250):
+    """Config 5's input (low rank + noise): (F, ep, 3) = 0.1 + coef (F x r) . modes (r x 3 ep) + noise,
+    coef[:, j] ~ N(0, decay^2j); the noise is drawn ``chunk`` frames at a time (part of the definition: it fixes the order
+    in which the generator is consumed and bounds the peak memory to one copy of the tensor)."""
+    rng = np.random.default_rng(seed)
+    coef = rng.normal(size=(F, rank)) * (decay ** np.arange(rank))[None, :]
+    modes = rng.normal(size=(rank, ep * 3))
+    X = np.empty((F, ep * 3))
+    for f0 in range(0, F, chunk):
+        f1 = min(F, f0 + chunk)
+        X[f0:f1] = 0.1 + coef[f0:f1] @ modes + noise * rng.normal(size=(f1 - f0, ep * 3))
+    return X.reshape(F, ep, 3)
+
+
 # --------------------------------------------------------------------------------------
 # snapshot ingest   (utils/process.py)
 # --------------------------------------------------------------------------------------

@@ -65,11 +65,92 @@ def compact(comps, G, sv):
 
 
 def run(ref, tag, mesh, F, rank, kind, seed, over, noise=1e-4):
+    rest, tris = read_obj(mesh)
+    verts = orc.synth_snapshots(rest, F, rank=rank, noise=noise, seed=seed, kind=kind)
+    head = dict(rest=rest, tris=tris, F=np.array(F), rank=np.array(rank), kind=np.array(kind), seed=np.array(seed),
+                noise=np.array(noise), mesh=np.array(mesh), probe_seed=np.array(777))
+    run_arrays(ref, tag, verts, tris, over, head)
+
+
+def run_c4(ref, tag="c4_uniform_pca_global", F=2000, N=100000, K=128, seed=4):
+    verts, tris = orc.synth_uniform_snapshots(F, N, seed)
+    head = dict(F=np.array(F), N=np.array(N), seed=np.array(seed), kind=np.array("uniform"), probe_seed=np.array(777),
+                frame0_head=verts[0, :4].copy(), frame_last_tail=verts[-1, -4:].copy())
+    run_arrays(ref, tag, verts, tris, dict(vertPos_numComponents=K), head)
+
+
+def run_c5(ref, tag="c5_constraints_pod_deim", F=4000, ep=50000, K=256, rank=320, decay=0.955, noise=1e-9, seed=5):
+    """Config 5: constraintsComponents.compute_pod_for_vectorized_nonlinear_snapshots_tensor
+    (:298-320), post_process_components (:415-446; standardised, not orthogonalised) and deim (:797-860) of the UNMODIFIED
+    reference on 50 000 x 3 rows x 4 000 frames.  The spectrum decays geometrically through all K components (rank 320,
+    4.5 % per component, noise far below sigma_K), so every one of the K singular vectors is individually determined and
+    the whole Pt sequence is comparable, not only the head."""
+    import types
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    t0 = time.time()
+    frames = orc.synth_constraint_frames(F, ep, rank, decay, noise, seed)
+    print(tag, "input %.0f s" % (time.time() - t0), flush=True)
+    M = 3 * ep
+    rng = np.random.default_rng(778)
+    Gp = rng.normal(size=(M, NPROJ)) / np.sqrt(M)
+    sv = np.sort(rng.choice(ep, size=NSAMPLE, replace=False))
+    param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=False,
+                                  deim_desired_num_components=K, constProj_output_directory=os.getcwd())
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param = param
+    ns.rest_shape = "first"
+    ns.dim = 3
+    ns.frs = F
+    ns.constraintsSize = 1
+    ns.num_constained_elements = ep
+    ns.snapTensor = frames                          # the reference's read() leaves exactly this array (F, ep, 3) f64
+    out = dict(F=np.array(F), ep=np.array(ep), K=np.array(K), rank=np.array(rank), decay=np.array(decay),
+               noise=np.array(noise), seed=np.array(seed), probe_seed=np.array(778),
+               frame0_head=frames[0, :4].copy(), frame_last_tail=frames[-1, -4:].copy())
+    del frames
+    ns.mean = None
+    ns.pre_scale_factor = 1
+    ns.massL = ns.invMassL = None
+    ns.standarize()
+    out["pre_scale_factor"] = np.float64(ns.pre_scale_factor)
+    out["mean_proj"] = ns.mean.reshape(-1) @ Gp
+    cc = object.__new__(constraintsComponents)
+    cc.param = param
+    cc.nonlinearSnapshots = ns
+    cc.numComp = 0
+    cc.comps = None
+    cc.geom_interpol_verts = []
+    rows = []
+    writer = types.SimpleNamespace(writerow=lambda r: rows.append(list(r)))
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_pod_for_vectorized_nonlinear_snapshots_tensor(writer)
+    out["ref_seconds"] = np.array(time.time() - t0)
+    print(tag, "pod_vectorized %.0f s" % (time.time() - t0), flush=True)
+    out["S"] = np.array([r[1] for r in rows])
+    c = cc.comps.reshape(K, -1)
+    out.update(comps_proj=c @ Gp, comps_sample=cc.comps[:, sv, :].copy(), sample_rows=sv,
+               comps_gram_offdiag=np.abs(c @ c.T - np.eye(K)).max())
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.post_process_components()
+    c = cc.comps.reshape(K, -1)
+    out.update(post_proj=c @ Gp, post_sample=cc.comps[:, sv, :].copy(), post_norms=np.sqrt((c ** 2).sum(1)))
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.deim()
+    print(tag, "deim %.0f s" % (time.time() - t0), flush=True)
+    out["Pt"] = np.asarray(cc.geom_Pt, dtype=np.int64)
+    out["alpha"] = np.asarray(cc.geom_alpha, dtype=np.int64)
+    out["alpha_ranges"] = np.asarray(cc.geom_alpha_ranges, dtype=np.int64)
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.0f KB" % (os.path.getsize(path) / 1024), "Pt[:8]", out["Pt"][:8].tolist(), flush=True)
+
+
+def run_arrays(ref, tag, verts, tris, over, head):
     import snapbases.posComponents as pc_mod
     posSnapshots, posComponents = ref["posSnapshots"], ref["posComponents"]
-    rest, tris = read_obj(mesh)
-    N = rest.shape[0]
-    verts = orc.synth_snapshots(rest, F, rank=rank, noise=noise, seed=seed, kind=kind)
+    F, N = verts.shape[:2]
     G, H, sv = probes(N, F)
     work = os.getcwd()
     param = _param(vertPos_output_directory=work, name=tag, **over)
@@ -109,9 +190,7 @@ def run(ref, tag, mesh, F, rank, kind, seed, over, noise=1e-4):
     comp.fileNameBases = "q_pos_"
     comp.param = param
 
-    out = dict(rest=rest, tris=tris, F=np.array(F), rank=np.array(rank), kind=np.array(kind), seed=np.array(seed),
-               noise=np.array(noise), mesh=np.array(mesh), probe_seed=np.array(777),
-               pre_scale_factor=np.float64(snap.pre_scale_factor),
+    out = dict(head, pre_scale_factor=np.float64(snap.pre_scale_factor),
                mean_proj=snap.mean.reshape(-1) @ G, snap_proj=np.einsum("pf,fn->pn", H, snap.snapTensor.reshape(F, -1)) @ G)
 
     picked, geo_idx = [], []
@@ -233,6 +312,12 @@ def main():
         os.chdir(work)                             # log_time writes function_timings.txt into cwd
         try:
             for w in which:
+                if w == "c4":                      # ~20 min, ~25 GB: not part of the default list
+                    run_c4(ref)
+                    continue
+                if w == "c5":                      # ~30 min, ~25 GB
+                    run_c5(ref)
+                    continue
                 tag, mesh, F, rank, kind, seed, over = CASES[w]
                 run(ref, tag, mesh, F, rank, kind, seed, over)
         finally:
