@@ -1757,6 +1757,229 @@ __global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_project_l2d (round 3): k_project_l2c with the two things its probes said it was losing.
+//  (1) BALANCE.  1172 tiles of 256 rows drawn from a queue by 256 resident blocks are 4.58 rounds of work done in 5: the
+//      last round keeps 58 % of the CUs busy (8 % of an MFMA-bound launch).  Here every block owns a contiguous range of
+//      16-row groups (73 or 74 of the 18 750 at config 4), cut into rounds of at most 16 groups spread evenly over the four
+//      row-tile waves: 4 4 4 4 groups per wave and round, then 3 2 2 2 -- 19 group-times per block against 20, where 18.3 is
+//      the ideal.  A wave's number of groups NTV in {0 .. 4} is a template parameter of the tile body (one instantiation
+//      each: the counted waits need the same number of loads on every path of a body).
+//  (2) NO BLOCK BARRIER PER STAGE.  A stage's weights are complete when all 8 waves' direct loads have landed; a wave knows
+//      that of its OWN loads behind the next wait for an X chunk requested after them, so it then adds 1 to the stage's
+//      arrival counter in LDS, and a wave entering stage s spins on that counter (usually already 8: the arrivals happened
+//      two chunk pairs earlier) -- the waves no longer meet every stage, they only cannot run ahead of the data.  Three
+//      stage buffers instead of two: the loads of stage s + 1 go out while stage s is computed and overwrite stage s - 2,
+//      which every wave has left -- a wave can only be inside stage s once all 8 have ARRIVED for s, and a wave arrives
+//      for s while it computes s - 1.
+// Everything else as in k_project_l2c: 8 waves = (row tile rt) x (frame half sub), X chunks in two register sets used
+// alternately, direct loads / LDS reads by hand so that the compiler counts one kind of pending load.
+// --------------------------------------------------------------------------------------
+template <int NCT, int P, int NTV, int SYNC, int NSB, int MODE, int XD>
+__device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq,
+                                         const double* __restrict__ wn2, const WideArgs& wa, double* __restrict__ comps,
+                                         long long comp_stride, long long group0, double* lds, unsigned cnt_byte) {
+    constexpr int RT = 4, NTM = 4, NI = 4 * P * NCT, PER = NI / (2 * RT), NS = NSB;
+    constexpr bool CNT = (SYNC & 1) != 0, BAR = SYNC != 1;
+    constexpr int DIST = CNT ? NS - 2 : 1;                      // the direct loads run DIST stages ahead of the MFMAs
+    static_assert(!CNT || NS >= 3, "counters need a third buffer");
+    constexpr int STAGE_D = NI * 128;                           // doubles per stage
+    constexpr int NTA = NTV > 0 ? NTV : 1;                      // (array bounds of a wave without rows)
+    typedef double (*red_t)[NTM][4][64];
+    red_t red = reinterpret_cast<red_t>(lds);                   // shares the stages' memory (used behind the tile's last MFMA)
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w % RT, sub = w / RT;
+    const int nchunk = Fp / 16, npair = (nchunk + 1) / 2, nstage = (npair + P - 1) / P;
+    const long long base = group0 * 16;
+    auto issue_stage = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = w * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
+            const int c = 2 * s * P + cc;
+            if (c < nchunk) {
+                const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
+                const unsigned lds_byte = __builtin_amdgcn_readfirstlane((unsigned)(((s % NS) * STAGE_D + q * 128) * 8));
+                unsigned m0_keep;                                // m0 is the compiler's: put back what it held
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_keep) : "v"(src), "s"(lds_byte) : "memory");
+            }
+        }
+    };
+    // arrival for stage s: this wave's direct loads of it have landed (callers: behind a wait that covers them)
+    auto arrive = [&](int s) {
+        const unsigned addr = cnt_byte + 4u * (unsigned)(s % NS);      // LDS byte address (the dynamic LDS starts at 0, as for the stages)
+        const unsigned one = 1u;                                       // (every lane adds: 64 per wave, 512 per stage)
+        asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory");
+    };
+    // entry into stage s: all 8 waves have arrived for it (the buffer's (s / NS + 1)-th use in this tile)
+    auto enter = [&](int s) {
+        const unsigned addr = cnt_byte + 4u * (unsigned)(s % NS);
+        const unsigned want = 512u * (unsigned)(s / NS + 1);       // (ds_add_u32 is per lane: a wave adds 64)
+        unsigned got, sg;
+        asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_lt_u32 %1, %3\n\ts_cbranch_scc1 1b"
+                     : "=&v"(got), "=&s"(sg) : "v"(addr), "s"(want) : "memory", "scc");
+    };
+    const double4* xp[NTA];                                     // chunk c: xp[m][4 * c]
+#pragma unroll
+    for (int m = 0; m < NTA; ++m) {
+        long long r = base + 16 * m + i;
+        if (r >= rows) r = rows - 1;
+        xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+    }
+    d4 acc[NTA][NCT];
+#pragma unroll
+    for (int m = 0; m < NTA; ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+    // XD = 2: a THIRD register set, the X chunk of pair j + 2 is requested while pair j computes (twice the tolerance for
+    // a slow HBM access; 32 more registers)
+    static_assert(XD == 1 || XD == 2, "prefetch distance");
+    static_assert(!CNT || XD < P, "the arrival for the next stage must fall inside the stage");
+    double4 a0[NTA], a1[NTA], a2[XD == 2 ? NTA : 1];
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nstage) issue_stage(d);
+    if (NTV > 0) {
+        const int c = sub < nchunk ? sub : nchunk - 1;
+#pragma unroll
+        for (int m = 0; m < NTA; ++m) a0[m] = xp[m][4 * c];
+        if (XD == 2) {
+            const int c1 = 2 + sub < nchunk ? 2 + sub : nchunk - 1;
+#pragma unroll
+            for (int m = 0; m < NTA; ++m) a1[m] = xp[m][4 * c1];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                              // first stage(s) and first X chunk of the tile: one exposed latency
+    if (CNT) {
+#pragma unroll
+        for (int d = 0; d < DIST; ++d)
+            if (d < nstage) arrive(d);
+    }
+    auto pair_step = [&](int j, double4 (&cur)[NTA], double4 (&nxt)[NTA]) {
+        const int s = j / P;
+        if (j == s * P) {
+            if (CNT && MODE != 5) enter(s);
+            if (BAR && MODE != 5) __syncthreads();
+        }
+        if (NTV > 0 && (MODE == 3 || MODE == 4)) {                    // probes: no X traffic inside the loop
+#pragma unroll
+            for (int m = 0; m < NTA; ++m) nxt[m] = cur[m];
+        } else if (NTV > 0) {
+            // the next pair's X chunk flies while this pair's MFMAs issue -- unconditionally (behind the last pair: the last
+            // chunk once more): the same number of loads on every path keeps the compiler's waits counted ones
+            const int cn = 2 * (j + XD) + sub < nchunk ? 2 * (j + XD) + sub : nchunk - 1;
+#pragma unroll
+            for (int m = 0; m < NTA; ++m) nxt[m] = xp[m][4 * cn];
+        }
+        // pair XD of a stage: the loads of stage s + DIST (issued in the first pair, older than the XD chunks requested since)
+        // have landed once everything but the newest XD * 2 NTV loads is back -- the chunk this pair computes from among them
+        if (CNT && j == s * P + XD && s + DIST < nstage) {
+            if (MODE == 3 || MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (XD * NTV == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (XD * NTV == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (XD * NTV == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (XD * NTV == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (XD * NTV == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (XD * NTV == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrive(s + DIST);
+        }
+        bool issued = false;
+        if (NTV > 0 && 2 * j + sub < nchunk) {
+            const int cc = 2 * (j - s * P) + sub;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                double2 b0, b1;
+                if (MODE == 4) {                                // probe: no LDS reads either
+                    b0 = make_double2(cur[0].x, cur[0].y);
+                    b1 = make_double2(cur[0].z, cur[0].w);
+                } else {
+                    const unsigned lds_addr = (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));
+                }
+#pragma unroll
+                for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].x, b0.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].y, b0.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].z, b1.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].w, b1.y, acc[m][ct], 0, 0, 0);
+                // the next stage's direct loads go out BEHIND the wait for the current X chunk (the first MFMAs above)
+                if (ct == 0 && j == s * P && s + DIST < nstage) { issue_stage(s + DIST); issued = true; }
+            }
+        }
+        if (!issued && j == s * P && s + DIST < nstage) issue_stage(s + DIST);
+    };
+    if (XD == 1) {
+        for (int j = 0; j < npair; j += 2) {
+            pair_step(j, a0, a1);
+            if (j + 1 < npair) pair_step(j + 1, a1, a0);
+        }
+    } else {
+        auto& b2 = reinterpret_cast<double4 (&)[NTA]>(a2);
+        for (int j = 0; j < npair; j += 3) {
+            pair_step(j, a0, b2);
+            if (j + 1 < npair) pair_step(j + 1, a1, a0);
+            if (j + 2 < npair) pair_step(j + 2, b2, a1);
+        }
+    }
+    // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        __syncthreads();            // (first: every wave is behind its last read of a stage -- `red` shares that memory)
+        if (NTV > 0 && sub == 1) {
+#pragma unroll
+            for (int m = 0; m < NTA; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[rt][m][q][l] = acc[m][ct][q];
+        }
+        __syncthreads();
+        if (NTV > 0 && sub == 0 && i < wa.nc[ct]) {
+            const double inv = wn2[16 * ct + i];
+            double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
+#pragma unroll
+            for (int m = 0; m < NTA; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = (acc[m][ct][q] + red[rt][m][q][l]) / inv;
+        }
+    }
+}
+
+template <int NCT, int P, int SYNC = 1, int NSB = (SYNC ? 3 : 2), int MODE = 0, int XD = 1>      // MODE: timing probes (asb_test_l2w_probe)
+__global__ __launch_bounds__(512, 2) void k_project_l2d(
+    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
+    WideArgs wa, double* __restrict__ comps, long long comp_stride) {
+    constexpr int NI = 4 * P * NCT, NS = NSB, STAGE_D = NI * 128, RED_D = 4 * 4 * 4 * 64;
+    constexpr int BODY_D = NS * STAGE_D > RED_D ? NS * STAGE_D : RED_D;
+    static_assert(NI % 8 == 0, "stage instructions must divide over the 8 waves");
+    static_assert(P >= 2, "a stage must hold at least two chunk pairs (arrival / completion of the direct loads)");
+    static_assert((BODY_D + 2) * 8 <= 160 * 1024, "the stages must fit the LDS of a CU (gfx950: 160 KB)");
+    extern __shared__ double l2d_lds[];
+    unsigned* cnt = reinterpret_cast<unsigned*>(l2d_lds + BODY_D);          // NS arrival counters
+    const int tid = threadIdx.x, rt = (tid >> 6) & 3;
+    const long long ngroups = (rows + 15) / 16;
+    const long long g0 = ngroups * blockIdx.x / gridDim.x, g1 = ngroups * (blockIdx.x + 1) / gridDim.x;
+    constexpr unsigned CNT_BYTE = (unsigned)BODY_D * 8u;
+    for (long long gr = g0; gr < g1; gr += 16) {
+        const int n = (int)(g1 - gr < 16 ? g1 - gr : 16);                   // groups of this round, spread evenly over the 4 row-tile waves
+        const int bs = n >> 2, ex = n & 3;
+        const int ntv = bs + (rt < ex ? 1 : 0);
+        const long long start = gr + rt * bs + (rt < ex ? rt : ex);
+        __syncthreads();                                                    // the last round's reads of `red` are done
+        if (tid < NS) cnt[tid] = 0u;
+        __syncthreads();
+        switch (ntv) {
+            case 4: l2d_tile<NCT, P, 4, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
+            case 3: l2d_tile<NCT, P, 3, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
+            case 2: l2d_tile<NCT, P, 2, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
+            case 1: l2d_tile<NCT, P, 1, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
+            default: l2d_tile<NCT, P, 0, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
+        }
+    }
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 // scal[(k0 + t) * 4 + 3] = sum over the blocks' partial column sums; one wave per column (launch with 1024 threads)
 __global__ __launch_bounds__(1024) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
@@ -2143,8 +2366,30 @@ static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
                        ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
     return ASB_OK;
 }
+template <int NCT, int P, int SYNC, int NSB = (SYNC ? 3 : 2), int XD = 1>
+static int launch_l2d(asb_ctx* ctx, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc, ngroups = (rows + 15) / 16;
+    const size_t stage = (size_t)NSB * 4 * P * NCT * 128, redd = (size_t)4 * 4 * 4 * 64;
+    const size_t lds = ((stage > redd ? stage : redd) + 2) * sizeof(double);
+    static bool attr_set_dev[64] = {false};
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2d<NCT, P, SYNC, NSB, 0, XD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    // one block per CU, each with its own contiguous share of the 16-row groups (no work queue)
+    const long long nb = ngroups < ctx->n_cu ? ngroups : ctx->n_cu;
+    hipLaunchKernelGGL((k_project_l2d<NCT, P, SYNC, NSB, 0, XD>), dim3((unsigned)nb), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
+                       ctx->wn2t3, wa, ctx->comps, rows);
+    return ASB_OK;
+}
 template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
+    if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage
+    if (variant == 46 && NCT == 4) return launch_l2c<4, 3>(ctx, wa);         // round 2's kernel (tile queue, barrier per stage)
+    if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
+    if (variant == 48 && NCT == 4) return launch_l2d<4, 2, 1, 4>(ctx, wa);   // 32-KB stages, four buffers: direct loads two stages ahead
+    if (variant == 49 && NCT == 4) return launch_l2d<4, 3, 1, 3, 2>(ctx, wa);   // third X register set
     if (variant == 40 && NCT <= 5)       // weights staged in LDS by direct loads, one barrier per P chunk pairs
         return launch_l2c<(NCT <= 5 ? NCT : 2), (NCT <= 3 ? 4 : (NCT == 4 ? 3 : 2))>(ctx, wa);
     if (variant == 41 && NCT <= 5)       // the same with shorter stages
@@ -2164,7 +2409,7 @@ static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
     // default: up to 3 sub-panels every wave fetches its own weights (two waves per SIMD); 4 sub-panels only fit two waves per
     // SIMD with the weights in LDS (1.83 ms against 1.96 ms with one wave per SIMD; for 2 and 3 sub-panels the LDS form loses:
     // 1.15 / 1.32 against 1.07 / 1.22 ms)
-    if (NCT == 4) return launch_l2c<(NCT == 4 ? 4 : 2), 3>(ctx, wa);
+    if (NCT == 4) return launch_l2d<4, 3, 1>(ctx, wa);
     return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 1>(ctx, wa, NCT <= 3 ? 4 : 2);
 }
 static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
@@ -2263,7 +2508,18 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
                 hipLaunchKernelGGL((k_project_l2c<4, 3, 4, 4, 2, M>), dim3(grid), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, \
                                    ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);                                     \
             }
-            if (mode == 10) ASB_L2C_PROBE(0) else if (mode == 13) ASB_L2C_PROBE(3) else if (mode == 15) ASB_L2C_PROBE(5) else ASB_L2C_PROBE(4)
+#define ASB_L2D_PROBE(M)                                                                                                        \
+            {                                                                                                                   \
+                const size_t lds3 = ((size_t)3 * 4 * 3 * 4 * 128 + 2) * sizeof(double);                                         \
+                const long long ngr = (rows + 15) / 16;                                                                         \
+                ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2d<4, 3, 1, 3, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+                hipLaunchKernelGGL((k_project_l2d<4, 3, 1, 3, M>), dim3((unsigned)(ngr < ctx->n_cu ? ngr : ctx->n_cu)), dim3(512), lds3, ctx->stream, \
+                                   ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows);                     \
+            }
+            if (mode == 10) ASB_L2C_PROBE(0) else if (mode == 13) ASB_L2C_PROBE(3) else if (mode == 15) ASB_L2C_PROBE(5)
+            else if (mode == 20) ASB_L2D_PROBE(0) else if (mode == 23) ASB_L2D_PROBE(3) else if (mode == 24) ASB_L2D_PROBE(4)
+            else if (mode == 25) ASB_L2D_PROBE(5) else ASB_L2C_PROBE(4)
+#undef ASB_L2D_PROBE
 #undef ASB_L2C_PROBE
             rc = ASB_OK;
         }

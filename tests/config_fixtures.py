@@ -1,5 +1,5 @@
-"""Helpers shared by the CPU and GPU tests of the full-size config-2 / config-3 fixtures
-(``tests/golden/c2_*.npz``, ``c3_*.npz``; written by oracle/gen_golden_configs.py from the unmodified reference)."""
+"""Helpers shared by the CPU and GPU tests of the full-size config fixtures (``tests/golden/c2_*.npz``, ``c3_*.npz``,
+``c4_*.npz``, ``c5_*.npz``; written by oracle/gen_golden_configs.py from the unmodified reference)."""
 import types
 
 import numpy as np
@@ -18,7 +18,7 @@ def regen_frames(g):
 
 def probes(g):
     """Same seeded probe matrices / vertex sample as the generator (gen_golden_configs.probes)."""
-    N, F = g["rest"].shape[0], int(g["F"])
+    N, F = (g["rest"].shape[0] if "rest" in g else int(g["N"])), int(g["F"])
     rng = np.random.default_rng(int(g["probe_seed"]))
     G = rng.normal(size=(3 * N, NPROJ)) / np.sqrt(3 * N)
     H = rng.normal(size=(NPROJ, F)) / np.sqrt(F)
@@ -61,3 +61,27 @@ def check_deflation(g, psf, mean, idx, comps, weigs, measures, signed, tol, mtol
         rows = np.array([[float(x) for x in ln.split(",")] for ln in lines[1:] if ln])
         ref_rows = np.array([[float(x) for x in ln.split(",")] for ln in ref_lines[1:] if ln])
         assert rows.shape == ref_rows[:K].shape and relerr(rows, ref_rows[:K]) < mtol
+
+
+def c4_frames(g):
+    """Config 4's input, rebuilt on the host from the seed (oracle.synth_uniform_snapshots), checked against the corner
+    values the generator recorded."""
+    verts, _ = orc.synth_uniform_snapshots(int(g["F"]), int(g["N"]), int(g["seed"]))
+    assert np.array_equal(verts[0, :4], g["frame0_head"]) and np.array_equal(verts[-1, -4:], g["frame_last_tail"])
+    return verts
+
+
+def c5_frames(g):
+    frames = orc.synth_constraint_frames(int(g["F"]), int(g["ep"]), int(g["rank"]), float(g["decay"]), float(g["noise"]),
+                                         int(g["seed"]))
+    assert np.array_equal(frames[0, :4], g["frame0_head"]) and np.array_equal(frames[-1, -4:], g["frame_last_tail"])
+    return frames
+
+
+def c5_probes(g):
+    M = 3 * int(g["ep"])
+    rng = np.random.default_rng(int(g["probe_seed"]))
+    Gp = rng.normal(size=(M, NPROJ)) / np.sqrt(M)
+    sv = np.sort(rng.choice(int(g["ep"]), size=NSAMPLE, replace=False))
+    assert np.array_equal(sv, g["sample_rows"])
+    return Gp, sv

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, relerr
-from config_fixtures import check_deflation, make_param, probes, regen_frames
+from config_fixtures import c4_frames, c5_frames, c5_probes, check_deflation, make_param, probes, regen_frames
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -88,3 +88,95 @@ def test_config3_armadillo_splocs(tmp_path, capsys):
         assert relerr(H @ W, g["splocs_W_proj"][-1]) < 1e-7
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("itr ")]
     assert len(lines) == itrs and lines[0].startswith("itr 000, Energy =")
+
+
+def check_config4(g, snaps, comp, param, tmp_path):
+    """The whole of config 4 against the UNMODIFIED reference's run on the same 4.8 GB input (23 minutes of NumPy in the build
+    container, oracle/gen_golden_configs.py c4): the 128 selected vertices bit-exact, sigma / residual norms / CSV,
+    pre_scale_factor, the basis at 48 sampled vertices, its norms, 32 seeded projections of basis and weights, and the
+    post-processed basis."""
+    check_deflation(g, snaps.pre_scale_factor, snaps.mean, comp.selected_vertices, comp.comps, comp.weigs,
+                    comp.measures_at_largeDeforVerts, signed=False, tol=TOL, mtol=1e-7,
+                    csv=open(str(tmp_path / (param.name + "_posBases_pcaExtraction_singValues_errorNorm.csv"))).read())
+    G, H, sv = probes(g)
+    K = comp.numComp
+    sign = np.sign(np.einsum("kp,kp->k", comp.comps.reshape(K, -1) @ G, g["comps_proj"]))
+    comp.post_process_components()
+    got = (comp.comps - snaps.mean[None]) * sign[:, None, None] + snaps.mean[None]
+    assert relerr(got.reshape(K, -1) @ G, g["post_proj"]) < TOL
+    assert relerr(got[:, sv, :], g["post_sample"]) < TOL
+    assert relerr(np.sqrt((got.reshape(K, -1) ** 2).sum(1)), g["post_norms"]) < TOL
+
+
+def test_config4_full_size_vs_reference(tmp_path):
+    """BASELINE config 4 (the headline): U[-1,1) 100 000 vertices x 2 000 frames, K = 128, global support, standardised --
+    the default device path (guessed first panel, four sub-panels per read, k_panel_multi, k_project_l2d)."""
+    from animsnapbases_amd import posComponents, posSnapshots
+    g = load_golden("c4_uniform_pca_global")
+    verts = c4_frames(g)
+    param = make_param(g, vertPos_output_directory=str(tmp_path))
+    snaps = posSnapshots.from_arrays(verts, None, param.vertPos_rest_shape, standarize=param.q_standarize,
+                                     massWeight=param.q_massWeight)
+    del verts
+    comp = posComponents(param, snaps)
+    comp.compute_components_store_singvalues()
+    st = snaps._engine.deflate_stats()
+    assert st["panels"] <= 3                      # reads of X (2 on this input: 64 + 64 components)
+    check_config4(g, snaps, comp, param, tmp_path)
+
+
+def test_config5_full_size_vs_reference(tmp_path):
+    """BASELINE config 5 at size: 50 000 x 3 rows x 4 000 frames, pod_vectorized K = 256 + post-processing + DEIM against
+    the unmodified reference (SciPy gesdd on the 150 000 x 4 000 matrix + the lstsq loop): all 4 000 singular values that
+    the data determine, all 256 vectors (sign-aligned), the post-processed basis and the whole 256-point DEIM sequence."""
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    import types
+    g = load_golden("c5_constraints_pod_deim")
+    frames = c5_frames(g)
+    K = int(g["K"])
+    param = types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=0, constProj_p_size=1,
+                                  constProj_massWeight=False, constProj_standarize=True, constProj_orthogonal=False,
+                                  constProj_basis_type="pod_vectorized", deim_desired_num_components=K,
+                                  constProj_store_sing_val=True, constProj_output_directory=str(tmp_path), name="c5",
+                                  constProj_name="verts")
+    ns = nonlinearSnapshots(param, frames=frames)
+    del frames
+    ns.config()
+    ns.snapshots_prepare()
+    assert abs(ns.pre_scale_factor - float(g["pre_scale_factor"])) < 1e-12 * float(g["pre_scale_factor"])
+    Gp, sv = c5_probes(g)
+    assert relerr(ns.mean.reshape(-1) @ Gp, g["mean_proj"]) < 1e-12
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.compute_components_store_singvalues()
+    S = cc.singular_values
+    big = g["S"] > 1e-6 * g["S"][0]               # (the 320 that are signal; the rest is the 1e-9 noise floor)
+    assert big.sum() >= K and relerr(S[big], g["S"][big]) < 1e-9
+    comps = cc.comps.copy()
+    P = comps.reshape(K, -1) @ Gp
+    sign = np.sign(np.einsum("kp,kp->k", P, g["comps_proj"]))
+    # accuracy of the Gram route + Rayleigh-Ritz: eps (sigma_0 / sigma_k)^2 leaks into directions beyond the K + 32 Ritz
+    # vectors, i.e. ~1e-6 on the LAST vectors here (sigma_256 = 3e-6 sigma_0) and rounding level on the strong ones; the
+    # bar is north_star's 1e-5 relative Frobenius error on the basis
+    per = np.sqrt((((P * sign[:, None]) - g["comps_proj"]) ** 2).sum(1) / (g["comps_proj"] ** 2).sum(1))
+    print("config 5: per-vector error of the 32 projections: head", per[:4], "k=128", per[126:130], "tail", per[-4:])
+    strong = g["S"][:K] > 1e-4 * g["S"][0]
+    assert strong.sum() >= 128 and per[strong].max() < 1e-8
+    assert relerr(P * sign[:, None], g["comps_proj"]) < 1e-5
+    assert relerr(comps[:, sv, :] * sign[:, None, None], g["comps_sample"]) < 1e-5
+    assert np.abs(comps.reshape(K, -1) @ comps.reshape(K, -1).T - np.eye(K)).max() < 1e-10
+    # install the reference's signs (LAPACK's are arbitrary and "+ mean" is not symmetric), post-process, DEIM
+    cc.comps = comps * sign[:, None, None]
+    del comps
+    cc.post_process_components()
+    post = cc.comps
+    assert relerr(post.reshape(K, -1) @ Gp, g["post_proj"]) < 1e-5
+    assert relerr(post[:, sv, :], g["post_sample"]) < 1e-5
+    assert relerr(np.sqrt((post.reshape(K, -1) ** 2).sum(1)), g["post_norms"]) < 1e-9
+    cc.deim()
+    same = np.asarray(cc.geom_Pt) == g["Pt"]
+    print("config 5: DEIM points equal to the reference's:", int(same.sum()), "of", K, "first difference at",
+          int(np.argmin(same)) if not same.all() else None)
+    assert cc.geom_Pt.tolist() == g["Pt"].tolist()                       # 256 interpolation points, bit-exact
+    assert cc.geom_alpha.tolist() == g["alpha"].tolist()
+    assert cc.geom_alpha_ranges.tolist() == g["alpha_ranges"].tolist()

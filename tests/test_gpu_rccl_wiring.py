@@ -154,3 +154,22 @@ def test_pod_deim_through_rccl(rccl_comm, tmp_path):
     for l in range(3):
         assert np.allclose(cc.comps[:, :, l] @ cc.comps[:, :, l].T, np.eye(K), atol=1e-10)
     assert len(set(cc.geom_Pt.tolist())) == K
+
+
+def test_config4_full_size_vs_reference_through_rccl(rccl_comm, tmp_path):
+    """The headline configuration through the MULTI-RANK protocol (every collective issued, candidates assembled, sub-panels
+    through asb_panel_sub_*) against the unmodified reference's run on the same input (tests/golden/c4_*.npz)."""
+    from animsnapbases_amd import posComponents, posSnapshots
+    from conftest import load_golden
+    from config_fixtures import c4_frames, make_param
+    from test_gpu_configs import check_config4
+    g = load_golden("c4_uniform_pca_global")
+    verts = c4_frames(g)
+    param = make_param(g, vertPos_output_directory=str(tmp_path))
+    snaps = posSnapshots.from_arrays(verts, None, param.vertPos_rest_shape, standarize=param.q_standarize,
+                                     massWeight=param.q_massWeight, comm=rccl_comm)
+    del verts
+    comp = posComponents(param, snaps)
+    with contextlib.redirect_stdout(io.StringIO()):
+        comp.compute_components_store_singvalues()
+    check_config4(g, snaps, comp, param, tmp_path)

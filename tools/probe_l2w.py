@@ -43,3 +43,10 @@ for nct in (2, 3):
 ms = ctypes.c_double()
 eng._ck(eng.lib.asb_test_l2w_probe(eng.h, 4, 15, 5, ctypes.byref(ms)))
 print("k_project_l2c<4,3> without the barrier per stage (wrong results, timing only): %.3f ms" % ms.value, flush=True)
+out = []
+for mode in (20, 23, 24, 25):
+    ms = ctypes.c_double()
+    eng._ck(eng.lib.asb_test_l2w_probe(eng.h, 4, mode, 5, ctypes.byref(ms)))
+    out.append(ms.value)
+print("k_project_l2d<4,3> (round 3): as it runs %.3f ms | no X loads inside the loop %.3f ms | nor LDS reads of the weights %.3f ms | "
+      "as it runs without the stage synchronisation (wrong results, timing only) %.3f ms" % tuple(out), flush=True)
