@@ -46,6 +46,8 @@ PROTOTYPES = {
     "asb_deflate_apply": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_deflate_run_global": (c_int, [ctypes.c_void_p, c_i64, c_i64]),
     "asb_deflate_results": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_components_stream": (c_int, [ctypes.c_void_p, c_int]),
+    "asb_components_pinned": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "asb_panel_scale": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_dbl]),
     "asb_panel_hist": (c_int, [ctypes.c_void_p, c_int, c_dp]),
     "asb_panel_tau": (c_int, [ctypes.c_void_p, c_int, c_dp]),

@@ -80,6 +80,13 @@ struct asb_ctx {
     int64_t K = 0;
     int mode = 0, local = 0;
     int64_t k_done = 0;
+    // overlapped download of the basis (asb_components_stream): pinned (K, n_loc, 3) buffer, copy stream, rows enqueued so far
+    int dl_enabled = 0;
+    double* dl_host = nullptr;
+    size_t dl_host_count = 0;
+    hipStream_t dl_stream = nullptr;
+    hipEvent_t dl_event = nullptr;
+    long long dl_done = 0;
     unsigned* coop_bar = nullptr;     // k_panel_multi: flags [-, abort, too many candidates, -] + debug timestamps
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop
@@ -281,6 +288,22 @@ static inline int asb_alloc(asb_ctx* ctx, T** p, size_t count) {
     if (count == 0) return ASB_OK;
     ASB_HIP(ctx, hipMalloc((void**)p, want));
     ctx->alloc_bytes[(void*)p] = want;
+    return ASB_OK;
+}
+
+int asb_dl_begin(asb_ctx* ctx);          // asb_linalg.hip
+// component rows [dl_done, k_to) are final: copy them to the pinned buffer on the copy stream, behind what the main stream
+// has enqueued so far (no-op unless asb_components_stream is on)
+static inline int asb_dl_enqueue(asb_ctx* ctx, long long k_to) {
+    if (!ctx->dl_enabled || !ctx->dl_host || !ctx->comps || k_to <= ctx->dl_done) return ASB_OK;
+    if (k_to > ctx->K) k_to = ctx->K;
+    const size_t row = (size_t)3 * ctx->n_loc;
+    if ((size_t)k_to * row > ctx->dl_host_count) return ASB_OK;
+    ASB_HIP(ctx, hipEventRecord(ctx->dl_event, ctx->stream));
+    ASB_HIP(ctx, hipStreamWaitEvent(ctx->dl_stream, ctx->dl_event, 0));
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->dl_host + (size_t)ctx->dl_done * row, ctx->comps + (size_t)ctx->dl_done * row,
+                                (size_t)(k_to - ctx->dl_done) * row * sizeof(double), hipMemcpyDeviceToHost, ctx->dl_stream));
+    ctx->dl_done = k_to;
     return ASB_OK;
 }
 

@@ -46,6 +46,10 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->n_spec_steps = ctx->n_spec_kept = 0;
     ctx->n_guess_panels = 0;
     ctx->spec_budget = ASB_PANEL_COLS;
+    {
+        const int rcd = asb_dl_begin(ctx);          // overlapped download of the basis (asb_components_stream): a new run
+        if (rcd) return rcd;
+    }
     if (mode == ASB_DEFLATE_PROJECT) return asb_project_begin(ctx, K);
     const size_t rows = (size_t)ctx->n_loc * 3;
     int rc;

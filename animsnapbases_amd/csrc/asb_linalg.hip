@@ -550,3 +550,50 @@ extern "C" int asb_components_download(asb_ctx* ctx, double* comps_out) {
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }
+
+// ---- the basis into pinned host memory, overlapped with the run (include/asb.h)
+static int dl_reserve(asb_ctx* ctx) {
+    const size_t want = (size_t)ctx->K * 3 * ctx->n_loc;
+    if (ctx->dl_host && ctx->dl_host_count >= want) return ASB_OK;
+    if (ctx->dl_host) {
+        (void)hipHostFree(ctx->dl_host);
+        ctx->dl_host = nullptr;
+        ctx->dl_host_count = 0;
+    }
+    if (want == 0) return ASB_OK;
+    ASB_HIP(ctx, hipHostMalloc((void**)&ctx->dl_host, want * sizeof(double), hipHostMallocDefault));
+    ctx->dl_host_count = want;
+    return ASB_OK;
+}
+extern "C" int asb_components_stream(asb_ctx* ctx, int enable) {
+    if (!ctx) return ASB_ERR_ARG;
+    if (!enable) {
+        if (ctx->dl_stream) (void)hipStreamSynchronize(ctx->dl_stream);
+        if (ctx->dl_host) (void)hipHostFree(ctx->dl_host);
+        ctx->dl_host = nullptr;
+        ctx->dl_host_count = 0;
+        ctx->dl_enabled = 0;
+        return ASB_OK;
+    }
+    if (!ctx->dl_stream) ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->dl_stream, hipStreamNonBlocking));
+    if (!ctx->dl_event) ASB_HIP(ctx, hipEventCreateWithFlags(&ctx->dl_event, hipEventDisableTiming));
+    ctx->dl_enabled = 1;
+    ctx->dl_done = 0;
+    return (ctx->K > 0 && ctx->n_loc > 0) ? dl_reserve(ctx) : ASB_OK;
+}
+// called by asb_deflate_begin: a new run starts (K is known): the pinned buffer is (re)sized, nothing is copied yet
+int asb_dl_begin(asb_ctx* ctx) {
+    if (!ctx->dl_enabled) return ASB_OK;
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));      // (copies of the last run still in flight read the old basis)
+    ctx->dl_done = 0;
+    return dl_reserve(ctx);
+}
+extern "C" int asb_components_pinned(asb_ctx* ctx, double** out) {
+    if (!ctx || !out || !ctx->comps) return ASB_ERR_ARG;
+    if (!ctx->dl_enabled || !ctx->dl_host) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_components_pinned: asb_components_stream is off");
+    int rc;
+    if ((rc = asb_dl_enqueue(ctx, ctx->K))) return rc;      // what is left (everything, for the paths that do not stream)
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
+    *out = ctx->dl_host;
+    return ASB_OK;
+}

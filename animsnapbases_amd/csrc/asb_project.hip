@@ -4385,6 +4385,9 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     const bool use_double = ctx->double_panels && !use_super && !global_all && ctx->panel_coop && ctx->Fp <= 2048 && ctx->spec_panels;
     while (k < k1) {
         ctx->sel_e2 = nullptr;
+        // rows below k are final (projection mode never rewrites a committed column): their copy to the pinned buffer runs
+        // on the copy stream while the next read of X computes (asb_components_stream; no-op otherwise)
+        if ((rc = asb_dl_enqueue(ctx, k))) return rc;
         if (use_double && stalled == 0) {
             int64_t done = 0;
             if ((rc = double_panel(ctx, k, k1, &done))) return rc;

@@ -576,6 +576,20 @@ class HipEngine(object):
         self._ck(rc)
         return row
 
+    def components_stream(self, enable=True):
+        """Overlapped download of the basis into a pinned host buffer owned by the context (asb.h: asb_components_stream)."""
+        self._ck(self.lib.asb_components_stream(self.h, 1 if enable else 0))
+        self._streaming = bool(enable)
+
+    def components_pinned(self):
+        """(K, n_loc, 3) ndarray VIEW of the context's pinned buffer: valid until the next deflate_begin on this engine."""
+        p = ctypes.c_void_p()
+        self._ck(self.lib.asb_components_pinned(self.h, ctypes.byref(p)))
+        n = int(self.K) * int(self.n_loc) * 3
+        buf = (ctypes.c_double * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.K, self.n_loc, 3)
+        return arr
+
     def results_comps(self):
         out = np.empty((self.K, self.n_loc, 3))
         self._ck(self.lib.asb_components_download(self.h, ptr(out)))

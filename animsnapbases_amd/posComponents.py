@@ -77,6 +77,11 @@ class posComponents:  # Components == bases
     def comps(self):
         if self._comps is None and self._comps_on_device:
             eng, comm = self.pos_snapshots._engine, self.pos_snapshots._comm
+            if getattr(self, "_comps_streamed", False) and getattr(eng, "_streaming", False) and not comm.multi:
+                # the engine streamed the rows into its pinned buffer while it computed (HipEngine.components_stream): a plain
+                # ndarray over that buffer, valid until the next run on this engine (np.array(...) to keep it longer)
+                self._comps = eng.components_pinned()
+                return self._comps
             loc = eng.results(want_comps=True, want_weigs=False)["comps"]
             self._comps = comm.all_gather_rows(loc, self.pos_snapshots.nVerts, axis=1)
         return self._comps
@@ -172,6 +177,7 @@ class posComponents:  # Components == bases
         self.weigs = res["weigs"]
         self.selected_vertices = res["idx"]
         self._comps, self._comps_on_device = None, True
+        self._comps_streamed = True     # the engine's pinned buffer (if it streams) holds exactly this run's basis
         self.measures_at_largeDeforVerts = np.column_stack([np.arange(K, dtype=np.float64), res["sigma"], normR])
         if self.storeSingVal and writer is not None:
             for k in range(K):
@@ -300,6 +306,7 @@ class posComponents:  # Components == bases
         snaps = self.pos_snapshots
         eng, comm = snaps._engine, snaps._comm
         v0, n_loc = snaps._shards[comm.rank]
+        self._comps_streamed = False    # (the device basis is about to change: a later read copies it afresh)
         if not self._comps_on_device:
             if self._comps is None:
                 raise ValueError("no components: run compute_components_store_singvalues first")

@@ -178,6 +178,45 @@ def other_config_pos(tag, fixture, support, kind, cpu=True):
     return out
 
 
+def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50):
+    """config 4's shape on STRUCTURED data ("parity on low-rank + noise"): rest + coef (F x r) . modes (r x N x 3)
+    + 1e-4 noise, modes ~ N(0, 0.02^2), coef[:, j] ~ N(0, 0.9^2j) -- every strong component reshuffles all energies, so a read
+    of X commits fewer components than on the random tensor of the headline."""
+    import torch
+    from animsnapbases_amd import posComponents, posSnapshots
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    rest = torch.randn((N * 3,), dtype=torch.float64, device=dev, generator=gen)
+    coef = torch.randn((F, r), dtype=torch.float64, device=dev, generator=gen) * (0.9 ** torch.arange(r, dtype=torch.float64, device=dev))[None]
+    modes = 0.02 * torch.randn((r, N * 3), dtype=torch.float64, device=dev, generator=gen)
+    Xd = rest[None] + coef @ modes
+    Xd += 1e-4 * torch.randn((F, N * 3), dtype=torch.float64, device=dev, generator=gen)
+    del coef, modes, rest
+    torch.cuda.synchronize()
+    holder = {}
+
+    def prep():
+        holder["snaps"] = posSnapshots.from_device(Xd.data_ptr(), F, N, rest_shape="first", standarize=True, keepalive=Xd)
+        holder["snaps"]._engine.sync()
+    t_prep, _ = _timed(prep, torch.cuda.synchronize)
+    snaps = holder["snaps"]
+    comp = posComponents(_pos_param(K, "global"), snaps)
+    sync = snaps._engine.sync
+    _timed(lambda: comp.extract_k_components(None), sync)                 # warm-up
+    ms, _ = _timed(lambda: comp.extract_k_components(None), sync)
+    st = snaps._engine.deflate_stats()
+    assert len(set(comp.selected_vertices.tolist())) == K
+    reads = st["panels"] + st.get("energy_passes", 0) + st.get("refreshes", 0)
+    out = {"workload": "config4 shape, low rank (%d) + 1e-4 noise: %d verts x %d frames, PCA K=%d global" % (r, N, F, K),
+           "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "prepare_ms": t_prep, "reads_of_X": reads, "panels": st["panels"],
+           "refreshes": st.get("refreshes", 0),
+           "roofline": {"bound": "hbm", "level": "call", "achieved": reads * 24.0 * N * F / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": reads * 24.0 * N * F / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "(reads of X) x 24 N F bytes / wall time: what THIS algorithm reads on this data"}}
+    del comp, snaps, holder
+    return out
+
+
 def other_config_c5(dev, cpu=True, ep=50000, F=4000, K=256):
     """config 5: constraint-projection snapshots 50 000 x 3 rows x 4 000 frames, POD (pod_vectorized) K = 256 + DEIM."""
     import torch
@@ -336,6 +375,34 @@ def main():
     basis_bytes = basis.nbytes
     del basis
 
+    # Steady-state end to end (one GPU): a SECOND animation on the same context -- its buffers exist, the basis streams into
+    # the context's pinned host buffer while the second read of X still computes (HipEngine.components_stream), and `comps`
+    # is a plain ndarray over that buffer.  Timed as ONE region, input tensor in HBM to basis in host memory, no
+    # synchronisation in between; the first cycle warms the path up (pinned pages, allocations), the second is reported.
+    steady = None
+    if world == 1 and not forced:
+        eng.components_stream(True)
+        for cyc in range(2):
+            gen.manual_seed(4321 + cyc)
+            Xd2 = torch.rand((F, n_loc, 3), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(quiet):
+                snaps2 = posSnapshots.from_device(Xd2.data_ptr(), F, n_loc, rest_shape="first", standarize=True, comm=comm,
+                                                  keepalive=Xd2, engine=eng)
+                t1 = time.perf_counter()
+                comp2 = posComponents(_pos_param(K, "global"), snaps2)
+                comp2.extract_k_components(None)
+                t2 = time.perf_counter()
+                basis2 = comp2.comps
+            t3 = time.perf_counter()
+            assert isinstance(basis2, np.ndarray) and basis2.shape == (K, n_loc, 3) and np.isfinite(basis2[-1]).all()
+            steady = {"prepare_ms": (t1 - t0) * 1e3, "step_ms": (t2 - t1) * 1e3, "basis_wait_ms": (t3 - t2) * 1e3,
+                      "total_ms": (t3 - t0) * 1e3, "snapshots_per_s": F / (t3 - t0)}
+            del basis2, comp2, snaps2, Xd2
+        eng.components_stream(False)
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = F * args.steps / dt
@@ -421,11 +488,19 @@ def main():
                          # SURVEY.md 8(d) priced a step at 24 N F (1 + K) bytes (one read of X per component); the panel
                          # algorithm commits up to 16 components per read, so that figure is not a roofline for it
                          survey_step_bytes=24.0 * N * F * (1 + K)),
-            "end_to_end": {"prepare_ms": prepare_ms, "step_ms": ms_step, "basis_download_ms": download_ms,
-                           "basis_bytes": basis_bytes, "total_ms": prepare_ms + ms_step + download_ms,
-                           "snapshots_per_s": F / ((prepare_ms + ms_step + download_ms) * 1e-3),
-                           "note": "input already in HBM (F,N,3); prepare = vertex-major layout change + rest shape + "
-                                   "standardisation; download = the (K,N,3) basis into pageable host memory"},
+            # steady state (what a second animation on a warm context costs) first; `cold` = the first cycle of the process
+            # (allocation of the 4.8 GB shard inside prepare, the basis into freshly allocated pageable memory)
+            "end_to_end": dict(steady or {}, basis_bytes=basis_bytes,
+                               note="input already in HBM (F,N,3) -> basis (K,N,3) as an ndarray in (pinned) host memory, one timed "
+                                    "region without intermediate synchronisation, second cycle on a warm context: prepare = "
+                                    "vertex-major layout change + rest shape + standardisation (the calls' host time: the kernels "
+                                    "overlap with what follows), step = extract_k_components with the basis streamed to the host "
+                                    "behind each read of X, basis_wait = what is left of the copy afterwards",
+                               cold={"prepare_ms": prepare_ms, "step_ms": ms_step, "basis_download_ms": download_ms,
+                                     "total_ms": prepare_ms + ms_step + download_ms,
+                                     "snapshots_per_s": F / ((prepare_ms + ms_step + download_ms) * 1e-3),
+                                     "note": "first cycle of the process: prepare includes the allocation of the shard, the "
+                                             "download goes into pageable memory"}),
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline_c4(F, N, K, args.cpu_budget)
@@ -434,7 +509,8 @@ def main():
         torch.cuda.empty_cache()
         cpu = not args.no_cpu_baseline
         oc = {}
-        for tag, fn in (("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
+        for tag, fn in (("c4_lowrank", lambda: other_config_c4_lowrank(dev)),
+                        ("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
                         ("c2_local", lambda: other_config_pos("config2 (local support)", "c2_bunny_pca_local", "local", "PCA", cpu)),
                         ("c3", lambda: other_config_pos("config3", "c3_armadillo_splocs", "local", "SPLOCS", cpu)),
                         ("c5", lambda: other_config_c5(dev, cpu))):

@@ -286,6 +286,14 @@ int asb_components_transform(asb_ctx* ctx, const double* T_host);
 int asb_components_expand(asb_ctx* ctx, const double* coef_host, int64_t r, int64_t F, double* out_host);
 /* the device-resident basis (K, n_loc, 3) to the host */
 int asb_components_download(asb_ctx* ctx, double* comps_out);
+/* The basis into PINNED host memory, overlapped with the run that produces it (posComponents.py:119 leaves `comps` in host
+ * memory: `self.comps = array(C)`).  asb_components_stream(ctx, 1) before asb_deflate_begin: the context keeps a pinned
+ * (K, n_loc, 3) buffer and a copy stream; every component row is copied as soon as it is final (projection mode: after each
+ * read of X, while the next read runs; otherwise at the end).  asb_components_pinned waits for the copies and returns the
+ * buffer: valid until the next asb_deflate_begin / destroy on this context (the caller copies what it wants to keep).
+ * asb_components_stream(ctx, 0) switches it off and frees the buffer. */
+int asb_components_stream(asb_ctx* ctx, int enable);
+int asb_components_pinned(asb_ctx* ctx, double** comps_pinned_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
 int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
 
