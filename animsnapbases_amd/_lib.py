@@ -46,6 +46,11 @@ PROTOTYPES = {
     "asb_deflate_apply": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_deflate_run_global": (c_int, [ctypes.c_void_p, c_i64, c_i64]),
     "asb_deflate_results": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "asb_st_upload": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "asb_st_residual_argmax": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+    "asb_deflate_residual_norm2": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
+    "asb_deim_block_residual_st": (c_int, [ctypes.c_void_p, c_i64, c_int, c_dp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64),
+                                           ctypes.POINTER(c_dbl)]),
     "asb_components_stream": (c_int, [ctypes.c_void_p, c_int]),
     "asb_components_pinned": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "asb_panel_scale": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_dbl]),

@@ -30,6 +30,40 @@ from .distributed import Comm
 from .engine import HipEngine
 from .utils import log_time, summed_grams, testSparsity, test_linear_dependency, test_linear_dependency_grams
 
+
+def read_sparse_matrix(file_name, file_type, key=None):
+    """The sparse operator files of the reference (utils/utils.py:289-323): ``.npz`` holding a pickled scipy matrix under
+    ``key``, or the C++ recorder's ``.bin`` -- ``<i rows><i cols><i nnz>`` then nnz triplets ``<i row><i col><d value>``."""
+    from scipy.sparse import csr_matrix
+    if file_type == ".npz":
+        if key is None:
+            raise ValueError("Empty file or wrong key:", file_type)
+        M = np.load(file_name, allow_pickle=True)[key]
+        return M.item() if isinstance(M, np.ndarray) and M.dtype == object else M
+    if file_type == ".bin":
+        raw = np.fromfile(file_name, dtype=np.uint8)
+        rows, cols, nnz = np.frombuffer(raw[:12].tobytes(), dtype="<i4")
+        trip = np.frombuffer(raw[12:12 + 16 * int(nnz)].tobytes(), dtype=np.dtype([("r", "<i4"), ("c", "<i4"), ("v", "<f8")]))
+        return csr_matrix((trip["v"], (trip["r"], trip["c"])), shape=(int(rows), int(cols)))
+    raise ValueError("unknown sparse matrix file_type:", file_type)
+
+
+def elements_of_vertex(v, elems):
+    """Indices (ascending) of the elements -- tets, triangles or edges, one per row of ``elems`` -- that contain vertex v:
+    what get_tetrahedrons_per_vert / get_triangles_per_vert / get_edges_per_vert return for ``[v]``
+    (utils/support.py:210-258), as one vectorised comparison."""
+    return np.flatnonzero((np.asarray(elems) == v).any(axis=1)).tolist()
+
+
+def vertex_star(v, faces):
+    """get_vert_star_per_vert (utils/support.py:239-246): the vertices of every face that contains v, v itself included, in
+    the order ``list(set)`` yields them -- reproduced by building the same set in the same insertion order."""
+    faces = np.asarray(faces)
+    star = set()
+    for f in faces[(faces == v).any(axis=1)]:
+        star.update(int(q) for q in f)
+    return list(star)
+
 constProj_output_directory = ""
 
 
@@ -52,6 +86,10 @@ class nonlinearSnapshots:
         self.invMassL = None
         self._snapTensor = None
         self.test_snapTensor = None
+        # element lists of the simulation mesh (the reference fills them from mesh files through libigl; here they are handed
+        # over, e.g. ns.tris = ...): used by the S^T variants to count / list the elements around a position-space vertex
+        self.verts = self.tris = self.tets = self.edges = None
+        self.ele_type = ""
         self.param = param
         self._frames, self._test_frames, self._preset_mass = frames, test_frames, mass
         # (dev_ptr, F, rows): an (F, rows, 3) float64 tensor already in this rank's HBM -- this rank's shard of the
@@ -97,8 +135,6 @@ class nonlinearSnapshots:
             self._engine = HipEngine(dev, stream)
         eng, comm = self._engine, self._comm
         if self._frames_device is not None:
-            if self.param.constProj_massWeight:
-                raise NotImplementedError("mass weighting of device-resident constraint snapshots")
             ptr_, F, rows = self._frames_device
             counts = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * rows) if comm.multi else np.array([rows])
             self._shards, v0 = [], 0
@@ -108,15 +144,22 @@ class nonlinearSnapshots:
             self.frames_rows = int(counts.sum())
             self.frs = int(F)
             self.num_constained_elements = self.frames_rows // self.constraintsSize
+            massL = None
+            if self.param.constProj_massWeight:             # (:82-88: M^{1/2} X, applied in the layout-change sweep)
+                self.load_factorize_masses()
+                assert self.massL.shape[0] == self.frames_rows
+                r0 = self._shards[comm.rank][0]
+                massL = np.ascontiguousarray(self.massL[r0:r0 + int(rows)])
             fused = None
             if self.rest_shape in ("first", "average") and self.param.constProj_standarize:
-                fused = eng.adopt_device_rest(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows,
+                fused = eng.adopt_device_rest(int(ptr_), int(F), int(rows), massL, self._shards[comm.rank][0], self.frames_rows,
                                               0 if self.rest_shape == "first" else 1, True)
             else:
-                eng.adopt_device(int(ptr_), int(F), int(rows), None, self._shards[comm.rank][0], self.frames_rows)
+                eng.adopt_device(int(ptr_), int(F), int(rows), massL, self._shards[comm.rank][0], self.frames_rows)
             if self.param.constProj_standarize:
                 self.standarize(_fused=fused)
-            print('nonlinearSnapshots ready ... Volkwein (False), standarized (' + str(self.param.constProj_standarize) + ').')
+            print('nonlinearSnapshots ready ... Volkwein (' + str(self.param.constProj_massWeight) + '), standarized (' +
+                  str(self.param.constProj_standarize) + ').')
             return
         self.frames_rows = X.shape[1]
         massL = None
@@ -148,14 +191,23 @@ class nonlinearSnapshots:
             X = np.asarray(self._frames, dtype=np.float64)
             self.test_snapTensor = self._test_frames
         else:
-            if file_type != ".npz":
-                raise NotImplementedError("only the .npz snapshot container is supported")
-            data = np.load(self.snapshots_file, allow_pickle=True)
             inc = p.constProj_frame_increment
-            X = np.stack([data[str(i)] for i in range(0, self.frs * inc, inc)]).astype(np.float64)
             jump = getattr(p, "constProj_train_test_jump", None)
+            if file_type == ".npz":
+                data = np.load(self.snapshots_file, allow_pickle=True)
+                frame = lambda i: data[str(i)]
+            elif file_type == ".bin":
+                # the PD recorder's per-frame files (:126-160): <pattern><i>.bin = <i rows><i cols> + rows x cols doubles,
+                # column by column
+                def frame(i):
+                    raw = np.fromfile(self.snapshots_file + str(i) + ".bin", dtype=np.uint8)
+                    ni, mi = (int(q) for q in np.frombuffer(raw[:8].tobytes(), dtype="<i4"))
+                    return np.frombuffer(raw[8:8 + 8 * ni * mi].tobytes(), dtype="<f8").reshape(mi, ni).T
+            else:
+                raise ValueError("unknown snapshot file type: " + str(file_type))
+            X = np.stack([frame(i) for i in range(0, self.frs * inc, inc)]).astype(np.float64)
             if jump:
-                self.test_snapTensor = np.stack([data[str(j)] for j in range(jump, self.frs * inc, inc)])
+                self.test_snapTensor = np.stack([frame(j) for j in range(jump, self.frs * inc, inc)])
         self.frs = X.shape[0]
         self.num_constained_elements = X.shape[1] // self.constraintsSize
         print("loaded snapshots size", X.shape)
@@ -163,17 +215,30 @@ class nonlinearSnapshots:
         return X
 
     def load_factorize_masses(self):
-        """nonlinear_snapshots.py:178-265 builds per-row masses from vertex masses and the element type with
-        libigl (absent here); this build takes the per-row mass vector directly (``mass=`` / a .npy file).
-        massL = sqrt(mass), invMassL = 1 / massL (:259-262 for a diagonal matrix)."""
+        """nonlinear_snapshots.py:178-265.  The mass FILE branch (:180-191: the simulator's auxiliary masses, ``<i n><i m>`` +
+        n doubles, one per constraint row) and the factorisation (:244-262: massL = sqrt(mass), invMassL = 1 / massL with 0
+        where the mass is 0) are built; a per-row vector can also be handed over directly (``mass=``; ``.npy``).  Deriving
+        the masses from the MESH (:192-240) needs libigl's Voronoi / tet mass matrices, absent from this image: that branch
+        raises (parity unpinned)."""
         m = self._preset_mass
         if m is None:
             if not self.mass_file or not os.path.exists(self.mass_file):
-                raise NotImplementedError("element masses from the mesh need libigl (out of scope); pass mass=")
-            m = np.load(self.mass_file)
-        self.mass = np.asarray(m, dtype=np.float64)
-        self.massL = np.sqrt(self.mass)
-        self.invMassL = 1.0 / self.massL
+                raise NotImplementedError("element masses from the mesh need libigl (absent here); give constProj_masses_file "
+                                          "(the recorder's .bin or a .npy) or pass mass=")
+            if self.mass_file.lower().endswith(".npy"):
+                m = np.load(self.mass_file)
+            else:
+                with open(self.mass_file, "rb") as fh:
+                    ni, _mi = np.frombuffer(fh.read(8), dtype="<i4")
+                    m = np.frombuffer(fh.read(8 * int(ni)), dtype="<f8")
+                    if m.shape[0] != int(ni):
+                        raise IOError(self.mass_file + " could not be read")
+        self.mass = np.array(m, dtype=np.float64)
+        massL = np.sqrt(self.mass)
+        invMassL = np.zeros_like(massL)
+        np.divide(1.0, massL, out=invMassL, where=massL != 0)
+        assert np.allclose(invMassL * massL, np.ones_like(massL))             # (:258, as the reference: a zero mass fails here)
+        self.massL, self.invMassL = massL, invMassL
 
     def standarize(self, _fused=None):
         """nonlinear_snapshots.py:268-288 (``_fused``: sum(x), sum(x^2) when the upload sweep already removed the rest
@@ -239,8 +304,9 @@ class constraintsComponents:  # Components == bases
 
     def config(self, fileNameBases="p_nl_", fileName_geom_points="p_nl_interpol_points_",
                file_name_sing="_constrprojBases_pcaExtraction_singValues"):
-        """constraintsComponents.py:61-74 (the weighted S^T operator is only read when configured: it feeds
-        the out-of-scope 'with_St' variants)."""
+        """constraintsComponents.py:61-74; the weighted S^T operator (``constProj_weightedSt``, an .npz holding a scipy
+        sparse matrix under ``costProj_St_key``) is read when configured -- 'pca_blocks_with_St' and the position-space
+        interpolation error use it (``self.St`` may also be assigned directly)."""
         p = self.param
         self.basesType = getattr(p, "constProj_bases_interpolation_type", "")
         self.support = getattr(p, "constProj_support", "global")
@@ -248,22 +314,48 @@ class constraintsComponents:  # Components == bases
         self.fileNameBases = fileNameBases
         self.fileName_geom_points = fileName_geom_points
         self.file_name_sing = file_name_sing
+        st_file = getattr(p, "constProj_weightedSt", None)
+        if st_file:
+            self.St = read_sparse_matrix(st_file, ".npz", key=getattr(p, "costProj_St_key", None))
+
+    def _elements_around(self, v):
+        """The elements the reference lists around position-space vertex v (constraintsComponents.py:182-194, 682-697)."""
+        ns = self.nonlinearSnapshots
+        kind = getattr(ns, "ele_type", "")
+        if kind == "_tets":
+            return elements_of_vertex(v, ns.tets)
+        if kind == "_tris":
+            return elements_of_vertex(v, ns.tris)
+        if kind == "_edges":
+            return elements_of_vertex(v, ns.edges)
+        if kind == "_verts":
+            return vertex_star([v], ns.tris)
+        raise ValueError("ERROR! unknown constraints projection type: %r" % (kind,))
+
+    def _st_on_device(self):
+        ns = self.nonlinearSnapshots
+        if self.St is None:
+            raise ValueError("the differential operator S^T is not set (constProj_weightedSt / costProj_St_key, or .St = ...)")
+        if ns._comm.multi:
+            raise NotImplementedError("the S^T variants run on one rank (every constraint row is needed for S^T R)")
+        if self.St.shape[1] != ns.frames_rows:
+            raise ValueError("S^T has %d columns, the snapshots %d constraint rows" % (self.St.shape[1], ns.frames_rows))
+        if getattr(self, "_st_uploaded", None) is not self.St:
+            ns._engine.st_upload(self.St)
+            self._st_uploaded = self.St
 
     @log_time(constProj_output_directory)
     def compute_components_store_singvalues(self):
         """constraintsComponents.py:108-153."""
         p = self.param
         kind = p.constProj_basis_type
-        if kind not in ("pod_vectorized", "pca_blocks", "pod"):
-            if kind == "pca_blocks_with_St":
-                raise NotImplementedError("constProj_basis_type %r needs the libigl-built differential operator S^T and the "
-                                          "reference's element adjacency (out of scope, SURVEY.md section 2 #3); 'pod', "
-                                          "'pod_vectorized' and 'pca_blocks' run on the GPU" % kind)
+        if kind not in ("pod_vectorized", "pca_blocks", "pca_blocks_with_St", "pod"):
             raise ValueError("Uknown basis type: ", kind)
-        if kind == "pca_blocks":
+        if kind in ("pca_blocks", "pca_blocks_with_St"):
             headerSing = ['component', 'idx', 'residual_matrix_norm'] + \
                          ['singVal' + str(i) for i in range(self.nonlinearSnapshots.constraintsSize)]
-            run = self.compute_nonlinearity_bases_blocks
+            run = self.compute_nonlinearity_bases_blocks if kind == "pca_blocks" else \
+                self.compute_nonlinearity_bases_blocks_utilizing_diffirential_operator
         elif kind == "pod":
             headerSing = ['component', 'singVal']
             run = self.compute_pod_for_nonlinear_snapshots_tensor
@@ -279,6 +371,70 @@ class constraintsComponents:  # Components == bases
                 run(writer)
         else:
             run(None)
+
+    @log_time(constProj_output_directory)
+    def compute_nonlinearity_bases_blocks_utilizing_diffirential_operator(self, writer=None):
+        """constraintsComponents.py:156-271 ('pca_blocks_with_St'), as the reference WRITES it: while |R| > bases_R_tol, the
+        position-space vertex v with the largest row of S^T R is found (one SpMM + row reduction on the device), the
+        elements around it are listed -- and then the loop ``for idx in range(len(elems))`` deflates the constraint blocks
+        0 .. len(elems) - 1 (the loop INDEX, not the listed elements, is what the reference uses as block number, :201-207),
+        p rows each, rank-1 SVD of the row's 3 x F slab, global support; CSV row and measures per block, early exit once
+        |R| < tol.  The residual lives on the device (residual mode, forced rows); one rank."""
+        if self.support == 'local':
+            raise ValueError("Local support maps are not yet available for nonlinear-term components")
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        self._st_on_device()
+        p = int(ns.constraintsSize)
+        tol = float(self.param.bases_R_tol)
+        # every deflation removes one direction of frame space from the whole residual: F of them empty it in exact
+        # arithmetic; what a tolerance above rounding level needs is bounded by that plus one sweep over the blocks
+        cap = int(ns.frs) + p * int(ns.num_constained_elements) + p
+        eng.deflate_begin(cap, False, _lib.DEFLATE_RESIDUAL)
+        S_v_idx, S_ele_idns, meas = [], [], []
+        n_done = bases_count = 0
+        normR = np.sqrt(max(eng.residual_norm2(), 0.0))
+        while normR > tol:
+            v, _ = eng.st_residual_argmax()
+            elems = self._elements_around(v)
+            print("vert", v, "elements", len(elems))
+            S_v_idx.append(v)
+            if not elems:
+                raise ArithmeticError("vertex %d has no element: the reference's loop would spin forever here" % v)
+            for idx in range(len(elems)):
+                if n_done + p > cap:
+                    raise ArithmeticError("the residual does not fall below bases_R_tol = %g within %d components" % (tol, cap))
+                S_ele_idns.append(idx)
+                sigma = []
+                for i in range(p):
+                    eng.force_next(idx * p + i)
+                    eng.pick(n_done)
+                    eng.apply(n_done)
+                    sigma.append(eng.get_pick(n_done)[1])
+                    n_done += 1
+                    print(np.sqrt(max(eng.residual_norm2(), 0.0)))
+                bases_count += 1
+                normR = np.sqrt(max(eng.residual_norm2(), 0.0))
+                singList = [bases_count, idx, normR] + sigma
+                meas.append(singList)
+                if self.storeSingVal and writer is not None:
+                    writer.writerow(singList)
+                if normR < tol:
+                    break
+        for what, lst in (("verts", S_v_idx), ("elements", S_ele_idns)):
+            if len(lst) == len(set(lst)):
+                print("PCA Large deformation %s are unique%s" % (what, ":" if what == "elements" else ""), len(lst))
+            else:
+                print("PCA Large deformation %s are not unique:" % what, len(set(lst)), "points out of", len(lst))
+        eng.components_truncate(n_done)
+        res = eng.results(want_comps=False, want_weigs=True)
+        self.weigs = res["weigs"]
+        self.largeDeforPoints = np.asarray(S_v_idx, dtype=np.int64)
+        self.largeDeforBlocks = np.asarray(S_ele_idns, dtype=np.int64)
+        self.measures_at_largeDeforVerts = np.array(meas)
+        self._comps, self._comps_on_device = None, True
+        self.numComp = n_done // p
+        print("bases shape", (n_done, ns.frames_rows, 3), "number of components", self.numComp)
 
     @log_time(constProj_output_directory)
     def compute_nonlinearity_bases_blocks(self, writer=None):
@@ -627,15 +783,78 @@ class constraintsComponents:  # Components == bases
 
     @log_time(constProj_output_directory)
     def geom_block_form_utilizing_differential_operator(self, error_in_pos_space=False):
-        """constraintsComponents.py:619-731 with the error measured in the constraint-projection space.  The position-space
-        variant multiplies the residual by the libigl-built operator S^T and walks mesh adjacency (utils/support.py:210-370):
-        out of scope of this build (SURVEY.md section 2 #3/#4)."""
-        if error_in_pos_space:
-            raise NotImplementedError("error_in_pos_space=True needs the differential operator S^T and the element adjacency "
-                                      "helpers of the reference (libigl; out of scope)")
-        if self._block_interpolation(int(self.nonlinearSnapshots.constraintsSize), True):
-            print("Computing interpolation elements utilizing differential operator, used", self.geom_alpha.shape[0],
-                  "constrained elements")
+        """constraintsComponents.py:619-731.  Constraint space (default): the block with the largest residual, no block
+        twice.  ``error_in_pos_space=True``: the residual of the block is mapped to position space by S^T (device SpMM), the
+        vertex with the largest row is the interpolation vertex, and of the elements around it those not taken yet -- at
+        most ``geom_ele_per_vert`` per step -- join the interpolation set with all p rows (``verts_bending``: the listed
+        vertices are first intersected with the constrained ones and enter by their position in that list, :692-696)."""
+        if not error_in_pos_space:
+            if self._block_interpolation(int(self.nonlinearSnapshots.constraintsSize), True):
+                print("Computing interpolation elements utilizing differential operator, used", self.geom_alpha.shape[0],
+                      "constrained elements")
+            return
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        if getattr(ns, "ele_type", "") not in ["_tets", "_tris", "_edges", "_verts"]:
+            print("ERROR! Unknown constained elements nonliner snapshots type!")
+            return
+        self._st_on_device()
+        bending = getattr(self.param, "constProj_snapshots_type", "") == "verts_bending"
+        if bending:
+            self.constrianed_verts = np.load(self.param.constProj_input_snaps_constrained_elements)["indices"]
+        p = int(ns.constraintsSize)
+        K = self.numComp
+        Kp = K * p
+        v0, n_loc = ns._shards[comm.rank]
+        if not self._comps_on_device:
+            eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))
+            self._comps_on_device = True
+        if eng.K != Kp:
+            raise ValueError("the basis has %d vectors, %d blocks of %d expected" % (eng.K, K, p))
+        self._rank_diagnostic(Kp)
+        per_vert = int(self.param.geom_ele_per_vert)
+        rows = np.zeros((0, Kp, 3))          # rows[m, j, i] = V[Pt[m], j, i]
+        Pt, e_points, e_jump, e_range = [], [], [], []
+        self.geom_interpol_verts = []
+        for k in range(K):
+            coef = None
+            if k > 0:
+                kp = k * p
+                coef = np.empty((3, kp, p))
+                for i in range(3):          # (:662-668: more rows than columns possible -- least squares, as the reference)
+                    coef[i] = np.linalg.lstsq(rows[:, :kp, i], rows[:, kp:kp + p, i], rcond=None)[0]
+            v_interpolate, val, _ = eng.deim_block_step_st(k, p, coef)
+            if k > 0 and np.sqrt(max(val, 0.0)) <= 1e-8:     # np.allclose(S^T r, 0) (:677): no row of S^T r above 1e-8
+                print("ERROR!: zero residual!!")
+                return
+            self.geom_interpol_verts.append(v_interpolate)
+            alpha_list = self._elements_around(v_interpolate) if ns.ele_type != "_edges" else elements_of_vertex(v_interpolate, ns.edges)
+            mapped = None
+            if bending and ns.ele_type == "_verts":
+                alpha_list, mapped, _ = np.intersect1d(self.constrianed_verts, alpha_list, return_indices=True)
+            jump = 0
+            new_rows = []
+            for al in range(len(alpha_list)):
+                alpha = int(alpha_list[al])
+                if alpha not in e_points and jump < per_vert:
+                    jump += 1
+                    e_points.append(alpha)
+                    if bending:
+                        new_rows.append(int(mapped[al]))      # (p == 1 in this case)
+                    else:
+                        print(k, alpha)
+                        new_rows.extend(alpha * p + m for m in range(p))
+            if new_rows:
+                rows = np.concatenate([rows, np.stack([eng.deim_row(r_) for r_ in new_rows])], axis=0)
+                Pt.extend(new_rows)
+            e_jump.append(jump)
+            e_range.append(int(np.sum(e_jump)))
+        self.geom_Pt = np.array(Pt)
+        self.geom_alpha = np.array(e_points)
+        self.geom_alpha_ranges = np.array(e_range)
+        self.geom_interpol_verts = np.array(self.geom_interpol_verts)
+        print("Computing interpolation elements utilizing differential operator, used", self.geom_alpha.shape[0],
+              "constrained elements")
 
     def geom_constructed(self, r, case, interpol="geom"):
         """constraintsComponents.py:489-521: reconstruction of the train / test frames from the r leading basis blocks and

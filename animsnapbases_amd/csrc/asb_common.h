@@ -87,6 +87,13 @@ struct asb_ctx {
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_event = nullptr;
     long long dl_done = 0;
+    // the sparse differential operator S^T of the constraint path (asb_st_upload: CSR on the device) and its work arrays
+    long long* st_indptr = nullptr;
+    long long* st_indices = nullptr;
+    double* st_data = nullptr;
+    long long st_rows = 0, st_cols = 0, st_nnz = 0;
+    double* st_energy = nullptr;      // (st_rows) squared row norms of S^T M
+    double* st_resid = nullptr;       // (n_loc, 3 p) residual block of the position-space interpolation error
     unsigned* coop_bar = nullptr;     // k_panel_multi: flags [-, abort, too many candidates, -] + debug timestamps
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
     int panel_coop = 1;               // ASB_PANEL_COOP=0 -> the two-kernel inner loop

@@ -104,31 +104,6 @@ extern "C" int asb_deflate_force_next(asb_ctx* ctx, int64_t gidx) {
     return ASB_OK;
 }
 
-// block energies: sum of the current residual energies of p consecutive rows; first maximum of this shard
-// (:86-92, indxLargestDeformation).  The shard must hold whole blocks.
-__global__ __launch_bounds__(256) void k_block_argmax(const double* __restrict__ energy, long long nblocks, int p, long long b0,
-                                                      double* __restrict__ pmax, long long* __restrict__ pidx) {
-    __shared__ double sh_d[256];
-    __shared__ long long sh_i[256];
-    double be = -1.0;
-    long long bi = 0x7fffffffffffffffLL;
-    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (long long)gridDim.x * 256) {
-        double s = 0.0;
-        for (int i = 0; i < p; ++i) s += energy[b * p + i];
-        if (am_better(s, b0 + b, be, bi)) { be = s; bi = b0 + b; }
-    }
-    sh_d[threadIdx.x] = be; sh_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o && am_better(sh_d[threadIdx.x + o], sh_i[threadIdx.x + o], sh_d[threadIdx.x], sh_i[threadIdx.x])) {
-            sh_d[threadIdx.x] = sh_d[threadIdx.x + o];
-            sh_i[threadIdx.x] = sh_i[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { pmax[blockIdx.x] = sh_d[0]; pidx[blockIdx.x] = sh_i[0]; }
-}
-
 static int energy_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out);
 extern "C" int asb_deflate_block_argmax(asb_ctx* ctx, int p, int64_t* block_out, double* val_out) {
     if (!ctx || !ctx->R || !ctx->energy || !block_out || p < 1) return ASB_ERR_ARG;

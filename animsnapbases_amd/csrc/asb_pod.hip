@@ -631,3 +631,185 @@ extern "C" int asb_deim_row(asb_ctx* ctx, int64_t gidx, double* row_out) {
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASB_OK;
 }
+
+// --------------------------------------------------------------------------------------
+// The weighted differential operator S^T (sparse, position-space vertices x constraint rows) of the constraint path:
+// 'pca_blocks_with_St' picks the position-space vertex where S^T R is largest (constraintsComponents.py:180), the
+// position-space variant of the geometric interpolation measures the residual of a basis block through S^T (:652, :672).
+// Both are "squared row norms of S^T M" for a dense row-major M on the device: one wave per row of S^T, the lanes over
+// M's columns, a chunk of 64 x U columns at a time (the CSR row is re-read per chunk: it is short and cached).
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_st_row_energy(const long long* __restrict__ indptr, const long long* __restrict__ indices,
+                                                       const double* __restrict__ data, long long n_rows, const double* __restrict__ M,
+                                                       long long ldm, long long ncols, double* __restrict__ E) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < n_rows; v += (long long)gridDim.x * 4) {
+        const long long a = indptr[v], b = indptr[v + 1];
+        double e = 0.0;
+        for (long long c0 = 0; c0 < ncols; c0 += 64 * U) {
+            double acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = 0.0;
+            for (long long q = a; q < b; ++q) {
+                const double w = data[q];
+                const double* row = M + indices[q] * ldm;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long long c = c0 + lane + 64 * u;
+                    if (c < ncols) acc[u] += w * row[c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) e += acc[u] * acc[u];
+        }
+        e = wave_sum(e);
+        if (lane == 0) E[v] = e;
+    }
+}
+
+extern "C" int asb_st_upload(asb_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int64_t* indices,
+                             const double* data) {
+    if (!ctx || n_rows < 1 || n_cols < 1 || nnz < 0 || !indptr || (nnz > 0 && (!indices || !data))) return ASB_ERR_ARG;
+    for (int64_t q = 0; q < nnz; ++q)
+        if (indices[q] < 0 || indices[q] >= n_cols) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_st_upload: column index out of range");
+    if (indptr[0] != 0 || indptr[n_rows] != nnz) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_st_upload: bad row pointers");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->st_indptr, (size_t)n_rows + 1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->st_indices, (size_t)(nnz > 0 ? nnz : 1)))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->st_data, (size_t)(nnz > 0 ? nnz : 1)))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->st_energy, (size_t)n_rows))) return rc;
+    static_assert(sizeof(long long) == sizeof(int64_t), "index width");
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->st_indptr, indptr, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0) {
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->st_indices, indices, (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->st_data, data, (size_t)nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->st_rows = n_rows;
+    ctx->st_cols = n_cols;
+    ctx->st_nnz = nnz;
+    return ASB_OK;
+}
+
+// first arg-max of E[0 .. n) (k_block_argmax with blocks of one row), read back
+static int st_argmax(asb_ctx* ctx, const double* E, long long n, int64_t* idx_out, double* val_out) {
+    const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_val, (size_t)256))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_idx, (size_t)256))) return rc;
+    hipLaunchKernelGGL(k_block_argmax, dim3(grid), dim3(256), 0, ctx->stream, E, n, 1, (long long)0, ctx->bam_val, ctx->bam_idx);
+    ASB_CHECK_LAUNCH(ctx);
+    double hv[256];
+    long long hi[256];
+    ASB_HIP(ctx, hipMemcpyAsync(hv, ctx->bam_val, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(hi, ctx->bam_idx, grid * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double be = -1.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int b = 0; b < grid; ++b)
+        if (hv[b] > be || (hv[b] == be && hi[b] < bi)) { be = hv[b]; bi = hi[b]; }
+    *idx_out = bi;
+    if (val_out) *val_out = be;
+    return ASB_OK;
+}
+static int st_row_energies(asb_ctx* ctx, const double* M, long long ldm, long long ncols) {
+    const long long want = (ctx->st_rows + 3) / 4;
+    const int grid = (int)(want < 8LL * ctx->n_cu ? want : 8LL * ctx->n_cu);
+    hipLaunchKernelGGL(k_st_row_energy, dim3(grid), dim3(256), 0, ctx->stream, ctx->st_indptr, ctx->st_indices, ctx->st_data,
+                       (long long)ctx->st_rows, M, ldm, ncols, ctx->st_energy);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+extern "C" int asb_st_residual_argmax(asb_ctx* ctx, int64_t* v_out, double* val_out) {
+    if (!ctx || !ctx->R || !v_out) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_st_residual_argmax needs the residual mode");
+    if (!ctx->st_indptr || ctx->st_cols != ctx->n_loc || ctx->n_loc != ctx->N_glob)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_st_residual_argmax: S^T (%lld columns) does not match the %lld constraint rows of this (single) shard",
+                 (long long)ctx->st_cols, (long long)ctx->n_loc);
+    // the residual of constraint row j is 3 Fp contiguous doubles (x, y, z sub-rows; the padding is zero)
+    int rc = st_row_energies(ctx, ctx->R, 3 * ctx->Fp, 3 * ctx->Fp);
+    if (rc) return rc;
+    return st_argmax(ctx, ctx->st_energy, ctx->st_rows, v_out, val_out);
+}
+
+// |R|^2 = sum of the per-row energies the last pass left (asb_deflate_begin / asb_deflate_apply)
+__global__ __launch_bounds__(1024) void k_sum_all(const double* __restrict__ x, long long n, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    double v[1] = {s};
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) *out = v[0];
+}
+extern "C" int asb_deflate_residual_norm2(asb_ctx* ctx, double* out) {
+    if (!ctx || !ctx->R || !ctx->energy || !out) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_residual_norm2 needs the residual mode");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->bam_val, (size_t)256))) return rc;
+    hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(1024), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc, ctx->bam_val);
+    ASB_CHECK_LAUNCH(ctx);
+    ASB_HIP(ctx, hipMemcpyAsync(out, ctx->bam_val, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASB_OK;
+}
+
+// residual of basis block k (k_deim_block_residual's arithmetic) written out: resid[e][m][i], e < n_rows, m < p, i < 3
+__global__ __launch_bounds__(256) void k_deim_block_residual_out(const double* __restrict__ comps, long long n_rows, int kp, int p,
+                                                                 const double* __restrict__ coef, double* __restrict__ resid,
+                                                                 double* __restrict__ pabs) {
+    __shared__ double sh_a[4];
+    const long long stride = 3 * n_rows;
+    double amax = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_rows; e += (long long)gridDim.x * 256) {
+        for (int m = 0; m < p; ++m) {
+            double r[3] = {0.0, 0.0, 0.0};
+            for (int j = 0; j < kp; ++j) {
+                const double* q = comps + (long long)j * stride + 3 * e;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r[i] += coef[((size_t)i * kp + j) * p + m] * q[i];
+            }
+            const double* q = comps + (long long)(kp + m) * stride + 3 * e;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                r[i] -= q[i];
+                resid[(e * p + m) * 3 + i] = r[i];
+                amax = fmax(amax, fabs(r[i]));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) sh_a[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) pabs[blockIdx.x] = fmax(fmax(sh_a[0], sh_a[1]), fmax(sh_a[2], sh_a[3]));
+}
+
+extern "C" int asb_deim_block_residual_st(asb_ctx* ctx, int64_t k, int p, const double* coef, double* maxabs_out, int64_t* v_out,
+                                          double* val_out) {
+    if (!ctx || !ctx->comps || k < 0 || p < 1 || (k + 1) * p > ctx->K || !maxabs_out || !v_out) return ASB_ERR_ARG;
+    if (k > 0 && !coef) return ASB_ERR_ARG;
+    // rows of the basis are constraint ROWS (e p of them); the reference reshapes the (e p, p, 3) block to (e p, 3 p) and S^T has
+    // e p columns (:652 `self.St @ vk.reshape(vk.shape[0], -1)`)
+    if (!ctx->st_indptr || ctx->st_cols != ctx->n_loc || ctx->n_loc != ctx->N_glob)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deim_block_residual_st: S^T (%lld columns) does not match the %lld rows of this (single) shard",
+                 (long long)ctx->st_cols, (long long)ctx->n_loc);
+    const int kp = (int)(k * p);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_coef, (size_t)3 * ctx->K * p + 8))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->st_resid, (size_t)ctx->n_loc * 3 * p))) return rc;
+    if (k > 0) ASB_HIP(ctx, hipMemcpyAsync(ctx->pod_coef, coef, (size_t)3 * kp * p * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    long long want = (ctx->n_loc + 255) / 256;
+    const int grid = (int)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(k_deim_block_residual_out, dim3(grid), dim3(256), 0, ctx->stream, ctx->comps, (long long)ctx->n_loc, kp, p,
+                       ctx->pod_coef, ctx->st_resid, ctx->pmax);
+    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = st_row_energies(ctx, ctx->st_resid, 3 * p, 3 * p))) return rc;
+    std::vector<double> h(grid);
+    ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->pmax, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = st_argmax(ctx, ctx->st_energy, ctx->st_rows, v_out, val_out))) return rc;      // (synchronises)
+    double am = 0.0;
+    for (int b = 0; b < grid; ++b) am = h[b] > am ? h[b] : am;
+    *maxabs_out = am;
+    return ASB_OK;
+}

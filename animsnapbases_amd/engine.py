@@ -568,6 +568,36 @@ class HipEngine(object):
         self._ck(self.lib.asb_energy_block_argmax(self.h, int(group), ctypes.byref(idx), ctypes.byref(val)))
         return idx.value, val.value, am.value
 
+    def st_upload(self, St):
+        """The sparse differential operator S^T (scipy sparse, |V| x e p) as CSR on the device."""
+        St = St.tocsr()
+        St.sort_indices()
+        indptr = np.ascontiguousarray(St.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(St.indices, dtype=np.int64)
+        data = np.ascontiguousarray(St.data, dtype=np.float64)
+        self._ck(self.lib.asb_st_upload(self.h, int(St.shape[0]), int(St.shape[1]), int(data.shape[0]), ptr(indptr),
+                                        ptr(indices), ptr(data)))
+
+    def st_residual_argmax(self):
+        v, val = ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_st_residual_argmax(self.h, ctypes.byref(v), ctypes.byref(val)))
+        return v.value, val.value
+
+    def residual_norm2(self):
+        out = ctypes.c_double()
+        self._ck(self.lib.asb_deflate_residual_norm2(self.h, ctypes.byref(out)))
+        return out.value
+
+    def deim_block_step_st(self, k, p, coef):
+        """Residual of basis block k mapped to position space by S^T: (vertex arg-max, its energy, largest |r|)."""
+        if coef is not None:
+            coef = np.ascontiguousarray(coef, dtype=np.float64)
+            assert coef.shape == (3, k * p, p)
+        am, v, val = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.asb_deim_block_residual_st(self.h, int(k), int(p), ptr(coef), ctypes.byref(am), ctypes.byref(v),
+                                                     ctypes.byref(val)))
+        return v.value, val.value, am.value
+
     def deim_row(self, gidx):
         row = np.empty((self.K, 3))
         rc = self.lib.asb_deim_row(self.h, int(gidx), ptr(row))

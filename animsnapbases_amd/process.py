@@ -13,76 +13,101 @@ same keys go to ``.npz`` (``posSnapshots`` reads both).
 import os
 import re
 from glob import glob
-from io import StringIO
 
 import numpy as np
-from scipy.sparse import csr_matrix
-from scipy.sparse.csgraph import connected_components
+
+
+_NUM_RUN = re.compile(r"(\d+)")
 
 
 def load_off(filename, no_colors=False):
-    """process.py:46-67."""
-    lines = open(filename).readlines()
-    lines = [line for line in lines if line.strip() != '' and line[0] != '#']
-    assert lines[0].strip() in ['OFF', 'COFF'], 'OFF header missing'
-    has_colors = lines[0].strip() == 'COFF'
-    n_verts, n_faces, _ = map(int, lines[1].split())
-    vertex_data = np.loadtxt(StringIO(''.join(lines[2:2 + n_verts])), dtype=float)
-    faces = np.loadtxt(StringIO(''.join(lines[2 + n_verts:])), dtype=int)[:, 1:] if n_faces > 0 else None
-    colors = None
-    if has_colors:
-        colors = vertex_data[:, 3:].astype(np.uint8)
-        vertex_data = vertex_data[:, :3]
-    return (vertex_data, faces) if no_colors else (vertex_data, colors, faces)
+    """Reads an ``OFF`` / ``COFF`` mesh (what process.py:46-67 returns: vertex array, [uint8 colours,] (M, 3) face array or
+    None).  Parsed as ONE token stream -- comment lines and blank lines dropped, header, the three counts, then
+    ``n_verts`` rows of equal width and ``n_faces`` rows ``k i0 .. i(k-1)`` -- instead of line slices fed to loadtxt."""
+    with open(filename) as fh:
+        rows = [ln.split() for ln in fh if ln.strip() and not ln.lstrip().startswith("#")]
+    kind = rows[0][0] if rows and len(rows[0]) == 1 else None
+    if kind not in ("OFF", "COFF"):
+        raise AssertionError("OFF header missing")
+    n_verts, n_faces = int(rows[1][0]), int(rows[1][1])
+    body = rows[2:]
+    table = np.array(body[:n_verts], dtype=np.float64).reshape(n_verts, -1)
+    faces = None
+    if n_faces > 0:
+        faces = np.array(body[n_verts:n_verts + n_faces], dtype=np.int64)[:, 1:]
+    if kind == "COFF":
+        xyz, rgba = table[:, :3], table[:, 3:].astype(np.uint8)
+    else:
+        xyz, rgba = table, None
+    return (xyz, faces) if no_colors else (xyz, rgba, faces)
 
 
 def alphanum_key(s):
-    """process.py:158-162: "z23a" -> ["z", 23, "a"]."""
-    return [int(c) if c.isdigit() else c for c in re.split('([0-9]+)', s)]
+    """Natural-sort key (process.py:158-162): digit runs compare as numbers, ``"z23a" -> ["z", 23, "a"]``."""
+    return [int(tok) if tok.isdigit() else tok for tok in _NUM_RUN.split(s)]
 
 
 def sort_nicely(l):
-    """process.py:170-173."""
+    """In-place natural sort of file names (process.py:170-173)."""
     l.sort(key=alphanum_key)
 
 
 def filter_reindex(condition, target):
-    """process.py:96-106."""
-    if condition.dtype != bool:
+    """New indices of ``target`` once only the elements with ``condition`` are kept (process.py:96-106)."""
+    condition = np.asarray(condition)
+    if condition.dtype != np.bool_:
         raise ValueError("condition must be a binary array")
-    return (np.cumsum(condition) - 1)[target]
+    new_index = np.cumsum(condition, dtype=np.int64)
+    new_index -= 1
+    return new_index[target]
+
+
+def _component_labels(n, edges):
+    """Connected components of an undirected graph given as an (E, 2) edge array: label = the SMALLEST vertex index of the
+    component (minimum-label propagation with pointer jumping, all NumPy; O(E log n)).  Ordering components by that
+    label is the order in which a traversal from vertex 0 upwards meets them -- the numbering scipy's csgraph gives."""
+    lab = np.arange(n, dtype=np.int64)
+    a, b = edges[:, 0], edges[:, 1]
+    while True:
+        low = np.minimum(lab[a], lab[b])
+        nxt = lab.copy()
+        np.minimum.at(nxt, a, low)
+        np.minimum.at(nxt, b, low)
+        while True:                      # pointer jumping: every vertex adopts its label's label
+            jump = nxt[nxt]
+            if np.array_equal(jump, nxt):
+                break
+            nxt = jump
+        if np.array_equal(nxt, lab):
+            return lab
+        lab = nxt
 
 
 def preprocess_mesh_animation(verts, tris):
-    """process.py:107-148: drop zero-area triangles (of frame 0), keep the biggest connected component,
-    normalise the animation into the -0.5 .. 0.5 cube.  Returns (verts, tris, removed_mask, mean, scale)."""
-    print("Vertices: ", verts.shape)
-    print("Triangles: ", tris.shape)
+    """Mesh clean-up of process.py:107-148: triangles that are degenerate in frame 0 go, only the largest connected
+    component stays (first one on a tie), the animation is centred and scaled into the unit cube (largest per-frame
+    extent = 1).  Returns (verts, tris, removed_vertex_mask, centre, scale); arithmetic stays in ``verts``' dtype."""
     assert verts.ndim == 3 and tris.ndim == 2
-    e1 = verts[0, tris[:, 1]] - verts[0, tris[:, 0]]
-    e2 = verts[0, tris[:, 2]] - verts[0, tris[:, 0]]
-    tris = tris[np.linalg.norm(np.cross(e1, e2), axis=1) > 1.e-8]
-    ij = np.r_[np.c_[tris[:, 0], tris[:, 1]], np.c_[tris[:, 0], tris[:, 2]], np.c_[tris[:, 1], tris[:, 2]]]
-    G = csr_matrix((np.ones(len(ij)), ij.T), shape=(verts.shape[1], verts.shape[1]))
-    n_components, labels = connected_components(G, directed=False)
-    if n_components > 1:
-        size_components = np.bincount(labels)
-        if len(size_components) > 1:
-            print("[warning] found %d connected components in the mesh, keeping only the biggest one" % n_components)
-            print("component sizes: ")
-            print(size_components)
-        keep_vert = labels == size_components.argmax()
-    else:
-        keep_vert = np.ones(verts.shape[1], bool)
+    print("input mesh animation: %d frames, %d vertices, %d triangles" % (verts.shape[0], verts.shape[1], tris.shape[0]))
+    n = verts.shape[1]
+    p = verts[0]
+    twice_area = np.linalg.norm(np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]]), axis=1)
+    tris = tris[twice_area > 1.e-8]
+    edges = np.concatenate([tris[:, (0, 1)], tris[:, (0, 2)], tris[:, (1, 2)]], axis=0)
+    lab = _component_labels(n, edges)
+    sizes = np.bincount(lab, minlength=n)
+    n_comp = int(np.count_nonzero(sizes))
+    if n_comp > 1:
+        print("[warning] the mesh has %d connected components (sizes %s): only the largest is kept"
+              % (n_comp, sizes[sizes > 0].tolist()))
+    keep_vert = lab == int(np.argmax(sizes))         # first maximum = the tied component met first
     verts = verts[:, keep_vert, :]
     tris = filter_reindex(keep_vert, tris[keep_vert[tris].all(axis=1)])
     verts_mean = verts.mean(axis=0).mean(axis=0)
-    verts -= verts_mean
-    verts_scale = np.abs(np.ptp(verts, axis=1)).max()
-    verts /= verts_scale
-    print("after preprocessing:")
-    print("Vertices: ", verts.shape)
-    print("Triangles: ", tris.shape)
+    verts = verts - verts_mean
+    verts_scale = np.abs(verts.max(axis=1) - verts.min(axis=1)).max()
+    verts = verts / verts_scale
+    print("kept: %d vertices, %d triangles" % (verts.shape[1], tris.shape[0]))
     return verts, tris, ~keep_vert, verts_mean, verts_scale
 
 
@@ -90,7 +115,7 @@ def _write_container(path, verts, tris, **attrs):
     if os.path.splitext(path)[1].lower() == ".npz":
         np.savez_compressed(path, verts=verts, tris=tris, **attrs)
         return
-    import h5py      # the reference's container (process.py:88-92)
+    import h5py      # the reference's container (process.py:88-92): gzip'd 'verts', plain 'tris', attributes
     with h5py.File(path, 'w') as f:
         f.create_dataset('verts', data=verts, compression='gzip')
         f['tris'] = tris
@@ -104,34 +129,37 @@ def _read_container(path):
 
 
 def convert_sequence_to_hdf5(filename_pattern, loader_function, hdf_output_file, max_frames, icreament):
-    """process.py:69-94 (output may also be ``.npz``)."""
-    verts_all, tris = [], None
+    """Frame files -> one animation container (process.py:69-94; same signature, ``.npz`` accepted as well): every
+    ``icreament``-th file of the naturally sorted match list, at most ``max_frames`` of them, one topology throughout,
+    float32 vertices, pre-processed, stored with the centre and scale that were removed."""
     files = glob(os.path.expanduser(filename_pattern))
     sort_nicely(files)
-    count = 0
-    for i, f in enumerate(files):
-        if i % icreament == 0 and count < max_frames:
-            print("loading file %d/%d [%s]" % (i + 1, len(files), f))
-            verts, new_tris = loader_function(f)
-            if tris is not None and new_tris.shape != tris.shape:
-                raise ValueError("inconsistent topology between meshes of different frames")
-            tris = new_tris
-            verts_all.append(verts)
-            count += 1
-    verts_all = np.array(verts_all, np.float32)
-    verts_all, tris, _, verts_mean, verts_scale = preprocess_mesh_animation(verts_all, tris)
-    _write_container(hdf_output_file, verts_all, tris, mean=verts_mean, scale=verts_scale)
-    print("saved as %s" % hdf_output_file)
+    chosen = files[::icreament][:max_frames]
+    frames, tris = [], None
+    for f in chosen:
+        print("reading %s" % f)
+        v, t = loader_function(f)
+        if tris is not None and t.shape != tris.shape:
+            raise ValueError("inconsistent topology between meshes of different frames")
+        frames.append(v)
+        tris = t
+    stack = np.asarray(frames, dtype=np.float32)
+    stack, tris, _, centre, scale = preprocess_mesh_animation(stack, tris)
+    _write_container(hdf_output_file, stack, tris, mean=centre, scale=scale)
+    print("wrote %s" % hdf_output_file)
 
 
 def transform(v, M, w=1):
-    """process.py:196-208."""
+    """Applies ``M`` to the points ``v`` (..., d) (process.py:196-208): a (d+1) x (d+1) matrix acts on the homogeneous
+    points (v, w) and the result is de-homogenised; a d x d matrix is a plain linear map."""
     v = np.asarray(v)
-    if M.shape[0] == M.shape[1] == v.shape[-1] + 1:
-        v1 = np.insert(v, v.shape[-1], w, axis=-1).reshape((-1, v.shape[-1] + 1))
-        out = np.dot(v1, M.T)
-        return (out[..., :-1] / out[..., np.newaxis, -1]).reshape(v.shape)
-    return np.dot(v.reshape((-1, v.shape[-1])), M.T).reshape(v.shape)
+    d = v.shape[-1]
+    pts = v.reshape(-1, d)
+    if M.shape == (d + 1, d + 1):
+        lin = pts @ M[:d, :d].T + w * M[:d, d]
+        hom = pts @ M[d, :d] + w * M[d, d]
+        return (lin / hom[:, None]).reshape(v.shape)
+    return (pts @ M.T).reshape(v.shape)
 
 
 def align_frames(verts, rigid, engine=None):
@@ -149,9 +177,8 @@ def find_rbm_procrustes(frompts, topts, rigid, engine=None):
 
 
 def align(input_hdf5_file, output_hdf5_file, rigid, engine=None):
-    """process.py:235-250."""
+    """Container in, aligned container out (process.py:235-250): every frame moved onto frame 0, all frames in one device call."""
     verts, tris = _read_container(input_hdf5_file)
-    for i in range(len(verts)):
-        print("frame %d/%d" % (i + 1, len(verts)))
+    print("aligning %d frames onto frame 0 (%s)" % (len(verts), "rigid" if rigid else "affine"))
     out, _ = align_frames(verts, rigid, engine)
     _write_container(output_hdf5_file, out, tris)

@@ -286,6 +286,19 @@ int asb_components_transform(asb_ctx* ctx, const double* T_host);
 int asb_components_expand(asb_ctx* ctx, const double* coef_host, int64_t r, int64_t F, double* out_host);
 /* the device-resident basis (K, n_loc, 3) to the host */
 int asb_components_download(asb_ctx* ctx, double* comps_out);
+/* ---- the weighted differential operator S^T of the constraint path (constraintsComponents.py:70-74: a scipy sparse matrix
+ * read from an .npz; rows = position-space vertices, columns = the e p constraint rows).  One rank holds all constraint rows. */
+int asb_st_upload(asb_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr_host,
+                  const int64_t* indices_host, const double* data_host);
+/* 'pca_blocks_with_St' (constraintsComponents.py:180): v = argmax_rows sum((S^T R_flat)^2) on the CURRENT residual of the
+ * residual-mode deflation (R_flat = (e p) x (3 F)); first maximum */
+int asb_st_residual_argmax(asb_ctx* ctx, int64_t* v_out, double* val_out);
+/* |R|_F^2 of the residual-mode deflation right now (the loop condition `while norm(R) > tol`, :179, :252) */
+int asb_deflate_residual_norm2(asb_ctx* ctx, double* out);
+/* geom_block_form_utilizing_differential_operator(error_in_pos_space=True) (:652-672): residual of basis block k as
+ * asb_deim_block_residual, mapped to position space by S^T ((|V|) x (3 p)); first arg-max of its squared row norms */
+int asb_deim_block_residual_st(asb_ctx* ctx, int64_t k, int p, const double* coef_host, double* maxabs_out, int64_t* v_out,
+                               double* val_out);
 /* The basis into PINNED host memory, overlapped with the run that produces it (posComponents.py:119 leaves `comps` in host
  * memory: `self.comps = array(C)`).  asb_components_stream(ctx, 1) before asb_deflate_begin: the context keeps a pinned
  * (K, n_loc, 3) buffer and a copy stream; every component row is copied as soon as it is final (projection mode: after each

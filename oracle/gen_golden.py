@@ -293,6 +293,68 @@ def _blocksdeim(work):
     print("wrote block_deim_p3", out["deim_block_form_alpha"].tolist(), out["geom_alpha"].tolist(), list(out["files"]))
 
 
+def _withst(work):
+    """The S^T variants: 'pca_blocks_with_St' (compute_nonlinearity_bases_blocks_utilizing_diffirential_operator,
+    constraintsComponents.py:156-271) and geom_block_form_utilizing_differential_operator(error_in_pos_space=True) (:619-731)
+    of the UNMODIFIED reference on a small triangle mesh: e = #triangles constraints of p = 2 rows ('_tris'), a synthetic
+    sparse weighted operator S^T (|V| x e p: every vertex sees the rows of the triangles around it), 16 frames."""
+    from scipy import sparse
+    ref = import_reference.cache
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    rng = np.random.default_rng(41)
+    rest, tris = orc.synth_mesh(5, 7, seed=41)
+    nv, e, p, F = rest.shape[0], tris.shape[0], 2, 16
+    ep = e * p
+    rows_, cols_, vals_ = [], [], []
+    for t, tri in enumerate(tris):
+        for v in tri:
+            for m in range(p):
+                rows_.append(int(v)); cols_.append(t * p + m); vals_.append(rng.uniform(0.2, 1.0) * (1 if rng.random() < 0.7 else -1))
+    St = sparse.csr_matrix((vals_, (rows_, cols_)), shape=(nv, ep))
+    modes = rng.normal(size=(F, ep, 3))
+    coef = rng.normal(size=(F, F)) * (0.75 ** np.arange(F))[None]
+    frames = 0.2 + np.tensordot(coef, modes, (1, 0))
+    out = dict(frames=frames, tris=tris, rest=rest, p=np.array(p), St_data=St.data, St_indices=St.indices, St_indptr=St.indptr,
+               St_shape=np.array(St.shape))
+
+    def make(kind, K=0, **over):
+        param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=False,
+                                      deim_desired_num_components=K, constProj_output_directory=work,
+                                      constProj_bases_interpolation_type=kind, constProj_snapshots_type="tris_strain",
+                                      bases_R_tol=1e-8, geom_ele_per_vert=2, **over)
+        ns = object.__new__(nonlinearSnapshots)
+        ns.param, ns.rest_shape, ns.dim, ns.frs, ns.constraintsSize = param, "first", 3, F, p
+        ns.num_constained_elements = e
+        ns.snapTensor = frames.astype(float).copy()
+        ns.mean, ns.pre_scale_factor, ns.massL, ns.invMassL = None, 1, None, None
+        ns.ele_type, ns.tris, ns.tets, ns.edges = "_tris", tris, None, None
+        ns.standarize()
+        cc = object.__new__(constraintsComponents)
+        cc.param, cc.nonlinearSnapshots, cc.numComp, cc.comps = param, ns, 0, None
+        cc.support, cc.storeSingVal, cc.geom_interpol_verts, cc.St = "global", False, [], St
+        return ns, cc
+
+    ns, cc = make("geom")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cc.compute_nonlinearity_bases_blocks_utilizing_diffirential_operator(None)
+    out.update(st_comps=cc.comps.copy(), st_weigs=cc.weigs.copy(), st_measures=cc.measures_at_largeDeforVerts.copy(),
+               st_numComp=np.array(cc.numComp),
+               st_verts=np.array([int(l.split()[1]) for l in buf.getvalue().splitlines() if l.startswith("vert ")]))
+    # position-space interpolation on a 'pca_blocks' basis (K = 6 blocks of p rows)
+    K = 6
+    ns, cc = make("geom", K)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_nonlinearity_bases_blocks(None)
+        cc.geom_block_form_utilizing_differential_operator(True)
+    out.update(pos_K=np.array(K), pos_comps=cc.comps.copy(), pos_Pt=np.asarray(cc.geom_Pt, dtype=np.int64),
+               pos_alpha=np.asarray(cc.geom_alpha, dtype=np.int64), pos_ranges=np.asarray(cc.geom_alpha_ranges, dtype=np.int64),
+               pos_interpol_verts=np.asarray(cc.geom_interpol_verts, dtype=np.int64))
+    np.savez_compressed(os.path.join(OUT, "with_st_p2.npz"), **out)
+    print("wrote with_st_p2: components", out["st_comps"].shape, "verts", out["st_verts"].tolist(), "| pos-space alpha",
+          out["pos_alpha"].tolist(), "ranges", out["pos_ranges"].tolist(), "verts", out["pos_interpol_verts"].tolist())
+
+
 def _podslices(work):
     """constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, :274-294; torch float32 SVD per (p, d) slice)."""
     ref = import_reference.cache
@@ -475,6 +537,8 @@ def main():
                 return _recon(work)
             if only is not None and "podslices" in only:
                 return _podslices(work)
+            if only is not None and "withst" in only:
+                return _withst(work)
             if only is not None and "blocks" in only:
                 return _blocks(work)
             if only is not None and "ingest" not in only:
@@ -496,6 +560,7 @@ def main():
             _blocksdeim(work)
             _recon(work)
             _podslices(work)
+            _withst(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

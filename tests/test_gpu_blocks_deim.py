@@ -3,7 +3,9 @@ reference (oracle/gen_golden.py `blocksdeim`, `recon`):
   deim_blocksForm (:733-795), geom_block_form_utilizing_differential_operator in the constraint space (:619-731),
   geom_constructed (:489-521, p = 1: with p > 1 the reference's normal matrix is singular by construction),
   store_components_gradually_to_files (:572-594, byte-identical files), and deim (:797-860) run entirely on the device."""
+import contextlib
 import hashlib
+import io
 import os
 import types
 
@@ -45,8 +47,6 @@ def test_block_interpolation_vs_reference_golden(kind, tmp_path, capsys):
         cc.deim_blocksForm()
     else:
         cc.geom_block_form_utilizing_differential_operator(False)
-        with pytest.raises(NotImplementedError):
-            cc.geom_block_form_utilizing_differential_operator(True)
     assert cc.geom_Pt.tolist() == g[kind + "_Pt"].tolist()
     assert cc.geom_alpha.tolist() == g[kind + "_alpha"].tolist()
     assert cc.geom_alpha_ranges.tolist() == g[kind + "_ranges"].tolist()
@@ -123,3 +123,85 @@ def test_pod_per_slice_vs_reference_golden(tmp_path):
                 s64 = np.sign(np.dot(got[k], U[k]))
                 assert relerr(got[k] * s32, ref32[k]) < 2e-4, (pi, d, k)
                 assert relerr(got[k] * s64, U[k]) < 1e-8, (pi, d, k)
+
+
+def _align(comps, ref):
+    out = comps.copy()
+    for k in range(out.shape[0]):
+        if np.vdot(out[k], ref[k]) < 0:
+            out[k] *= -1
+    return out
+
+
+def _st_setup(g, tmp_path, K=0):
+    from scipy import sparse
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    p = int(g["p"])
+    St = sparse.csr_matrix((g["St_data"], g["St_indices"], g["St_indptr"]), shape=tuple(g["St_shape"]))
+    param = types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=0, constProj_p_size=p,
+                                  constProj_massWeight=False, constProj_standarize=True, constProj_orthogonal=False,
+                                  constProj_basis_type="pca_blocks_with_St" if K == 0 else "pca_blocks",
+                                  deim_desired_num_components=K, constProj_store_sing_val=True, constProj_support="global",
+                                  constProj_output_directory=str(tmp_path), name="st", constProj_name="tris",
+                                  constProj_bases_interpolation_type="geom", constProj_snapshots_type="tris_strain",
+                                  constProj_element_type="_tris", bases_R_tol=1e-8, geom_ele_per_vert=2)
+    ns = nonlinearSnapshots(param, frames=g["frames"])
+    ns.config()
+    ns.tris = g["tris"]
+    ns.snapshots_prepare()
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.St = St
+    return ns, cc
+
+
+def test_pca_blocks_with_St_vs_reference(tmp_path):
+    """'pca_blocks_with_St' (constraintsComponents.py:156-271): the vertex sequence chosen through S^T R (device SpMM + row
+    reduction), the blocks the reference's loop index names, every component, weight and CSV row."""
+    g = load_golden("with_st_p2")
+    ns, cc = _st_setup(g, tmp_path)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cc.compute_components_store_singvalues()
+    verts = [int(l.split()[1]) for l in buf.getvalue().splitlines() if l.startswith("vert ")]
+    assert verts == g["st_verts"].tolist()
+    assert cc.numComp == int(g["st_numComp"]) and cc.comps.shape == g["st_comps"].shape
+    comps, weigs = cc.comps.copy(), cc.weigs.copy()
+    for k in range(comps.shape[0]):               # rank-1 SVD sign (LAPACK's is arbitrary): w c^T is what is defined
+        if np.vdot(weigs[:, k], g["st_weigs"][:, k]) < 0:
+            weigs[:, k] *= -1
+    # the last components are computed from a residual that has fallen by many orders of magnitude: compare the rank-1 terms
+    scale0 = np.linalg.norm(np.multiply.outer(g["st_weigs"][:, 0], g["st_comps"][0]))
+    checked = 0
+    for k in range(comps.shape[0]):
+        a = np.multiply.outer(cc.weigs[:, k], cc.comps[k])
+        b = np.multiply.outer(g["st_weigs"][:, k], g["st_comps"][k])
+        if np.linalg.norm(b) < 1e-9 * scale0:     # (rest shape "first" leaves 15 directions in 16 frames: the 16th term is rounding noise)
+            continue
+        assert relerr(a, b) < 1e-6, k
+        checked += 1
+    assert checked >= comps.shape[0] - 1
+    assert relerr(weigs[:, :8], g["st_weigs"][:, :8]) < 1e-9
+    m, mr = cc.measures_at_largeDeforVerts, g["st_measures"]
+    assert m.shape == mr.shape and np.array_equal(m[:, :2], mr[:, :2])
+    big = mr[:, 2] > 1e-6 * mr[0, 2]
+    assert relerr(m[big, 2:], mr[big, 2:]) < 1e-8
+    rows = open(str(tmp_path / "st_tris_constrprojBases_pcaExtraction_singValues.csv")).read().splitlines()
+    assert rows[0] == "component,idx,residual_matrix_norm,singVal0,singVal1" and len(rows) == 1 + m.shape[0]
+
+
+def test_position_space_interpolation_vs_reference(tmp_path):
+    """geom_block_form_utilizing_differential_operator(error_in_pos_space=True) (:619-731) on a 'pca_blocks' basis: the
+    interpolation vertices found through S^T r, the elements taken around them (at most geom_ele_per_vert new ones per
+    step), Pt and the ranges."""
+    g = load_golden("with_st_p2")
+    K = int(g["pos_K"])
+    ns, cc = _st_setup(g, tmp_path, K)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_components_store_singvalues()
+        assert relerr(_align(cc.comps, g["pos_comps"]), g["pos_comps"]) < 1e-8
+        cc.geom_block_form_utilizing_differential_operator(True)
+    assert cc.geom_interpol_verts.tolist() == g["pos_interpol_verts"].tolist()
+    assert cc.geom_alpha.tolist() == g["pos_alpha"].tolist()
+    assert cc.geom_Pt.tolist() == g["pos_Pt"].tolist()
+    assert cc.geom_alpha_ranges.tolist() == g["pos_ranges"].tolist()

@@ -94,3 +94,54 @@ def test_rank_diagnostic_from_gram_matrices(capsys):
     assert by_gram == by_rows
     assert by_gram[0] == ".. linear independent." and "rank: %d" % (K - 1) in by_gram[1]
     assert asked == [1]                               # only the doubtful dimension went to the host
+
+
+def test_constraint_path_host_helpers(tmp_path):
+    """Host pieces of SURVEY 8 f-4 / a15 that need no GPU: the element lists around a vertex (utils/support.py:210-258, as the
+    reference's Python loops give them), the sparse-operator readers (utils/utils.py:289-323), the mass FILE branch of
+    nonlinearSnapshots.load_factorize_masses (nonlinear_snapshots.py:180-191, 244-262) and the per-frame .bin reader (:126-143)."""
+    import struct
+    import types
+    from scipy import sparse
+    from animsnapbases_amd import constraints as C
+    rng = np.random.default_rng(3)
+    tris = rng.integers(0, 12, size=(30, 3))
+    for v in (0, 5, 11):
+        want = [i for i, t in enumerate(tris) if any(q in {v} for q in t)]                  # the reference's loop
+        assert C.elements_of_vertex(v, tris) == want
+        star = set()
+        for f in tris:
+            if [v] in f:
+                star.update(f)
+        assert sorted(C.vertex_star([v], tris)) == sorted(int(q) for q in star)
+    M = sparse.random(9, 14, density=0.3, random_state=4, format="csr")
+    np.savez(str(tmp_path / "st.npz"), St=np.array(M, dtype=object))
+    got = C.read_sparse_matrix(str(tmp_path / "st.npz"), ".npz", key="St")
+    assert (got != M).nnz == 0
+    coo = M.tocoo()
+    with open(str(tmp_path / "st.bin"), "wb") as fh:
+        fh.write(struct.pack("<iii", 9, 14, coo.nnz))
+        for r, c, v in zip(coo.row, coo.col, coo.data):
+            fh.write(struct.pack("<iid", int(r), int(c), float(v)))
+    assert (C.read_sparse_matrix(str(tmp_path / "st.bin"), ".bin") != M).nnz == 0
+    # masses
+    mass = rng.uniform(0.5, 2.0, size=20)
+    with open(str(tmp_path / "m.bin"), "wb") as fh:
+        fh.write(struct.pack("<ii", 20, 1))
+        fh.write(mass.astype("<f8").tobytes())
+    param = types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=3, constProj_p_size=2,
+                                  constProj_masses_file=str(tmp_path / "m.bin"), constProj_frame_increment=2,
+                                  constProj_train_test_jump=1, constProj_input_snapshots_pattern=str(tmp_path / "snap_"))
+    ns = C.nonlinearSnapshots(param)
+    ns.config()
+    ns.load_factorize_masses()
+    assert np.array_equal(ns.mass, mass) and np.allclose(ns.massL ** 2, mass) and np.allclose(ns.invMassL * ns.massL, 1.0)
+    # per-frame .bin files: <i rows><i cols>, column by column
+    frames = rng.normal(size=(6, 20, 3))
+    for i in range(6):
+        with open(str(tmp_path / ("snap_%d.bin" % i)), "wb") as fh:
+            fh.write(struct.pack("<ii", 20, 3))
+            fh.write(frames[i].T.astype("<f8").tobytes())
+    X = ns.read(".bin")
+    assert np.array_equal(X, frames[0:6:2]) and np.array_equal(ns.test_snapTensor, frames[1:6:2])
+    assert ns.num_constained_elements == 10
