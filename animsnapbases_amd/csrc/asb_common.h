@@ -87,6 +87,7 @@ struct asb_ctx {
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_event = nullptr;
     long long dl_done = 0;
+    double* td_wy = nullptr;          // blocked back-transformation: T factors, reflector panels, work
     // the sparse differential operator S^T of the constraint path (asb_st_upload: CSR on the device) and its work arrays
     long long* st_indptr = nullptr;
     long long* st_indices = nullptr;
