@@ -267,16 +267,20 @@ __global__ __launch_bounds__(256) void k_td_wy_t(const double* __restrict__ A, c
     const int b = blockIdx.x, j0 = b * TB_NB, tid = threadIdx.x;
     const int nbb = nrefl - j0 < TB_NB ? nrefl - j0 : TB_NB;
     // v_{j0+i}[c] = A[j0+i][c] for c >= j0+i+1, 0 before; G[i][m] = v_i . v_m (c >= max start)
-    for (int e = tid; e < TB_NB * TB_NB; e += 256) {
-        const int i = e / TB_NB, m = e % TB_NB;
-        double acc = 0.0;
-        if (i < nbb && m < nbb && m >= i) {
-            const double* vi = A + (long long)(j0 + i) * n;
-            const double* vm = A + (long long)(j0 + m) * n;
-            for (int c = j0 + m + 1; c < n; ++c) acc += vi[c] * vm[c];
+    for (int e = tid; e < TB_NB * TB_NB; e += 256) Ts[e / TB_NB][e % TB_NB] = 0.0;
+    {   // one WAVE per pair (i, m >= i), its lanes along the rows (coalesced), ordered wave sum
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int e = wv; e < TB_NB * TB_NB; e += 4) {
+            const int i = e / TB_NB, m = e % TB_NB;
+            double acc = 0.0;
+            if (i < nbb && m < nbb && m >= i) {
+                const double* vi = A + (long long)(j0 + i) * n;
+                const double* vm = A + (long long)(j0 + m) * n;
+                for (int c = j0 + m + 1 + lane; c < n; c += 64) acc += vi[c] * vm[c];
+                acc = wave_sum(acc);
+            }
+            if (lane == 0) G[i][m] = acc;
         }
-        G[i][m] = acc;
-        Ts[i][m] = 0.0;
     }
     __syncthreads();
     for (int i = 0; i < nbb; ++i) {

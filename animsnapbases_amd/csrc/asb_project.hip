@@ -408,28 +408,6 @@ __global__ __launch_bounds__(256) void k_panel_arm(PanelState* __restrict__ pane
 }
 
 __global__ void k_sc_copy(double* __restrict__ sc, int dst, int src) { sc[dst] = sc[src]; }
-// band_E[i] = E[band_idx[i] - v0]
-__global__ __launch_bounds__(256) void k_band_energy(const double* __restrict__ E, const long long* __restrict__ band_idx,
-                                                     const PanelState* __restrict__ bstate, long long v0, double* __restrict__ band_E) {
-    const long long n = bstate->n_cand;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) band_E[i] = E[band_idx[i] - v0];
-}
-// sc[SC_BANDMAX] = max over the band's per-block maxima (k_correct on the band)
-__global__ __launch_bounds__(256) void k_band_max(const double* __restrict__ pmax, int nblk, double* __restrict__ sc,
-                                                  const PanelState* __restrict__ bstate) {
-    __shared__ double sh[256];
-    double m = -1.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) m = fmax(m, pmax[b]);
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
-        __syncthreads();
-    }
-    // a band that overflowed its buffer does not cover (tau2, tau]: no bound from it
-    if (threadIdx.x == 0) sc[SC_BANDMAX] = bstate->pad ? 1.0e300 : sh[0];
-}
-
 // forced single candidate (degenerate ties): global vertex id gidx if this shard owns it
 __global__ void k_force_single(long long gidx, long long v0, long long n_loc, long long* __restrict__ cand_idx,
                                PanelState* __restrict__ panel) {
@@ -861,96 +839,6 @@ __global__ __launch_bounds__(256) void k_build_wt(const double* __restrict__ W, 
         wn2[threadIdx.x] = (threadIdx.x < ncols) ? scal[(k0 + threadIdx.x) * 4 + 1] : 1.0;
 }
 
-// --------------------------------------------------------------------------------------
-// k_project_mfma: Y = X (rows x Fp) . Wt (Fp x 16) with v_mfma_f64_16x16x4_f64.
-//
-// Block = NWV waves; wave w owns the frame chunks [w*CPW, (w+1)*CPW) (16 frames = one
-// 128-byte line per row each) and keeps its slice of Wt in registers for the whole kernel
-// (4 doubles per chunk: lane (i = l&15, g = l>>4) holds Wt[16*chunk + 4g + j][i]).
-// Per group of 48 rows (16 vertices): each lane loads 32 B = frames 4g..4g+3 of row i
-// straight into the A-operand position (k slot g <-> frame 16*chunk + 4g + j for MFMA j),
-// 3 row tiles x CPW chunks x 4 MFMAs, then the NWV partial 48x16 tiles are summed
-// through LDS and the epilogue writes the raw coefficients y / |w|^2 (k_correct finishes).
-// --------------------------------------------------------------------------------------
-template <int NWV, int CPW>
-__global__ __launch_bounds__(NWV * 64) void k_project_mfma(
-    const double* __restrict__ X, long long rows, long long n_vert, int Fp, int NC, const double* __restrict__ Wt,
-    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride) {
-    constexpr int NT = NWV * 64;
-    __shared__ double red[NWV * 768];
-    __shared__ double ysh[768];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, g = l >> 4;
-
-    // super-chunks: NWV*CPW chunks (of 16 frames) are covered per sweep; F <= 2048 needs one sweep
-    // and the B registers are loaded once for the whole kernel, longer rows reload them per sweep
-    // (Wt stays L2-resident).
-    const int nsweep = (NC + NWV * CPW - 1) / (NWV * CPW);
-    double breg[CPW][4];
-    auto load_b = [&](int sweep) {
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int chunk = (sweep * NWV + w) * CPW + c;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                breg[c][j] = (chunk < NC) ? Wt[((long long)chunk * 16 + 4 * g + j) * ASB_PANEL_COLS + i] : 0.0;
-        }
-    };
-    if (nsweep == 1) load_b(0);
-    const long long ngroups = (rows + 47) / 48;
-    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const long long row0 = grp * 48;
-        d4 acc[3];
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt) acc[rt] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int sweep = 0; sweep < nsweep; ++sweep) {
-            if (nsweep > 1) load_b(sweep);
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt) {
-                long long r = row0 + 16 * rt + i;
-                if (r >= rows) r = rows - 1;
-                const double* xr = X + r * Fp + 4 * g;
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) {
-                    const int chunk = (sweep * NWV + w) * CPW + c;
-                    if (chunk < NC) {
-                        const double4 x = *reinterpret_cast<const double4*>(xr + (long long)chunk * 16);
-                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, breg[c][0], acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, breg[c][1], acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.z, breg[c][2], acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.w, breg[c][3], acc[rt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // C/D layout of the f64 MFMA: row = g + 4*reg, col = i
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) red[w * 768 + (16 * rt + g + 4 * q) * 16 + i] = acc[rt][q];
-        __syncthreads();
-        for (int o = tid; o < 768; o += NT) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < NWV; ++q) s += red[q * 768 + o];
-            ysh[o] = s;
-        }
-        __syncthreads();
-        // components: thread (col, vl) writes c[col][3v .. 3v+2]
-        if (tid < 256) {
-            const int col = tid >> 4, vl = tid & 15;
-            const long long v = grp * 16 + vl;
-            if (col < ncols && v < n_vert) {
-                const double inv = wn2[col];
-                double* dst = comps + (long long)col * comp_stride + v * 3;
-                dst[0] = ysh[(3 * vl + 0) * 16 + col] / inv;
-                dst[1] = ysh[(3 * vl + 1) * 16 + col] / inv;
-                dst[2] = ysh[(3 * vl + 2) * 16 + col] / inv;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // B-operand panel from a frame-major (F x ldw) matrix: columns k0 .. k0+ncols-1, unit norms
 __global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ Wfk, long long ldw, long long k0,
                                                      int ncols, int F, int Fp, double* __restrict__ Wt,
@@ -978,75 +866,6 @@ __global__ __launch_bounds__(256) void k_build_wt_fk(const double* __restrict__ 
 // --------------------------------------------------------------------------------------
 __device__ __forceinline__ int wt_perm(int f) { return (f & ~5) | ((f & 1) << 2) | ((f >> 2) & 1); }
 
-__global__ __launch_bounds__(1024) void k_project_lds(
-    const double* __restrict__ X, long long rows, int Fp, int f_begin, int nf, const double* __restrict__ Wt,
-    const double* __restrict__ wn2, int ncols, double* __restrict__ comps, long long comp_stride,
-    double* __restrict__ ypart, int first, int last, unsigned int* __restrict__ counter) {
-    extern __shared__ double wl[];
-    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4;
-    for (int e = tid; e < nf * 16; e += blockDim.x) {
-        const int f = e >> 4, c = e & 15;
-        wl[wt_perm(f) * 16 + c] = Wt[(long long)(f_begin + f) * ASB_PANEL_COLS + c];
-    }
-    __syncthreads();
-    const long long ntiles = (rows + 15) / 16;
-    const int nchunk = nf / 16;
-    // LDS word offsets of this lane's four B values inside a chunk (see wt_perm): frame 4g + j
-    const int boff0 = (((g >> 1) * 8 + 0 + (g & 1)) * 16 + i);         // j = 0
-    const int boff1 = (((g >> 1) * 8 + 4 + (g & 1)) * 16 + i);         // j = 1
-    const int boff2 = (((g >> 1) * 8 + 2 + (g & 1)) * 16 + i);         // j = 2
-    const int boff3 = (((g >> 1) * 8 + 6 + (g & 1)) * 16 + i);         // j = 3
-    for (;;) {
-        unsigned int t = 0;
-        if (l == 0) t = atomicAdd(counter, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if ((long long)t >= ntiles) break;
-        long long r = (long long)t * 16 + i;
-        if (r >= rows) r = rows - 1;
-        const double* xr = X + r * Fp + f_begin + 4 * g;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (!first) acc = *reinterpret_cast<const d4*>(ypart + ((long long)t * 64 + l) * 4);
-#define ASB_MFMA4(xv, cc)                                                                       \
-    {                                                                                           \
-        const double* wb = wl + (cc) * 256;                                                     \
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).x, wb[boff0], acc, 0, 0, 0);            \
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).y, wb[boff1], acc, 0, 0, 0);            \
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).z, wb[boff2], acc, 0, 0, 0);            \
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((xv).w, wb[boff3], acc, 0, 0, 0);            \
-    }
-        // groups of 4 chunks, double-buffered in registers: the next group's 8 KB per wave is in
-        // flight while the current group's 16 MFMAs issue
-        const double4* xp = reinterpret_cast<const double4*>(xr);      // chunk c is xp[4*c]
-        int c = 0;
-        double4 a0, a1, a2, a3;
-        if (nchunk >= 4) { a0 = xp[0]; a1 = xp[4]; a2 = xp[8]; a3 = xp[12]; }
-        for (; c + 8 <= nchunk; c += 4) {
-            const double4 b0 = xp[4 * (c + 4)], b1 = xp[4 * (c + 5)], b2 = xp[4 * (c + 6)], b3 = xp[4 * (c + 7)];
-            ASB_MFMA4(a0, c) ASB_MFMA4(a1, c + 1) ASB_MFMA4(a2, c + 2) ASB_MFMA4(a3, c + 3)
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-        }
-        if (c + 4 <= nchunk) {
-            ASB_MFMA4(a0, c) ASB_MFMA4(a1, c + 1) ASB_MFMA4(a2, c + 2) ASB_MFMA4(a3, c + 3)
-            c += 4;
-        }
-        for (; c < nchunk; ++c) {
-            const double4 x = xp[4 * c];
-            ASB_MFMA4(x, c)
-        }
-        if (last) {
-            if (i < ncols) {
-                const double inv = wn2[i];
-                double* dst = comps + (long long)i * comp_stride + (long long)t * 16 + g;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((long long)t * 16 + g + 4 * q < rows) dst[4 * q] = acc[q] / inv;
-            }
-        } else {
-            *reinterpret_cast<d4*>(ypart + ((long long)t * 64 + l) * 4) = acc;
-        }
-    }
-}
-
 // --------------------------------------------------------------------------------------
 // k_project_l2: single sweep over the FULL rows.  The B operand comes from L2 instead of LDS: the panel
 // is stored in MFMA-lane order, Wq[chunk][g][i][j] = W_panel[16*chunk + 4g + j][i], so a lane fetches its four
@@ -1062,95 +881,6 @@ __global__ __launch_bounds__(256) void k_build_wq(const double* __restrict__ Wt,
         const int j = (int)(e & 3), i = (int)((e >> 2) & 15), g = (int)((e >> 6) & 3);
         const long long chunk = e >> 8;
         Wq[e] = Wt[(chunk * 16 + 4 * g + j) * ASB_PANEL_COLS + i];
-    }
-}
-
-// NT row tiles (of 16 rows) per wave share every B load; G chunks per register group (double-buffered).
-template <int NT, int G>
-__global__ __launch_bounds__(512) void k_project_l2(
-    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
-    int ncols, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
-    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
-    constexpr int TR = 16 * NT;
-    const long long ntiles = (rows + TR - 1) / TR;
-    const int nchunk = Fp / 16;
-    const double4* wq = reinterpret_cast<const double4*>(Wq) + (g * 16 + i);      // chunk c: wq[64 * c]
-    for (;;) {
-        unsigned int t = 0;
-        if (l == 0) t = atomicAdd(counter, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if ((long long)t >= ntiles) break;
-        const double4* xp[NT];                                                     // chunk c: xp[m][4 * c]
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            long long r = (long long)t * TR + 16 * m + i;
-            if (r >= rows) r = rows - 1;
-            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
-        }
-        d4 acc[NT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
-        double4 a[NT][G], bq[G], an[NT][G], bn[G];
-        int c = 0;
-        if (nchunk >= G) {
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                bq[q] = wq[64 * q];
-#pragma unroll
-                for (int m = 0; m < NT; ++m) a[m][q] = xp[m][4 * q];
-            }
-        }
-#define ASB_GROUP_MFMA(AA, BB)                                                                         \
-    _Pragma("unroll") for (int q = 0; q < G; ++q) {                                                   \
-        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].x, BB[q].x, acc[m], 0, 0, 0);       \
-        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].y, BB[q].y, acc[m], 0, 0, 0);       \
-        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].z, BB[q].z, acc[m], 0, 0, 0);       \
-        _Pragma("unroll") for (int m = 0; m < NT; ++m)                                                \
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AA[m][q].w, BB[q].w, acc[m], 0, 0, 0);       \
-    }
-        // while the MFMAs of group c issue, the A (HBM) and B (L2) operands of group c+G are in flight
-        for (; c + 2 * G <= nchunk; c += G) {
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                bn[q] = wq[64 * (c + G + q)];
-#pragma unroll
-                for (int m = 0; m < NT; ++m) an[m][q] = xp[m][4 * (c + G + q)];
-            }
-            ASB_GROUP_MFMA(a, bq)
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                bq[q] = bn[q];
-#pragma unroll
-                for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
-            }
-        }
-        if (c + G <= nchunk) {
-            ASB_GROUP_MFMA(a, bq)
-            c += G;
-        }
-        for (; c < nchunk; ++c) {
-            const double4 bb = wq[64 * c];
-#pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                const double4 x = xp[m][4 * c];
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, bb.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, bb.y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.z, bb.z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.w, bb.w, acc[m], 0, 0, 0);
-            }
-        }
-        if (i < ncols) {
-            const double inv = wn2[i];
-            double* dst = comps + (long long)i * comp_stride + (long long)t * TR + g;
-#pragma unroll
-            for (int m = 0; m < NT; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((long long)t * TR + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = acc[m][q] / inv;
-        }
     }
 }
 
@@ -1268,89 +998,6 @@ __global__ __launch_bounds__(64 * S * NQ, OCC) void k_project_l2s(
 // --------------------------------------------------------------------------------------
 #define ASB_MAX_SUB 8          // sub-panels (16-column tiles) per read of X
 struct WideArgs { long long kb[ASB_MAX_SUB]; int nc[ASB_MAX_SUB]; };
-template <int NT, int G, int NCT, bool MAP>
-__global__ __launch_bounds__(512) void k_project_wide(
-    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
-    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter,
-    const long long* __restrict__ vmap, const PanelState* __restrict__ bstate, long long v0) {
-    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
-    constexpr int TR = 16 * NT;
-    if (MAP) rows = 3 * bstate->n_cand;
-    const long long ntiles = (rows + TR - 1) / TR;
-    const int nchunk = Fp / 16;
-    const double4* wq[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) wq[ct] = reinterpret_cast<const double4*>(Wq + (long long)ct * Fp * 16) + (g * 16 + i);
-    for (;;) {
-        unsigned int t = 0;
-        if (l == 0) t = atomicAdd(counter, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if ((long long)t >= ntiles) break;
-        const double4* xp[NT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            long long r = (long long)t * TR + 16 * m + i;
-            if (r >= rows) r = rows - 1;
-            if (MAP) r = 3 * (vmap[r / 3] - v0) + r % 3;
-            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
-        }
-        d4 acc[NT][NCT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
-        double4 a[NT][G], an[NT][G];
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-            for (int m = 0; m < NT; ++m) a[m][q] = (q < nchunk) ? xp[m][4 * q] : make_double4(0, 0, 0, 0);
-        for (int c = 0; c < nchunk; c += G) {
-#pragma unroll
-            for (int q = 0; q < G; ++q)
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-                    an[m][q] = (c + G + q < nchunk) ? xp[m][4 * (c + G + q)] : make_double4(0, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < G; ++q) {
-                if (c + q < nchunk) {
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const double4 b = wq[ct][64 * (c + q)];
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].x, b.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].y, b.y, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].z, b.z, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][q].w, b.w, acc[m][ct], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < G; ++q)
-#pragma unroll
-                for (int m = 0; m < NT; ++m) a[m][q] = an[m][q];
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-            if (i < wa.nc[ct]) {
-                const double inv = wn2[16 * ct + i];
-                double* col = comps + (wa.kb[ct] + i) * comp_stride;
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        long long r = (long long)t * TR + 16 * m + g + 4 * q;
-                        if (r < rows) {
-                            if (MAP) r = 3 * (vmap[r / 3] - v0) + r % 3;
-                            col[r] = acc[m][ct][q] / inv;
-                        }
-                    }
-            }
-    }
-}
-
 // k_project_l2w: the NCT-tile product with S waves per row tile (k_project_l2s's split: wave `sub` takes every S-th group of
 // G frame chunks, partial accumulators summed through LDS in a fixed order) and BOTH operands of the next group in flight
 // while the current group's 4 * NT * NCT * G MFMAs issue.  k_project_wide gives a whole 64-row tile to one wave -- 125 chunks
@@ -1497,263 +1144,6 @@ __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
                 }
         }
         // the next iteration's first barrier (tile id) also orders these reads of `red` before its next writes
-    }
-}
-
-// k_project_l2b: the multi-tile product with the L2 operand SHARED through LDS.  Measured on config 4 (asb_test_l2w_probe,
-// tools/probe_l2w.py): k_project_l2w without its MFMAs takes 0.99 / 1.08 / 1.15 ms for 2 / 3 / 4 tiles against 0.87 ms for the
-// X operand alone, and just as long with X coming from cache -- the vector memory path delivers ~8.3 TB/s in all, and every
-// wave fetching its own copy of the weights (1.2 GB per tile and launch, against 4.8 GB of X) is what fills it.  Here a
-// block of 8 waves owns 256 rows: wave w = (row tile rt = w & 3, frame half sub = w >> 2); per iteration the block stages the
-// weights of TWO frame chunks (one per frame half, all NCT column tiles) in LDS once -- a quarter of the L2 traffic -- while
-// each wave keeps its own 64 rows of X in registers one chunk ahead.  One barrier per iteration (double-buffered stage);
-// the two frame halves meet through LDS at the end of the tile, one column tile at a time.
-template <int NCT>
-__global__ __launch_bounds__(512, 2) void k_project_l2b(
-    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
-    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
-    constexpr int NT = 4;
-    extern __shared__ double l2b_lds[];
-    double4* Bs = reinterpret_cast<double4*>(l2b_lds);                            // [2 stages][2 chunks][NCT][64 lanes]
-    typedef double (*red_t)[NT][4][64];
-    red_t red = reinterpret_cast<red_t>(l2b_lds + (size_t)2 * 2 * NCT * 64 * 4);   // [4 row tiles][NT][4][64]
-    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2b_lds + (size_t)2 * 2 * NCT * 64 * 4 + (size_t)4 * NT * 4 * 64);
-    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w & 3, sub = w >> 2;
-    const long long ntiles = (rows + 255) / 256;
-    const int nchunk = Fp / 16, npair = (nchunk + 1) / 2;
-    // staging: thread e < 128 NCT fetches one double4 of the pair's weights: e = (chunk of the pair, column tile, lane)
-    const bool stager = tid < 128 * NCT;
-    const int s_cc = tid / (64 * NCT), s_ct = (tid / 64) % NCT, s_l = tid & 63;
-    const double4* s_src = reinterpret_cast<const double4*>(Wq + (long long)s_ct * Fp * 16) + s_l;      // chunk c: s_src[64 * c]
-    for (;;) {
-        if (tid == 0) tile_sh = atomicAdd(counter, 1u);
-        __syncthreads();
-        const unsigned int t = tile_sh;
-        if ((long long)t >= ntiles) break;                      // the same for every wave of the block
-        const long long base = (long long)t * 256 + 64 * rt;
-        const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            long long r = base + 16 * m + i;
-            if (r >= rows) r = rows - 1;
-            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
-        }
-        d4 acc[NT][NCT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
-        double4 a[NT], an[NT], breg = make_double4(0, 0, 0, 0);
-        {
-            const int c = sub < nchunk ? sub : nchunk - 1;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) a[m] = xp[m][4 * c];
-            if (stager) breg = (s_cc < nchunk) ? s_src[64 * s_cc] : make_double4(0, 0, 0, 0);
-        }
-        for (int j = 0; j < npair; ++j) {
-            double4* stage = Bs + (size_t)(j & 1) * 2 * NCT * 64;
-            if (stager) stage[(s_cc * NCT + s_ct) * 64 + s_l] = breg;
-            // the next pair's operands fly while this pair's MFMAs issue
-            if (j + 1 < npair) {
-                const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
-#pragma unroll
-                for (int m = 0; m < NT; ++m) an[m] = xp[m][4 * cn];
-                const int sc = 2 * (j + 1) + s_cc;
-                if (stager) breg = (sc < nchunk) ? s_src[64 * sc] : make_double4(0, 0, 0, 0);
-            }
-            __syncthreads();            // the stage is complete; its previous readers (iteration j - 2) passed barrier j - 1
-            if (2 * j + sub < nchunk) {
-                const double4* bsrc = stage + (size_t)sub * NCT * 64 + l;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const double4 b = bsrc[ct * 64];
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b.y, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].z, b.z, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].w, b.w, acc[m][ct], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < NT; ++m) a[m] = an[m];
-        }
-        // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            __syncthreads();            // `red` is free (first round: also orders the last MFMA stage against nothing of ours)
-            if (sub == 1) {
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) red[rt][m][q][l] = acc[m][ct][q];
-            }
-            __syncthreads();
-            if (sub == 0 && i < wa.nc[ct]) {
-                const double inv = wn2[16 * ct + i];
-                double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = (acc[m][ct][q] + red[rt][m][q][l]) / inv;
-            }
-        }
-        // the next iteration's first barrier (tile id) orders the last reads of `red` and of the stages before their reuse
-    }
-}
-
-// k_project_l2c: the multi-tile product with the weights staged in LDS by DIRECT loads (global_load_lds_dwordx4: no
-// registers), P chunk pairs per stage, ONE barrier per stage.  k_project_l2b showed that sharing the weights pays only if the
-// waves are not put in lock-step chunk by chunk: here a wave drifts by up to P iterations between barriers.  Block = 8 waves =
-// (row tile rt = w & 3 of 64 rows) x (frame half sub = w >> 2: chunk 2 j + sub of pair j), 256 rows per block tile; stage s
-// holds the weights of pairs [s P, s P + P) for all NCT column tiles: 4 P NCT wave-instructions of 1 KB, 1/8 of them per
-// wave, issued right behind the barrier that opens stage s - 1 -- so a whole stage of MFMAs hides them.  Their completion
-// needs no extra wait: loads retire in order, and before the barrier that opens stage s every wave has waited for X chunks
-// it requested AFTER those instructions.  LDS: 2 stages x 4 P NCT KB + 32 KB for the meeting of the two frame halves.
-template <int NCT, int P, int NT = 4, int RT = 4, int OCC = 2, int MODE = 0>      // RT row tiles of 16 NT rows per block, 2 RT waves; MODE: probes
-__global__ __launch_bounds__(128 * RT, OCC) void k_project_l2c(
-    const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq, const double* __restrict__ wn2,
-    WideArgs wa, double* __restrict__ comps, long long comp_stride, unsigned int* __restrict__ counter) {
-    constexpr int NI = 4 * P * NCT, PER = NI / (2 * RT), TR = 16 * NT, BR = TR * RT;       // 1-KB instructions per stage / per wave; rows
-    static_assert(NI % (2 * RT) == 0, "stage instructions must divide over the waves");
-    // the direct loads of stage s + 1 are never waited for explicitly: they are complete at the barrier that opens stage s + 1
-    // because every wave waits for an X chunk it requested AFTER them -- which needs a later pair in the same stage
-    static_assert(P >= 2, "a stage must hold at least two chunk pairs (completion of the direct loads, see the header)");
-    static_assert(2 * NI * 128 * 8 <= 160 * 1024, "both stages must fit the LDS range M0 addresses (gfx950: 160 KB)");
-    extern __shared__ double l2c_lds[];
-    constexpr int STAGE_D = NI * 128;                           // doubles per stage
-    typedef double (*red_t)[NT][4][64];
-    // the meeting place of the two frame halves shares the stages' memory: it is used only behind the tile's last MFMA
-    // (a barrier in between), when no stage is being read or filled
-    constexpr int RED_D = RT * NT * 4 * 64, BODY_D = 2 * STAGE_D > RED_D ? 2 * STAGE_D : RED_D;
-    red_t red = reinterpret_cast<red_t>(l2c_lds);
-    unsigned int& tile_sh = *reinterpret_cast<unsigned int*>(l2c_lds + BODY_D);
-    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4, w = tid >> 6, rt = w % RT, sub = w / RT;
-    const long long ntiles = (rows + BR - 1) / BR;
-    const int nchunk = Fp / 16, npair = (nchunk + 1) / 2, nstage = (npair + P - 1) / P;
-    // instruction q of a stage = ((chunk cc of the stage, column tile ct), half h of the lane's double4): lane l's 16 bytes
-    auto issue_stage = [&](int s) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int q = w * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
-            const int c = 2 * s * P + cc;
-            if (c < nchunk) {
-                // by hand (m0 = LDS byte address of the instruction's 1 KB, each lane's 16 bytes behind one another): a direct
-                // load the compiler knows about is a second kind of pending vector-memory event, and with two kinds pending
-                // its waitcnt pass no longer counts -- every wait for an X chunk becomes vmcnt(0), which also waits for the
-                // chunk requested a moment ago (1.76 ms; the X prefetch then overlaps with nothing)
-                const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
-                const unsigned lds_byte = __builtin_amdgcn_readfirstlane((unsigned)(((s & 1) * STAGE_D + q * 128) * 8));
-                unsigned m0_keep;                                // m0 is the compiler's: put back what it held
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(m0_keep) : "v"(src), "s"(lds_byte) : "memory");
-            }
-        }
-    };
-    for (;;) {
-        if (tid == 0) tile_sh = atomicAdd(counter, 1u);
-        __syncthreads();
-        const unsigned int t = tile_sh;
-        if ((long long)t >= ntiles) break;                      // the same for every wave of the block
-        const long long base = (long long)t * BR + TR * rt;
-        const double4* xp[NT];                                  // chunk c: xp[m][4 * c]
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            long long r = base + 16 * m + i;
-            if (r >= rows) r = rows - 1;
-            xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
-        }
-        d4 acc[NT][NCT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
-        // X chunks in two register sets used alternately (pair j computes from one while pair j + 1's chunk lands in the other):
-        // NO copy between them -- a rotation "a = an" at the end of the iteration makes the compiler spread the copies through
-        // the MFMA block, each waiting for the chunk requested a moment ago, and the prefetch overlaps with nothing.
-        double4 a0[NT], a1[NT];
-        issue_stage(0);
-        {
-            const int c = sub < nchunk ? sub : nchunk - 1;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) a0[m] = xp[m][4 * c];
-        }
-        __builtin_amdgcn_s_waitcnt(0);                          // first stage (and first X chunk) of the tile: one exposed latency
-        auto pair_step = [&](int j, double4 (&cur)[NT], double4 (&nxt)[NT]) {
-            const int s = j / P;
-            if (j == s * P && MODE != 5) __syncthreads();      // stage s is complete in LDS (see above); the readers of stage s - 1 are done
-            if (MODE == 3 || MODE == 4) {                       // probes: no X traffic inside the loop
-#pragma unroll
-                for (int m = 0; m < NT; ++m) nxt[m] = cur[m];
-            } else {
-                // the next pair's X chunk flies while this pair's MFMAs issue -- UNCONDITIONALLY (behind the last pair: the last
-                // chunk once more): only if every path issues the same number of loads can the compiler wait for the
-                // current chunk with vmcnt(8) instead of vmcnt(0), which would wait for this prefetch as well
-                const int cn = 2 * (j + 1) + sub < nchunk ? 2 * (j + 1) + sub : nchunk - 1;
-#pragma unroll
-                for (int m = 0; m < NT; ++m) nxt[m] = xp[m][4 * cn];
-            }
-            if (2 * j + sub < nchunk) {
-                const int cc = 2 * (j - s * P) + sub;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    // The weights come out of LDS by hand-written ds_read_b128: a compiler-visible LDS load behind a direct load
-                    // into the same LDS array makes the waitcnt pass wait for ALL outstanding vector loads (vmcnt(0)) in front
-                    // of it.  That the stage is complete is guaranteed by the barrier that opened it (see the header).
-                    double2 b0, b1;
-                    if (MODE == 4) {                            // probe 4: no LDS reads either
-                        b0 = make_double2(cur[0].x, cur[0].y);
-                        b1 = make_double2(cur[0].z, cur[0].w);
-                    } else {
-                        const unsigned lds_addr = (unsigned)(((s & 1) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
-                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));      // early-clobber: neither may share the address register
-                    }
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].x, b0.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].y, b0.y, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].z, b1.x, acc[m][ct], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].w, b1.y, acc[m][ct], 0, 0, 0);
-                    // the next stage's direct loads go out BEHIND the wait for the current X chunk (the first MFMA above): in front
-                    // of it they would be among the "newest 8" that wait lets pass, and the next X chunk would be waited for instead
-                    if (ct == 0 && j == s * P && s + 1 < nstage) issue_stage(s + 1);
-                }
-            } else if (j == s * P && s + 1 < nstage) {
-                issue_stage(s + 1);
-            }
-        };
-        for (int j = 0; j < npair; j += 2) {
-            pair_step(j, a0, a1);
-            if (j + 1 < npair) pair_step(j + 1, a1, a0);
-        }
-        // the two frame halves of a row tile meet through LDS, one column tile at a time (fixed order: half 0 + half 1)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            __syncthreads();
-            if (sub == 1) {
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) red[rt][m][q][l] = acc[m][ct][q];
-            }
-            __syncthreads();
-            if (sub == 0 && i < wa.nc[ct]) {
-                const double inv = wn2[16 * ct + i];
-                double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = (acc[m][ct][q] + red[rt][m][q][l]) / inv;
-            }
-        }
-        // the next iteration's first barrier (tile id) orders the last reads of `red` and of the stages before their reuse
     }
 }
 
@@ -2253,70 +1643,6 @@ static int project_pass(asb_ctx* ctx, long long k0, int ncols, int proven = ASB_
     return ASB_OK;
 }
 
-// ---- super-panels ------------------------------------------------------------------------------------------------
-static int super_alloc(asb_ctx* ctx) {
-    int rc;
-    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->band_idx, (size_t)ctx->band_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->band_E, (size_t)ctx->band_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->btmp, (size_t)ASB_CBLOCKS * ctx->band_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->bcnt, (size_t)ASB_CBLOCKS))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->bstate, (size_t)1))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->bpmax, (size_t)ctx->nblk_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->bpidx, (size_t)ctx->nblk_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->bpsum, (size_t)ctx->nblk_cap))) return rc;
-    return ASB_OK;
-}
-
-// builds tile ct's panel operands (B in both layouts, |w|^2) for components [kb, kb + nc)
-static void wide_build_tile(asb_ctx* ctx, int ct, long long kb, int nc) {
-    double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
-    hipLaunchKernelGGL(k_build_wt, dim3(64), dim3(256), 0, ctx->stream, ctx->W, ctx->scal, kb, nc, (int)ctx->Fp, Wt, ctx->wn2t3 + 16 * ct);
-    hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, Wt, (int)ctx->Fp, ctx->Wq3 + (size_t)ct * ctx->Fp * 16,
-                       ctx->tile_counter);
-}
-
-// correction + energy update of tile ct (its columns against everything before them), like the tail of project_pass
-static int wide_correct_tile(asb_ctx* ctx, int ct, long long kb, int nc, bool band) {
-    const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
-    hipLaunchKernelGGL(k_panel_gram, dim3((unsigned)(kb + nc)), dim3(256), 0, ctx->stream, ctx->W, Wt, (int)ctx->Fp, ctx->gram);
-    if (band) {
-        long long cw = (ctx->band_cap + 255) / 256;
-        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                           (long long)0, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->band_E, ctx->bpmax, ctx->bpidx, ctx->bpsum,
-                           ctx->colpart, ctx->band_idx, ctx->bstate, (long long)ctx->v0);
-        hipLaunchKernelGGL(k_band_max, dim3(1), dim3(256), 0, ctx->stream, ctx->bpmax, cgrid, ctx->scalar_dev, ctx->bstate);
-    } else {
-        long long cw = (ctx->n_loc + 255) / 256;
-        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-        hipLaunchKernelGGL(k_correct<false>, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                           (long long)ctx->n_loc, (int)kb, nc, ctx->gram, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
-                           ctx->psum, ctx->colpart);
-        ctx->nblk = cgrid;
-        hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, nc, kb, ctx->scal);
-    }
-    ASB_CHECK_LAUNCH(ctx);
-    return ASB_OK;
-}
-
-// the band's exact energies after the sub-panel [kb, kb + nc): projection of the band's rows of X (16 columns), correction
-static int band_pass(asb_ctx* ctx, long long kb, int nc) {
-    wide_build_tile(ctx, 0, kb, nc);
-    WideArgs wa{};
-    wa.kb[0] = kb;
-    wa.nc[0] = nc;
-    // 16-row tiles: the band is only ~36k rows, larger tiles would leave most waves idle
-    hipLaunchKernelGGL((k_project_wide<1, 8, 1, true>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, (long long)0, (int)ctx->Fp,
-                       ctx->Wq3, ctx->wn2t3, wa, ctx->comps, (long long)(3 * ctx->n_loc), ctx->tile_counter, ctx->band_idx, ctx->bstate,
-                       (long long)ctx->v0);
-    ASB_CHECK_LAUNCH(ctx);
-    return wide_correct_tile(ctx, 0, kb, nc, true);
-}
-
 // the multi-tile projection kernel (bracketed by the profiling events); tiles built by wide_build_tile.
 // Up to 3 tiles: compiled for two waves per SIMD (<= 256 registers: 8 waves x 8 KB of X in flight per CU); from 4 tiles on
 // the accumulators alone take 128+ registers: one wave per SIMD, the MFMA time per chunk (1024 cycles per tile) hides the
@@ -2335,35 +1661,6 @@ static int launch_l2w_cfg(asb_ctx* ctx, const WideArgs& wa, int blocks_per_cu) {
     const long long cap = (long long)blocks_per_cu * ctx->n_cu;
     hipLaunchKernelGGL((k_project_l2w<NT, G, S, NCT, OCC, PD>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * S), lds, ctx->stream,
                        ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    return ASB_OK;
-}
-template <int NCT>
-static int launch_l2b(asb_ctx* ctx, const WideArgs& wa) {
-    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 255) / 256;
-    const size_t lds = ((size_t)2 * 2 * NCT * 64 * 4 + (size_t)4 * 4 * 4 * 64 + 2) * sizeof(double);
-    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
-    bool& attr_set = attr_set_dev[ctx->dev & 63];
-    if (!attr_set) {
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2b<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_project_l2b<NCT>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(512), lds, ctx->stream,
-                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
-    return ASB_OK;
-}
-template <int NCT, int P, int NT = 4, int RT = 4, int OCC = 2>
-static int launch_l2c(asb_ctx* ctx, const WideArgs& wa) {
-    const long long rows = 3 * ctx->n_loc, ntiles = (rows + 16 * NT * RT - 1) / (16 * NT * RT);
-    const size_t stage2 = (size_t)2 * 4 * P * NCT * 128, redd = (size_t)RT * NT * 4 * 64;
-    const size_t lds = ((stage2 > redd ? stage2 : redd) + 2) * sizeof(double);
-    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
-    bool& attr_set = attr_set_dev[ctx->dev & 63];
-    if (!attr_set) {
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<NCT, P, NT, RT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_project_l2c<NCT, P, NT, RT, OCC>), dim3((unsigned)(ntiles < ctx->n_cu ? ntiles : ctx->n_cu)), dim3(128 * RT), lds,
-                       ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
     return ASB_OK;
 }
 template <int NCT, int P, int SYNC, int NSB = (SYNC ? 3 : 2), int XD = 1>
@@ -2385,30 +1682,14 @@ static int launch_l2d(asb_ctx* ctx, const WideArgs& wa) {
 }
 template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
-    if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage
-    if (variant == 46 && NCT == 4) return launch_l2c<4, 3>(ctx, wa);         // round 2's kernel (tile queue, barrier per stage)
+    if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage (two buffers)
     if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
     if (variant == 48 && NCT == 4) return launch_l2d<4, 2, 1, 4>(ctx, wa);   // 32-KB stages, four buffers: direct loads two stages ahead
-    if (variant == 49 && NCT == 4) return launch_l2d<4, 3, 1, 3, 2>(ctx, wa);   // third X register set
-    if (variant == 40 && NCT <= 5)       // weights staged in LDS by direct loads, one barrier per P chunk pairs
-        return launch_l2c<(NCT <= 5 ? NCT : 2), (NCT <= 3 ? 4 : (NCT == 4 ? 3 : 2))>(ctx, wa);
-    if (variant == 41 && NCT <= 5)       // the same with shorter stages
-        return launch_l2c<(NCT <= 5 ? NCT : 2), 2>(ctx, wa);
-    if (variant == 42 && NCT == 4)       // 32-row tiles per wave, 12 waves per block: three waves per SIMD
-        return launch_l2c<4, 3, 2, 6, 3>(ctx, wa);
-    if (variant == 43 && NCT == 4)       // 48-row tiles per wave, 8 waves
-        return launch_l2c<4, 3, 3, 4, 2>(ctx, wa);
-    if (variant == 44 && NCT == 4)       // 32-row tiles per wave, 16 waves per block: four waves per SIMD
-        return launch_l2c<4, 3, 2, 8, 4>(ctx, wa);
-    if (variant == 20 && NCT <= 4) return launch_l2b<(NCT <= 4 ? NCT : 2)>(ctx, wa);                               // weights shared through LDS
-    if (variant == 30 && NCT <= 4) return launch_l2w_cfg<8, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 128-row tiles: half the weight traffic
-    if (variant == 31 && NCT <= 4) return launch_l2w_cfg<6, 1, 2, (NCT <= 4 ? NCT : 1), 1, 1>(ctx, wa, 2);           // 96-row tiles
-    if (variant == 3 && NCT <= 5) return launch_l2w_cfg<4, 2, 2, (NCT <= 5 ? NCT : 1), 1, 1>(ctx, wa, 2);       // two chunks per group
-    if (variant == 10) return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 2>(ctx, wa, NCT <= 3 ? 4 : 2);   // HBM operand two chunks ahead
-    if (variant == 5) return launch_l2w_cfg<4, 1, 2, NCT, 1, 1>(ctx, wa, 2);                                    // one wave per SIMD throughout
-    // default: up to 3 sub-panels every wave fetches its own weights (two waves per SIMD); 4 sub-panels only fit two waves per
-    // SIMD with the weights in LDS (1.83 ms against 1.96 ms with one wave per SIMD; for 2 and 3 sub-panels the LDS form loses:
-    // 1.15 / 1.32 against 1.07 / 1.22 ms)
+    // (round 2's variants -- one wave per tile, 32- / 48- / 96- / 128-row tiles, deeper prefetch, weights shared through LDS with a
+    // barrier per chunk pair (k_project_l2b) or per stage from a tile queue (k_project_l2c) -- were measured and removed; their
+    // numbers are in DESIGN.md section 5 and profiles/r02*)
+    // default: up to 3 sub-panels every wave fetches its own weights from L2 (two waves per SIMD); 4 sub-panels only fit two waves
+    // per SIMD with the weights staged in LDS
     if (NCT == 4) return launch_l2d<4, 3, 1>(ctx, wa);
     return launch_l2w_cfg<4, 1, 2, NCT, (NCT <= 3 ? 2 : 1), 1>(ctx, wa, NCT <= 3 ? 4 : 2);
 }
@@ -2418,17 +1699,7 @@ static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     size_t slot;
     int rc;
     if ((rc = prof_begin(ctx, slot))) return rc;
-    if (variant == 0 && ntile <= 3) {          // round 1's kernel: one wave per 64-row tile
-        if (ntile == 1)
-            hipLaunchKernelGGL((k_project_wide<4, 2, 1, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-        else if (ntile == 2)
-            hipLaunchKernelGGL((k_project_wide<4, 2, 2, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-        else
-            hipLaunchKernelGGL((k_project_wide<4, 1, 3, false>), dim3(ctx->n_cu), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                               ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter, (const long long*)nullptr, (const PanelState*)nullptr, (long long)0);
-    } else if (ntile == 1) {          // one tile: the single-panel kernel on the tile's operands
+    if (ntile == 1) {                 // one tile: the single-panel kernel on the tile's operands
         const long long ntiles = (rows + 63) / 64;
         hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream,
                            ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa.nc[0], ctx->comps + (size_t)wa.kb[0] * rows, rows, ctx->tile_counter);
@@ -2498,16 +1769,8 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
         if (nct == N && mode < 10) rc = mode == 0 ? l2w_probe_launch<N, 0>(ctx, wa) : (mode == 1 ? l2w_probe_launch<N, 1>(ctx, wa) : l2w_probe_launch<N, 2>(ctx, wa));
         ASB_PROBE_CASE(2) ASB_PROBE_CASE(3) ASB_PROBE_CASE(4)
 #undef ASB_PROBE_CASE
-        if (nct == 4 && mode >= 10) {          // k_project_l2c<4, 3>: 10 = as it runs, 13 = no X loads in the loop, 14 = nor LDS reads
-            const long long rows = 3 * ctx->n_loc, ntl = (rows + 255) / 256;
-            const size_t lds = ((size_t)2 * 4 * 3 * 4 * 128 + 2) * sizeof(double);
-            const unsigned grid = (unsigned)(ntl < ctx->n_cu ? ntl : ctx->n_cu);
-#define ASB_L2C_PROBE(M)                                                                                                        \
-            {                                                                                                                   \
-                ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2c<4, 3, 4, 4, 2, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((k_project_l2c<4, 3, 4, 4, 2, M>), dim3(grid), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, \
-                                   ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);                                     \
-            }
+        if (nct == 4 && mode >= 20) {          // k_project_l2d<4, 3>: 20 = as it runs, 23 = no X loads in the loop, 24 = nor LDS reads, 25 = no stage sync
+            const long long rows = 3 * ctx->n_loc;
 #define ASB_L2D_PROBE(M)                                                                                                        \
             {                                                                                                                   \
                 const size_t lds3 = ((size_t)3 * 4 * 3 * 4 * 128 + 2) * sizeof(double);                                         \
@@ -2516,11 +1779,8 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
                 hipLaunchKernelGGL((k_project_l2d<4, 3, 1, 3, M>), dim3((unsigned)(ngr < ctx->n_cu ? ngr : ctx->n_cu)), dim3(512), lds3, ctx->stream, \
                                    ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows);                     \
             }
-            if (mode == 10) ASB_L2C_PROBE(0) else if (mode == 13) ASB_L2C_PROBE(3) else if (mode == 15) ASB_L2C_PROBE(5)
-            else if (mode == 20) ASB_L2D_PROBE(0) else if (mode == 23) ASB_L2D_PROBE(3) else if (mode == 24) ASB_L2D_PROBE(4)
-            else if (mode == 25) ASB_L2D_PROBE(5) else ASB_L2C_PROBE(4)
+            if (mode == 23) ASB_L2D_PROBE(3) else if (mode == 24) ASB_L2D_PROBE(4) else if (mode == 25) ASB_L2D_PROBE(5) else ASB_L2D_PROBE(0)
 #undef ASB_L2D_PROBE
-#undef ASB_L2C_PROBE
             rc = ASB_OK;
         }
         if (rc) return rc;
@@ -2536,84 +1796,24 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
     return ASB_OK;
 }
 
-// ONE pass over X for up to three sub-panels
-static int project_pass_wide(asb_ctx* ctx, int ntile, const long long* kb, const int* nc) {
-    WideArgs wa{};
-    for (int ct = 0; ct < ntile; ++ct) {
-        wide_build_tile(ctx, ct, kb[ct], nc[ct]);
-        wa.kb[ct] = kb[ct];
-        wa.nc[ct] = nc[ct];
-    }
-    ASB_CHECK_LAUNCH(ctx);
-    int rc;
-    if ((rc = launch_wide(ctx, ntile, wa))) return rc;
-    for (int ct = 0; ct < ntile; ++ct)
-        if ((rc = wide_correct_tile(ctx, ct, kb[ct], nc[ct], false))) return rc;
-    return ASB_OK;
-}
-
-static int launch_project_lds(asb_ctx* ctx, int ncols, double* out) {
-    const int NC = (int)(ctx->Fp / 16);
-    const long long rows = 3 * ctx->n_loc;
-    const int nsweep = (NC + 62) / 63;
-    const int cs = (NC + nsweep - 1) / nsweep;
-    int rc;
-    if (nsweep > 1 && (rc = asb_alloc(ctx, &ctx->ypart, (size_t)((rows + 15) / 16) * 256))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
-    const size_t lds = (size_t)cs * 16 * 16 * sizeof(double);
-    static bool attr_set_dev[64] = {false};              // per device: a second GPU in the same process needs its own
-    bool& attr_set = attr_set_dev[ctx->dev & 63];
-    if (!attr_set) {
-        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 63 * 256 * 8));
-        attr_set = true;
-    }
-    const long long ntiles = (rows + 15) / 16;
-    long long wantb = (ntiles + 15) / 16;
-    const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
-    ASB_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 16 * sizeof(unsigned int), ctx->stream));
-    for (int sw = 0; sw < nsweep; ++sw) {
-        const int c0 = sw * cs, c1 = (c0 + cs < NC) ? c0 + cs : NC;
-        size_t slot;
-        if ((rc = prof_begin(ctx, slot))) return rc;
-        hipLaunchKernelGGL(k_project_lds, dim3(grid), dim3(1024), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, c0 * 16,
-                           (c1 - c0) * 16, ctx->Wt, ctx->wn2t, ncols, out, rows, ctx->ypart, sw == 0 ? 1 : 0,
-                           sw == nsweep - 1 ? 1 : 0, ctx->tile_counter + sw);
-        if ((rc = prof_end(ctx, slot))) return rc;
-    }
-    ASB_CHECK_LAUNCH(ctx);
-    return ASB_OK;
-}
-
 static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
     const long long rows = 3 * ctx->n_loc;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->Wq, (size_t)ctx->Fp * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     hipLaunchKernelGGL(k_build_wq, dim3(64), dim3(256), 0, ctx->stream, ctx->Wt, (int)ctx->Fp, ctx->Wq, ctx->tile_counter);
-    const int variant = ctx->l2_variant;
-    const int NT = variant == 0 ? 2 : (variant == 1 ? 3 : 4);      // 4, 5: k_project_l2s<4, 2, S, 1> with S = 2, 4 waves per tile
-    const long long ntiles = (rows + 16 * NT - 1) / (16 * NT);
-    long long wantb = (ntiles + 7) / 8;
-    const int grid = (int)(wantb < ctx->n_cu ? wantb : ctx->n_cu);
+    const int variant = ctx->l2_variant;       // 4 (default): two waves (one 128-thread block) per 64-row tile; 5: four; 6: <= 256 registers
+    const long long ntiles = (rows + 63) / 64;
     size_t slot;
     if ((rc = prof_begin(ctx, slot))) return rc;
-    if (variant == 0)
-        hipLaunchKernelGGL((k_project_l2<2, 4>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 1)
-        hipLaunchKernelGGL((k_project_l2<3, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 4)      // default: two waves (one 128-thread block) per 64-row tile
-        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
-                           ctx->wn2t, ncols, out, rows, ctx->tile_counter);
-    else if (variant == 6)      // the same compiled for two waves per SIMD (<= 256 registers)
+    if (variant == 6)
         hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1, 2>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else if (variant == 5)      // four waves per tile: loses at the barriers what it gains at the end of the launch
         hipLaunchKernelGGL((k_project_l2s<4, 2, 4, 1>), dim3((unsigned)(ntiles < 2 * ctx->n_cu ? ntiles : 2 * ctx->n_cu)), dim3(256), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     else
-        hipLaunchKernelGGL((k_project_l2<4, 2>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
+        hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq,
                            ctx->wn2t, ncols, out, rows, ctx->tile_counter);
     if ((rc = prof_end(ctx, slot))) return rc;
     ASB_CHECK_LAUNCH(ctx);
@@ -2621,30 +1821,7 @@ static int launch_project_l2(asb_ctx* ctx, int ncols, double* out) {
 }
 
 static void launch_project(asb_ctx* ctx, int ncols, double* out) {
-    if (ctx->project_kernel == 3) {
-        if (launch_project_l2(ctx, ncols, out) == ASB_OK) return;
-    }
-    if (ctx->project_kernel == 2 && ctx->Fp <= 16 * 63 * 16) {
-        if (launch_project_lds(ctx, ncols, out) == ASB_OK) return;
-    }
-    const int NC = (int)(ctx->Fp / 16);
-    const int nwg = (int)((3 * ctx->n_loc + 47) / 48);
-    int grid = ctx->n_cu * ((NC <= 16) ? 2 : 1);
-    if (grid > nwg) grid = nwg;
-    if (grid < 1) grid = 1;
-    const long long rows = 3 * ctx->n_loc;
-    size_t slot;
-    (void)prof_begin(ctx, slot);
-    if (NC <= 16)
-        hipLaunchKernelGGL((k_project_mfma<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
-                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
-    else if (NC <= 64)
-        hipLaunchKernelGGL((k_project_mfma<8, 8>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
-                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
-    else
-        hipLaunchKernelGGL((k_project_mfma<8, 16>), dim3(grid), dim3(512), 0, ctx->stream, ctx->X, rows, (long long)ctx->n_loc,
-                           (int)ctx->Fp, NC, ctx->Wt, ctx->wn2t, ncols, out, rows);
-    (void)prof_end(ctx, slot);
+    (void)launch_project_l2(ctx, ncols, out);      // (errors surface through the launch check of the caller)
 }
 
 // out_rows (ncols, 3 n_loc) = X . Wfk[:, k0:k0+ncols] / col_scale[k0 + t]   (col_scale NULL: raw products;
@@ -3377,8 +2554,8 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                 // reset is visible before its next record, and whoever writes or reads the buffer again has seen ALL records)
                 unsigned long long* wold = wbuf + (size_t)ring_prev * WROW;
                 const int per = (WROW + Gact - 1) / Gact;
-                const int f = (int)blockIdx.x * per + tid;
-                if (tid < per && f < WROW) coop_store_u64(wold + f, ASB_SENT_D);
+                const int f1 = ((int)blockIdx.x + 1) * per < WROW ? ((int)blockIdx.x + 1) * per : WROW;
+                for (int f = (int)blockIdx.x * per + tid; f < f1; f += 256) coop_store_u64(wold + f, ASB_SENT_D);   // (few blocks: long slices)
             }
             if (!(be > thr) || bi >= n_cand) {           // cannot be proven to be the global arg-max ...
                 if (proven < 0) proven = t;
@@ -3767,68 +2944,6 @@ extern "C" int asb_panel_set_coop(asb_ctx* ctx, int on) {
 }
 extern "C" int64_t asb_panel_capacity(const asb_ctx* ctx) { return ctx ? ctx->m_cap : 0; }
 extern "C" int64_t asb_panel_target(const asb_ctx* ctx) { return ctx ? (ctx->m_target_eff ? ctx->m_target_eff : ctx->m_target) : 0; }
-
-// single-rank driver: all K components with no host round trip inside a panel
-// Super-panel (ASB_SUPER_PANELS=1): up to three sub-panels of <= 16 greedy steps on the SAME candidate rows (the panel
-// kernel writes them back) before X is read once for all their columns.  What lets a later sub-panel prove its picks:
-// a BAND of the next ~12k vertices below the candidates gets exact energies after every sub-panel (projection of its
-// rows only + the usual correction: ~0.1 ms), so the bound on everything that is not a candidate drops from the stale
-// tau to max(tau2, largest band energy), where tau2 (stale, valid) bounds the vertices below the band.
-static int super_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_out) {
-    int rc;
-    *done_out = 0;
-    if ((rc = super_alloc(ctx))) return rc;
-    // candidates: energy > tau
-    for (int level = 1; level <= 2; ++level) {
-        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
-        if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
-    }
-    if ((rc = asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr))) return rc;
-    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU_HI, (int)SC_TAU);
-    // band: tau2 < energy <= tau
-    for (int level = 1; level <= 2; ++level) {
-        if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
-        hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level, (long long)ctx->band_target,
-                           (long long)ctx->band_cap);
-    }
-    hipLaunchKernelGGL(k_compact_a, dim3(ASB_CBLOCKS), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc, (long long)ctx->v0,
-                       ctx->scalar_dev, 0, (long long)ctx->band_cap, ctx->btmp, ctx->bcnt, (int)SC_TAU_HI);
-    hipLaunchKernelGGL(k_compact_b, dim3(ASB_CBLOCKS), dim3(64), 0, ctx->stream, ctx->btmp, ctx->bcnt, ASB_CBLOCKS,
-                       (long long)ctx->band_cap, ctx->band_idx, ctx->bstate);
-    hipLaunchKernelGGL(k_band_energy, dim3(64), dim3(256), 0, ctx->stream, ctx->energy, ctx->band_idx, ctx->bstate, (long long)ctx->v0,
-                       ctx->band_E);
-    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU2, (int)SC_TAU);
-    hipLaunchKernelGGL(k_sc_copy, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU, (int)SC_TAU_HI);
-    ASB_CHECK_LAUNCH(ctx);
-    long long kb[3];
-    int nc[3], ntile = 0;
-    long long total = 0;
-    for (int sp = 0; sp < 3 && k + total < k1; ++sp) {
-        const int steps = (int)((k1 - k - total) < ASB_PANEL_COLS ? (k1 - k - total) : ASB_PANEL_COLS);
-        int64_t done = 0;
-        ctx->run_writeback = 1;
-        ctx->run_theta_band = sp > 0 ? 1 : 0;
-        rc = asb_panel_run(ctx, k + total, steps, 0, 0, &done);
-        ctx->run_writeback = 0;
-        ctx->run_theta_band = 0;
-        if (rc) return rc;
-        if (done == 0) break;
-        kb[ntile] = k + total;
-        nc[ntile] = (int)done;
-        ++ntile;
-        total += done;
-        if (!ctx->run_coop_used) break;            // the two-kernel fallback does not carry the rows over
-        static const int min_go = getenv("ASB_SUPER_MIN") ? atoi(getenv("ASB_SUPER_MIN")) : 4;
-        if (done < min_go) break;                  // the bound is what stopped it early (all energies are moving): read X
-        if (sp < 2 && k + total < k1 && (rc = band_pass(ctx, kb[ntile - 1], (int)done))) return rc;
-    }
-    if (total > 0) {
-        if ((rc = project_pass_wide(ctx, ntile, kb, nc))) return rc;
-        ctx->k_done = k + total;
-    }
-    *done_out = total;
-    return ASB_OK;
-}
 
 // ---- double panels (ASB_DOUBLE_PANELS=1, experimental): TWO sub-panels of up to 16 steps on the same candidate rows (the
 // panel kernel writes the deflated rows back), then ONE read of X for their up to 32 columns.  The second sub-panel's
@@ -4374,15 +3489,7 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     long long k = k0;
     int stalled = 0;
     const int global_all = ctx->n_loc <= ctx->m_cap;
-    // worth it (and the band meaningful) from a few ten thousand vertices on; the band is ~1/10 of the shard, at most 8192
-    const bool use_super = ctx->super_panels && !global_all && ctx->project_kernel == 3 && ctx->panel_coop && ctx->Fp <= 2048 &&
-                           ctx->n_loc >= 20000;
-    if (use_super && !getenv("ASB_BAND_TARGET")) {
-        long long bt = ctx->n_loc / 10;
-        ctx->band_target = bt < 2048 ? 2048 : (bt > 8192 ? 8192 : bt);
-        ctx->band_cap = ctx->band_target * 4 / 3;
-    }
-    const bool use_double = ctx->double_panels && !use_super && !global_all && ctx->panel_coop && ctx->Fp <= 2048 && ctx->spec_panels;
+    const bool use_double = ctx->double_panels && !global_all && ctx->panel_coop && ctx->Fp <= 2048 && ctx->spec_panels;
     while (k < k1) {
         ctx->sel_e2 = nullptr;
         // rows below k are final (projection mode never rewrites a committed column): their copy to the pinned buffer runs
@@ -4393,14 +3500,6 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
             if ((rc = double_panel(ctx, k, k1, &done))) return rc;
             if (done > 0) { k += done; continue; }
             stalled = 1;                                 // nothing stood: exact energies, then the plain path below
-            if ((rc = asb_panel_refresh(ctx, k, nullptr, nullptr))) return rc;
-            continue;
-        }
-        if (use_super && stalled == 0) {
-            int64_t done = 0;
-            if ((rc = super_panel(ctx, k, k1, &done))) return rc;
-            if (done > 0) { k += done; continue; }
-            stalled = 1;                                 // nothing provable: the single-panel path below refreshes / forces
             if ((rc = asb_panel_refresh(ctx, k, nullptr, nullptr))) return rc;
             continue;
         }

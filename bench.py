@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor spec; the guide lists no f64 row; tools/probe_mfma_f64: 70 measured)
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")      # offline rocprofv3 --pmc passes of THIS build
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")      # offline rocprofv3 --pmc passes of THIS build
 
 
 def _cpu_info():
@@ -407,8 +407,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = F * args.steps / dt
         mode = "project" if getattr(eng, "mode", 0) == 1 else "residual"
-        pk = int(os.environ.get("ASB_PROJECT_KERNEL", "3"))
-        nsweep = -(-((F + 15) // 16) // 63) if (mode == "project" and pk == 2) else 1   # k_project_lds: sweeps per pass
+        nsweep = 1
         # dominant kernel: one streaming pass over this rank's shard per launch; algorithmic bytes per launch = 24 n_loc F
         # (c = 1: one read of the shard)
         alg_bytes = 24.0 * n_loc * F / nsweep
@@ -418,16 +417,15 @@ def main():
         # this build at this shape (tools/summarise_pmc.py), an OFFLINE measurement committed under profiles/ -- counters
         # cannot be read from inside the run
         traffic, traffic_src = None, None
-        # default settings: up to four 16-column sub-panels per read of X (k_project_l2c / l2w); the multi-rank protocol
-        # and ASB_DOUBLE_PANELS=0 read X once per 16-column panel (k_project_l2s)
-        wide = (mode == "project" and pk == 3 and world == 1 and not forced and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0"
-                and os.environ.get("ASB_WIDE_VARIANT", "4") == "4")
-        kname = "k_project_l2w<4, 1, 2, 3, 2, 1, 0>" if wide else {2: "k_project_lds", 3: "k_project_l2s<4, 2, 2, 1>"}.get(pk)
+        # default settings: up to four 16-column sub-panels per read of X (k_project_l2d for 4, k_project_l2w for 2 - 3);
+        # ASB_DOUBLE_PANELS=0 reads X once per 16-column panel (k_project_l2s)
+        wide = (mode == "project" and os.environ.get("ASB_DOUBLE_PANELS", "1") != "0" and os.environ.get("ASB_WIDE_VARIANT", "4") == "4")
+        kname = "k_project_l2s<4, 2, 2, 1>"
         try:
             pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
             if mode == "project" and (N, F, world) == (100000, 2000, 1) and os.environ.get("ASB_L2_VARIANT", "4") == "4":
                 if wide:        # the multi-tile launches of a step: the average launch, as `achieved` is
-                    ks = [v for k, v in pm["kernels"].items() if k.startswith("k_project_l2w<4, 1, 2, ") or k.startswith("k_project_l2c<")]
+                    ks = [v for k, v in pm["kernels"].items() if k.startswith("k_project_l2w<4, 1, 2, ") or k.startswith("k_project_l2d<")]
                     if ks:
                         traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 elif kname in pm["kernels"]:
@@ -466,11 +464,10 @@ def main():
                            ("mfma", ({"achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_MFMA_PEAK_TFLOPS} if (launches and mode == "project") else None))]),
                          traffic=traffic, traffic_source=traffic_src,
-                         kernel=(("k_project_l2c<4,3> / k_project_l2w<4,1,2,NCT,2,1> (f64-MFMA projection on 4 / NCT <= 3 sixteen-column "
+                         kernel=(("k_project_l2d<4,3,1,3> / k_project_l2w<4,1,2,NCT,2,1> (f64-MFMA projection on 4 / NCT <= 3 sixteen-column "
                                   "sub-panels, 1 launch = one read of X per up to 64 components; config 4: two launches with 4 "
                                   "sub-panels)" if wide else
-                                  {2: "k_project_lds", 3: "k_project_l2s<4,2,2,1>"}.get(pk, "k_project_mfma") +
-                                  " (f64-MFMA panel projection, %d launch(es) = one read of X per panel)" % nsweep)
+                                  "k_project_l2s<4,2,2,1> (f64-MFMA panel projection, one launch = one read of X per 16-column panel)")
                                  if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          columns_per_launch=(K * args.steps / launches * nsweep if launches else None),
                          algorithmic_flops_per_launch=flops_launch,

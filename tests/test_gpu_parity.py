@@ -1192,40 +1192,3 @@ def test_full_size_config5_properties(tmp_path):
     resid = float(torch.linalg.norm(A - P @ U) ** 2)
     tail = float((S[K:] ** 2).sum())
     assert abs(resid - tail) < 1e-6 * total and resid < 0.01 * total
-
-
-@pytest.mark.parametrize("kind,N,F,K", [("uniform", 24000, 96, 60), ("lowrank", 30000, 64, 40), ("smooth", 21000, 130, 50),
-                                        ("dupes", 26000, 48, 30), ("first", 40000, 80, 70)])
-def test_super_panels_vs_oracle(kind, N, F, K, monkeypatch):
-    """Super-panels (several sub-panels on the same candidates per read of X, band of exact energies below them;
-    ASB_SUPER_PANELS=1, shards of >= 20 000 vertices): index sequence and values == oracle on data with diffuse energies
-    (many commits per read), with a dominant shared direction (few), exact duplicates, low rank."""
-    from animsnapbases_amd import HipEngine
-    monkeypatch.setenv("ASB_SUPER_PANELS", "1")
-    rng = np.random.default_rng(N + F)
-    if kind == "lowrank":
-        X = np.tensordot(rng.normal(size=(F, 12)) * (0.75 ** np.arange(12)), rng.normal(size=(12, N, 3)), (1, 0)) \
-            + 1e-5 * rng.normal(size=(F, N, 3))
-    elif kind == "smooth":
-        t = np.linspace(0, 1, F)[:, None, None]
-        X = np.sin(2 * np.pi * (t * rng.uniform(0.5, 4, size=(1, N, 3)) + rng.uniform(size=(1, N, 3)))) * rng.uniform(0.1, 1, size=(1, N, 1))
-    else:
-        X = rng.uniform(-1, 1, size=(F, N, 3))
-    if kind == "dupes":
-        X[:, 5] = X[:, 20001]
-        X[:, 777] = X[:, 20001]
-    if kind == "first":
-        X = X - X[0:1]                       # the bench's shape: every vertex shares the -x_0 direction
-    e = HipEngine(0)
-    e.upload(X, 0, N)
-    e.deflate_begin(K, False, 1)
-    e.run_global(0, K)
-    r = e.results()
-    st = e.deflate_stats()
-    e.close()
-    ref = orc.extract_k_components(X, K)
-    sig = ref["measures"][:, 1]
-    good = int(np.argmax(sig < 1e-9 * sig[0])) if np.any(sig < 1e-9 * sig[0]) else K
-    assert r["idx"][:good].tolist() == ref["idx"][:good].tolist(), (kind, st)
-    comps, weigs = align_signs(r["comps"][:good], r["weigs"][:, :good], ref["comps"][:good])
-    assert relerr(comps, ref["comps"][:good]) < 1e-8 and relerr(weigs, ref["weigs"][:, :good]) < 1e-8, (kind, st)

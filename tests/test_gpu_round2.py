@@ -262,8 +262,9 @@ def test_reads_with_several_sub_panels_project_on_orthogonalised_weights(kind, m
 
 @pytest.mark.parametrize("kind", ["uniform", "lowrank_noise"])
 def test_reads_finished_on_the_device_match_the_step_by_step_path(kind, monkeypatch):
-    """By default the sub-panel runs and the tiles of a read are enqueued back to back and read once (ASB_SUB_CHAIN /
-    ASB_TILE_CHAIN); with both off every sub-panel run and every tile costs a host read.  Same panels, same basis --
+    """By default all sub-panels of a read run in ONE launch (k_panel_multi) and its tiles are enqueued back to back and read
+    once (ASB_TILE_CHAIN); with ASB_SUB_CHAIN=0 / ASB_TILE_CHAIN=0 every sub-panel is its own launch (same kernel, rows written
+    back in between) and every tile costs a host read.  Same panels, same basis --
     on data where every tile stands (uniform) and on data where reads are cut short by rejections (low rank + noise: the
     tile that does not stand in full is committed the slow way from untouched energies)."""
     rng = np.random.default_rng(41)

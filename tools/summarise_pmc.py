@@ -41,7 +41,7 @@ def main():
                                  fetch_size_raw_kib=fl["kib_total"] / n, write_size_raw_kib=wl["kib_total"] / n)
     path = "profiles/%s_pmc_traffic.json" % tag
     json.dump(out, open(path, "w"), indent=1)
-    for k in ("k_project_l2w<4, 1, 2, 3, 2, 1, 0>", "k_project_l2w<4, 1, 2, 2, 2, 1, 0>", "k_project_l2s<4, 2, 2, 1, 1>", "k_project_l2s<4, 2, 2, 1>", "k_project_l2<4, 2>", "k_project_lds", "k_project_mfma<8, 16>", "k_stream<256, 4, true>", "k_stream<256, 4, false>"):
+    for k in [q for q in out["kernels"] if q.startswith("k_project_l2d<")] + ["k_project_l2w<4, 1, 2, 3, 2, 1, 0>", "k_project_l2w<4, 1, 2, 2, 2, 1, 0>", "k_project_l2s<4, 2, 2, 1, 1>", "k_project_l2s<4, 2, 2, 1>", "k_project_l2<4, 2>", "k_project_lds", "k_project_mfma<8, 16>", "k_stream<256, 4, true>", "k_stream<256, 4, false>"]:
         if k in out["kernels"]:
             print(k, "%.1f MB / launch" % (out["kernels"][k]["hbm_bytes"] / 1e6))
     print("wrote", path)
