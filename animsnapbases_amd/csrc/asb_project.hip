@@ -2695,6 +2695,31 @@ static int launch_panel_multi(asb_ctx* ctx, int grid, const MultiArgs& ma, bool*
     if (per_cu < 1) { *launched = false; return ASB_OK; }
     if ((long long)per_cu * ctx->n_cu < grid) grid = per_cu * ctx->n_cu;      // the kernel refuses panels with more candidates
     unsigned long long* words = (unsigned long long*)ctx->coop_rec;
+    if (ctx->coop_launch == 1) {
+        // A COOPERATIVE launch (ASB_COOP_LAUNCH=1) makes the runtime assert what the plain launch infers from the occupancy
+        // query -- that all blocks are resident at once -- and refuse instead of running when they cannot be.  Not the default:
+        // the cooperative path serialises against every other queue of the process; where the stream (or the device)
+        // does not take it the launch falls back to the plain form, whose poll limit turns a surprise into an error, not a hang.
+        const double* a0 = ctx->candR;
+        int a1 = (int)ctx->F, a2 = (int)ctx->Fp;
+        double *a3 = ctx->W, *a4 = ctx->scal;
+        MultiArgs a5 = ma;
+        const PanelState* a6 = ctx->pstate;
+        PanelState* a7 = sub;
+        const long long* a8 = ctx->cand_idx;
+        unsigned* a9 = ctx->coop_bar;
+        unsigned long long *a10 = words, *a11 = words + (size_t)3 * grid * 2;
+        double* a12 = writeback ? ctx->candR : (double*)nullptr;
+        int a13 = ctx->coop_test_stall;
+        void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &a10, &a11, &a12, &a13};
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_panel_multi<NJ>, dim3(grid), dim3(256), args, 0, ctx->stream);
+        if (e == hipSuccess) {
+            *launched = true;
+            return ASB_OK;
+        }
+        (void)hipGetLastError();
+        ctx->coop_launch = -1;                // this context's stream / device does not take cooperative launches
+    }
     hipLaunchKernelGGL(k_panel_multi<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal,
                        ma, ctx->pstate, sub, ctx->cand_idx, ctx->coop_bar, words, words + (size_t)3 * grid * 2,
                        writeback ? ctx->candR : (double*)nullptr, ctx->coop_test_stall);

@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=18.0)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): --verts vertices in all, sharded over the ranks (config 4 is one fixed job); "
+                         "weak: --verts vertices PER RANK (the tensor grows with the GPUs)")
     args = ap.parse_args()
 
     # native libraries (RCCL prints a version banner) write to fd 1: keep the real stdout for the ONE JSON line
@@ -317,6 +320,8 @@ def main():
     from animsnapbases_amd import Comm, partition, posComponents, posSnapshots
 
     F, N, K = args.frames, args.verts, args.comps
+    if args.scaling == "weak":
+        N = args.verts * world
     comm = Comm()
     v0, n_loc = partition(N, world)[rank]
     gen = torch.Generator(device=dev)
@@ -368,6 +373,12 @@ def main():
     assert len(set(comp.selected_vertices.tolist())) == K
     assert np.isfinite(comp.measures_at_largeDeforVerts).all()
     stats = eng.deflate_stats()
+    # the co-resident panel kernel's exchange timing out (another process on the GPU, a rank that lost its CUs) is survived --
+    # all ranks repeat the panel through the two-kernel loop together and stay on it -- but it must not pass unnoticed
+    fallbacks = int(comm.allreduce_sum([float(stats.get("coop_fallbacks", 0))])[0]) if world > 1 else int(stats.get("coop_fallbacks", 0))
+    if fallbacks and rank == 0:
+        print("[bench] WARNING: the panel kernel's exchange timed out %d time(s) over the ranks: those panels were redone by the "
+              "two-kernel loop and the timed steps include it (is something else running on these GPUs?)" % fallbacks, file=sys.stderr)
     # the (K, N, 3) basis back in host memory, as the reference leaves it (rank 0's share; pageable destination)
     t0 = time.perf_counter()
     basis = comp.comps if world == 1 else eng.results(want_comps=True, want_weigs=False)["comps"]
@@ -445,7 +456,7 @@ def main():
         out = {
             "metric": "snapshots/sec (SVD+SPLOCS) for n_verts x n_frames; basis Frobenius err vs ref",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config4: synthetic U[-1,1) %d verts x %d frames, greedy-deflation PCA K=%d, "
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
@@ -471,7 +482,7 @@ def main():
                                  if mode == "project" else "k_stream<T,E2,UPDATE> (deflation pass, read+write of R)"),
                          columns_per_launch=(K * args.steps / launches * nsweep if launches else None),
                          algorithmic_flops_per_launch=flops_launch,
-                         algorithm=mode, panels_per_step=stats["panels"],
+                         algorithm=mode, panels_per_step=stats["panels"], panel_kernel_fallbacks=fallbacks,
                          refreshes=stats["refreshes"], launches=launches,
                          avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg_bytes,
                          # the whole step against the same peak: what THIS algorithm has to read (one read of X per

@@ -424,16 +424,20 @@ def test_multirank_hip_path_on_one_gpu(world, mode, support):
         assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1], outs[0][1])
 
 
-def test_eight_ranks_projection_protocol_on_one_gpu(monkeypatch):
+@pytest.mark.parametrize("coop", ["0", "1"])
+def test_eight_ranks_projection_protocol_on_one_gpu(coop, monkeypatch):
     """The panel protocol with EIGHT vertex shards (the node size the scaling bench runs): per-rank exports, the global
     threshold selection over 8 x capacity energies, the packed all-gather and its assembly.  Eight contexts share one
-    GPU here, so the co-resident panel kernel (which wants the whole GPU per context) is replaced by its two-kernel
-    form; the exchange logic is the same."""
+    GPU here: once with the panel's inner loop as the two-kernel form, once with the co-resident kernel k_panel_multi ON
+    over a reduced grid (256 candidates = 64 blocks per launch; every rank runs the identical steps on the assembled rows
+    and none of them may time out)."""
     import contextlib
     import io
     from animsnapbases_amd import HipEngine, posComponents, posSnapshots
     from thread_comm import run_ranks
-    monkeypatch.setenv("ASB_PANEL_COOP", "0")
+    monkeypatch.setenv("ASB_PANEL_COOP", coop)
+    if coop == "1":
+        monkeypatch.setenv("ASB_M_TARGET", "256")
     rng = np.random.default_rng(58)
     verts, K = rng.uniform(-1, 1, size=(72, 12011, 3)), 30
     param = _param(vertPos_numComponents=K)
@@ -451,6 +455,8 @@ def test_eight_ranks_projection_protocol_on_one_gpu(monkeypatch):
     pre = orc.prepare_snapshots(verts, "first", True)
     ref = orc.extract_k_components(pre["snapTensor"], K, "global", None, 0.1, 0.35)
     assert outs[0][3]["panels"] >= 3
+    if coop == "1":
+        assert all(o[3]["coop_fallbacks"] == 0 for o in outs)
     for idx, comps, weigs, _ in outs:
         assert idx.tolist() == ref["idx"].tolist()
         comps, weigs = align_signs(comps, weigs, ref["comps"])
