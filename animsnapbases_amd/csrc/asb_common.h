@@ -168,6 +168,7 @@ struct asb_ctx {
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
     long long* tile_res = nullptr;         // per tile: columns kept (-1: not reached); [ASB_MAX_SUB]: the chain flag
+    int spec_pass = 1;                     // ASB_SPEC_PASS=0: the read's pass is enqueued only once the host knows the sub-panels' counts
     int coop_launch = 0;                   // ASB_COOP_LAUNCH=1: hipLaunchCooperativeKernel for the panel kernel (-1: tried, refused)
     int sub_chain = 1;                     // the sub-panels of a read enqueued without host reads in between (ASB_SUB_CHAIN=0: one by one)
     int tile_chain = 1;                    // tiles of a read finished without host reads in between (ASB_TILE_CHAIN=0: one read per tile)

@@ -1536,13 +1536,21 @@ __global__ __launch_bounds__(64) void k_publish_multi(const PanelState* __restri
     if (l == 0)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(pin + 648), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-static int fetch_multi(asb_ctx* ctx, unsigned long long* out9) {
+// begin: the publication is enqueued right behind the panel kernel (*seq = 0: no polled slot, `end` copies synchronously);
+// end: wait for it.  Whatever the caller enqueues in between runs while the host waits.
+static int fetch_multi_begin(asb_ctx* ctx, unsigned long long* seq) {
     int rc = asb_pin_alloc(ctx);
     if (rc) return rc;
+    *seq = 0;
     if (ctx->host_poll && ctx->host_pin_dev) {
-        const unsigned long long seq = ++ctx->pin_seq;
-        hipLaunchKernelGGL(k_publish_multi, dim3(1), dim3(64), 0, ctx->stream, ctx->pstate2, ctx->coop_bar, ctx->host_pin_dev, seq);
+        *seq = ++ctx->pin_seq;
+        hipLaunchKernelGGL(k_publish_multi, dim3(1), dim3(64), 0, ctx->stream, ctx->pstate2, ctx->coop_bar, ctx->host_pin_dev, *seq);
         ASB_CHECK_LAUNCH(ctx);
+    }
+    return ASB_OK;
+}
+static int fetch_multi_end(asb_ctx* ctx, unsigned long long seq, unsigned long long* out9) {
+    if (seq) {
         volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->host_pin + 648);
         const auto t0 = std::chrono::steady_clock::now();
         bool arrived = false;
@@ -1555,6 +1563,7 @@ static int fetch_multi(asb_ctx* ctx, unsigned long long* out9) {
         memcpy(out9, ctx->host_pin + 512, 9 * 8);
         return ASB_OK;
     }
+    // (no polled slot: a synchronising copy -- it also waits for whatever was enqueued behind the panel kernel)
     PanelState h[8];
     unsigned fl[4];
     ASB_HIP(ctx, hipMemcpyAsync(h, ctx->pstate2, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -3142,9 +3151,18 @@ static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa) {
 // The sub-panels of a read in ONE launch (k_panel_multi): arm, kernel, one read of the summary.
 // *ntile = -1: the launch did not run to the end of its first sub-panel (exchange timed out / too many candidates): nothing
 // was committed, the caller takes the one-by-one path with its fallbacks.
-static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven) {
+static int dbl_build_tiles(asb_ctx* ctx, int ntile, const WideArgs& wa);
+static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa);
+// spec_ntile / spec_nc (optional): the read's PASS is enqueued right behind the panel kernel on the column counts the
+// sub-panels are EXPECTED to reach (their step budgets), before the host knows what they reached -- it runs while the host waits
+// for the summary instead of after it.  Safe: a sub-panel that ended early only means columns computed from rows of W nobody
+// wrote (they lie at and beyond the first column that is not committed, and a later tile exists only behind a FULL one, so no
+// committed column is ever orthogonalised against them); the caller checks the tiles on the counts really reached.
+static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven,
+                           int* spec_ntile = nullptr, int* spec_nc = nullptr) {
     int rc;
     *ntile = -1;
+    if (spec_ntile) *spec_ntile = 0;
     int cgrid_all = 0;
     size_t n_words = 0;
     if ((rc = coop_buffers(ctx, &cgrid_all, &n_words))) return rc;
@@ -3165,8 +3183,23 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
     bool launched = false;
     if ((rc = launch_panel_multi_any(ctx, cgrid_all, ma, &launched, ctx->pstate2, false))) return rc;
     if (!launched) return ASB_OK;
-    unsigned long long sum[9];
-    if ((rc = fetch_multi(ctx, sum))) return rc;
+    unsigned long long sum[9], seq = 0;
+    if ((rc = fetch_multi_begin(ctx, &seq))) return rc;
+    if (spec_ntile && seq && ctx->spec_pass && ctx->spec_budget >= ASB_PANEL_COLS && ctx->pre_orth && ctx->correct_rows) {
+        WideArgs wa{};
+        int nt = 0;
+        for (int sp = 0; sp < n; ++sp) {
+            wa.kb[nt] = ma.kb[sp];
+            wa.nc[nt] = ma.steps[sp];
+            spec_nc[nt] = ma.steps[sp];
+            ++nt;
+            if (ma.steps[sp] < ASB_PANEL_COLS) break;
+        }
+        if ((rc = dbl_build_tiles(ctx, nt, wa))) return rc;
+        if ((rc = launch_wide(ctx, nt, wa))) return rc;
+        *spec_ntile = nt;
+    }
+    if ((rc = fetch_multi_end(ctx, seq, sum))) return rc;
     ctx->n_panels++;
     ctx->run_coop_used = 1;
     if (getenv("ASB_DEBUG_PANELS")) print_multi_timeline(ctx, (int)(sum[0] & 0xffffffffu) + 16 * (n - 1));
@@ -3208,11 +3241,11 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     long long kb[ASB_MAX_SUB];
     int nc[ASB_MAX_SUB] = {0}, proven[ASB_MAX_SUB] = {0};
     for (int sp = 0; sp < ASB_MAX_SUB; ++sp) kb[sp] = k + (long long)sp * ASB_PANEL_COLS;
-    int ntile = 0;
+    int ntile = 0, spec_ntile = 0, spec_nc[ASB_MAX_SUB] = {0};
     bool chained_runs = false;
     if (ctx->sub_chain && ctx->panel_coop && ctx->spec_panels && ctx->Fp <= 2048 && nsub_max > 1) {
         int nt = -1;
-        if ((rc = multi_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven))) return rc;
+        if ((rc = multi_chain_run(ctx, k, k1, nsub_max, &nt, nc, proven, &spec_ntile, spec_nc))) return rc;
         if (nt == 0) return ASB_OK;                      // nothing committed: the caller's refresh / forced path
         if (nt > 0) { ntile = nt; chained_runs = true; }
     }
@@ -3251,8 +3284,13 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         wa.kb[ct] = kb[ct];
         wa.nc[ct] = nc[ct];
     }
-    if ((rc = dbl_build_tiles(ctx, ntile, wa))) return rc;
-    if ((rc = launch_wide(ctx, ntile, wa))) return rc;
+    // (the pass may already be running: enqueued behind the panel kernel on the expected counts, which cover the reached ones)
+    bool covered = chained_runs && spec_ntile >= ntile;
+    for (int ct = 0; covered && ct < ntile; ++ct) covered = spec_nc[ct] >= nc[ct];
+    if (!covered) {
+        if ((rc = dbl_build_tiles(ctx, ntile, wa))) return rc;
+        if ((rc = launch_wide(ctx, ntile, wa))) return rc;
+    }
     int64_t total = 0;
     int full = 0;
     bool rejected = false;
@@ -3263,7 +3301,9 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
         long long cwr = (ctx->n_loc + 63) / 64;
         // (two blocks per CU, grid-strided: the one-block k_tile_decide sums a partial per block and column)
-        const int rgrid = (int)(cwr < 2 * ctx->n_cu ? cwr : 2 * ctx->n_cu);
+        static const int bpc = getenv("ASB_CHECK_BLOCKS_PER_CU") ? atoi(getenv("ASB_CHECK_BLOCKS_PER_CU")) : 2;
+        const long long rcap = (long long)(bpc < 1 ? 1 : (bpc > 8 ? 8 : bpc)) * ctx->n_cu;
+        const int rgrid = (int)(cwr < rcap ? cwr : rcap);
         long long cw = (ctx->n_loc + 255) / 256;
         const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
         for (int ct = 0; ct < ntile; ++ct) {
