@@ -168,6 +168,7 @@ struct asb_ctx {
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
     long long* tile_res = nullptr;         // per tile: columns kept (-1: not reached); [ASB_MAX_SUB]: the chain flag
+    int spec_w_rank = 24;                  // ASB_SPEC_W_RANK: blocks ranked below it publish their w ahead of the exchange (0: none)
     int spec_pass = 1;                     // ASB_SPEC_PASS=0: the read's pass is enqueued only once the host knows the sub-panels' counts
     int coop_launch = 0;                   // ASB_COOP_LAUNCH=1: hipLaunchCooperativeKernel for the panel kernel (-1: tried, refused)
     int sub_chain = 1;                     // the sub-panels of a read enqueued without host reads in between (ASB_SUB_CHAIN=0: one by one)
@@ -389,6 +390,17 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
     v = min((int)s[0], (int)s[1]);
     s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
     return min((int)s[0], (int)s[1]);
+}
+
+__device__ __forceinline__ int wave_isum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    auto s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)s[0] + (int)s[1];
+    s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)s[0] + (int)s[1];
 }
 
 // Block-wide sum of NV values per thread; result valid in every thread.

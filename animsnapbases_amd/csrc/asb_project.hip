@@ -2433,14 +2433,15 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                                                         double* __restrict__ W, double* __restrict__ scal, MultiArgs ma,
                                                         const PanelState* panel, PanelState* sub,
                                                         const long long* __restrict__ cand_idx, unsigned* __restrict__ bar,
-                                                        unsigned long long* rec, unsigned long long* wbuf, double* rows_out,
-                                                        int test_stall) {
+                                                        unsigned long long* rec, unsigned long long* wbuf, unsigned long long* swbuf,
+                                                        double* rows_out, int test_stall, int spec_rank) {
     constexpr int NQ = NJ / 4;                                   // weight words per thread
-    __shared__ double w_sh[NJ * 64 + 8];                         // [NJ * 64] = |w|^2, [NJ * 64 + 1] = lambda
+    __shared__ __attribute__((aligned(16))) double w_sh[NJ * 64 + 8];      // [NJ * 64] = |w|^2, [NJ * 64 + 1] = lambda
     __shared__ double wv_e[4];
     __shared__ long long wv_i[4];
     __shared__ double sh_e[4];
     __shared__ int sh_i[4];
+    __shared__ int sh_c[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = gridDim.x;
     const long long n_cand = panel->n_cand;
@@ -2466,6 +2467,15 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                 x[d][j] = (have && f < Fp) ? row[(long long)d * Fp + f] : 0.0;
             }
     }
+    if (spec_rank > 0) {
+        // this block's three speculative buffers start out as "not written": nobody is directed to them before a record of
+        // THIS launch says so, and the block's first record goes out behind the drain of these stores (top of step 0)
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) {
+            unsigned long long* sown = swbuf + ((size_t)r3 * G + blockIdx.x) * WROW;
+            for (int f = tid; f < WROW; f += 256) coop_store_u64(sown + f, ASB_SENT_D);
+        }
+    }
     double g[6] = {0, 0, 0, 0, 0, 0};                            // Gram matrix of the wave's row (00 01 02 11 12 22), every lane
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -2477,6 +2487,11 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
     const long long spin_max = test_stall ? (1LL << 10) : (1LL << 20);
     int gstep = 0;
     bool aborted = false, ended = false;
+    // SPECULATIVE publication of w: a block whose best candidate ranked among the first `spec_rank` of the LAST step's records
+    // stores its w (to its own buffer, straight from the wave that computed it) while the records still travel; if it wins,
+    // the others find w already in memory when they know the winner -- the second exchange overlaps the first.  The record
+    // says whether w was published that way (bit 32 of the slot word); a winner that did not publishes behind the poll as before.
+    bool spec_now = false, spec_prev = false;
     int sp = 0;
     for (; sp < ma.nsub && !ended; ++sp) {
         const long long k0 = ma.kb[sp];
@@ -2497,14 +2512,15 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                 if (am_better(wv_e[q], wv_i[q], wv_e[ow], wv_i[ow])) ow = q;
             unsigned long long* myrec = rec + ((size_t)ring * G + blockIdx.x) * 2;
             if (tid == 0 && !(test_stall && (int)blockIdx.x == Gact - 1)) {      // (tests: the last block never signals)
+                const unsigned long long slot32 = wv_i[ow] > 0x7ffffffeLL ? 0x7fffffffull : (unsigned long long)wv_i[ow];
                 coop_store(reinterpret_cast<double*>(myrec), wv_e[ow]);
-                coop_store_u64(myrec + 1, (unsigned long long)wv_i[ow]);
+                coop_store_u64(myrec + 1, slot32 | (spec_now && wv_e[ow] > 0.0 ? (1ull << 32) : 0ull));
             }
             if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 1] = wall_clock64();
             // ---- 2. the best wave solves its 3 x 3 eigen-problem while the other three poll the records
             double lam = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
             double be = -2.0;                            // (records carry -1 at the least)
-            int bi = 0x7fffffff, dead = 0;               // slots fit 31 bits (4 G <= 4096)
+            int bi = 0x7fffffff, dead = 0, better = 0;   // slots fit 30 bits (4 G <= 4096); better: records that outrank this block's
             if (wv == ow) {
                 // the eigen-pair AND w = u^T row of the block's best candidate, into LDS, while the records travel: should
                 // the block win, its w only has to be stored (w_sh is free here: the last reads of it -- the deflation of
@@ -2520,6 +2536,24 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                     }
                     wave_sum_dpp<1>(wn1);
                     if (lane == 0) { w_sh[NJ * 64] = wn1[0]; w_sh[NJ * 64 + 1] = lam; }
+                    if (spec_now) {
+                        // 16-byte write-through stores of frame pairs (the wave's own LDS writes are in order for it)
+                        double* sw = reinterpret_cast<double*>(swbuf) + ((size_t)ring * G + blockIdx.x) * WROW;
+#pragma unroll
+                        for (int q = 0; q < NJ / 2; ++q) {
+                            const int f2 = 2 * lane + 128 * q;
+                            if (f2 < Fp) {
+                                typedef double d2v __attribute__((ext_vector_type(2)));
+                                const d2v v = *reinterpret_cast<const d2v*>(&w_sh[f2]);
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(sw + f2), "v"(v) : "memory");
+                            }
+                        }
+                        if (lane == 0) {
+                            typedef double d2v __attribute__((ext_vector_type(2)));
+                            const d2v hd2 = {wn1[0], lam};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(sw + Fp), "v"(hd2) : "memory");
+                        }
+                    }
                 }
             } else {
                 const unsigned long long* recs = rec + (size_t)ring * G * 2;
@@ -2537,21 +2571,30 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                     }
                     if (dead) break;
                     const double ebd = __longlong_as_double((long long)eb);
-                    const int ibs = ib > 0x7ffffffeull ? 0x7fffffff : (int)ib;
+                    // key = 2 slot + (1 - published): the lowest slot wins a tie, the flag rides below it
+                    const int sl = (int)(ib & 0x7fffffffull);
+                    const int ibs = sl == 0x7fffffff ? 0x7fffffff : 2 * sl + ((ib >> 32) & 1ull ? 0 : 1);
                     if (ebd > be || (ebd == be && ibs < bi)) { be = ebd; bi = ibs; }
+                    if (ebd > wv_e[ow] || (ebd == wv_e[ow] && (long long)sl < wv_i[ow])) ++better;
                 }
                 // arg-max over the wave: largest energy, then lowest slot among the lanes that hold it (NumPy's first max)
                 const double em = wave_max_dpp(be);
                 bi = wave_min_dpp(be == em ? bi : 0x7fffffff);
                 be = em;
+                better = wave_isum_dpp(better);
             }
-            if (lane == 0) { sh_e[wv] = be; sh_i[wv] = bi; }
+            if (lane == 0) { sh_e[wv] = be; sh_i[wv] = bi; sh_c[wv] = better; }
             if (__syncthreads_or(dead)) { aborted = true; break; }
             be = sh_e[0]; bi = sh_i[0];
 #pragma unroll
             for (int q = 1; q < 4; ++q)
                 if (sh_e[q] > be || (sh_e[q] == be && sh_i[q] < bi)) { be = sh_e[q]; bi = sh_i[q]; }
-            const int bb = bi >> 2;                      // the winner's block (slot = 4 block + wave)
+            const bool win_spec = bi != 0x7fffffff && (bi & 1) == 0;       // the winner's w is (being) published already
+            if (bi != 0x7fffffff) bi >>= 1;              // the winner's slot
+            const int bb = bi >> 2;                      // its block (slot = 4 block + wave)
+            const bool spec_mine = spec_now && wv_e[ow] > 0.0;             // this block published at this step
+            // who publishes ahead at the NEXT step: the blocks whose record ranked among the first spec_rank now
+            spec_now = spec_rank > 0 && wv_e[ow] > 0.0 && (sh_c[0] + sh_c[1] + sh_c[2] + sh_c[3]) < spec_rank;
             if (blockIdx.x == 0 && tid == 0) tlog[gstep * 6 + 2] = wall_clock64();
             // every block is past step gstep - 1: its words can be reset (see the header)
             if (tid == 0) {
@@ -2559,6 +2602,16 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
                 coop_store_u64(old, ASB_SENT_D);
                 coop_store_u64(old + 1, (unsigned long long)ASB_SENT_I);
             }
+            if (spec_prev) {                             // this block's own speculative buffer of step gstep - 1
+                unsigned long long* sold = swbuf + ((size_t)ring_prev * G + blockIdx.x) * WROW;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int f = tid + 256 * q;
+                    if (f < Fp) coop_store_u64(sold + f, ASB_SENT_D);
+                }
+                if (tid < 2) coop_store_u64(sold + Fp + tid, ASB_SENT_D);
+            }
+            spec_prev = spec_mine;
             {   // the weight buffer of step gstep - 1: every block resets its slice (same argument block by block: a block's
                 // reset is visible before its next record, and whoever writes or reads the buffer again has seen ALL records)
                 unsigned long long* wold = wbuf + (size_t)ring_prev * WROW;
@@ -2577,9 +2630,11 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
             }
             nrun = t + 1;
             // ---- 3. the winner's w: its block writes it (LDS -> write-through stores by all four waves), the others spin on it
-            unsigned long long* wb = wbuf + (size_t)ring * WROW;
+            unsigned long long* wb = win_spec ? swbuf + ((size_t)ring * G + bb) * WROW : wbuf + (size_t)ring * WROW;
             dead = 0;
-            if (bb == (int)blockIdx.x) {             // (w_sh holds this block's w since the barrier behind the poll)
+            if (bb == (int)blockIdx.x && win_spec) {
+                // (w_sh holds this block's w since the barrier behind the poll, and its best wave has stored it already)
+            } else if (bb == (int)blockIdx.x) {      // (w_sh holds this block's w since the barrier behind the poll)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int f = tid + 256 * q;
@@ -2691,7 +2746,8 @@ __global__ __launch_bounds__(256, (NJ > 16 ? 1 : 2)) void k_panel_multi(const do
 static int coop_buffers(asb_ctx* ctx, int* cgrid_all, size_t* n_words) {
     int rc;
     *cgrid_all = (int)((ctx->m_cap + 3) / 4);
-    *n_words = (size_t)3 * *cgrid_all * 2 + (size_t)3 * (ctx->Fp + 8);
+    // records (3 rings x blocks x 2), the winner's weight buffers (3 x (Fp + 8)), the speculative ones (3 x blocks x (Fp + 8))
+    *n_words = (size_t)3 * *cgrid_all * 2 + (size_t)3 * (ctx->Fp + 8) + (size_t)3 * *cgrid_all * (ctx->Fp + 8);
     if ((rc = asb_alloc(ctx, &ctx->coop_bar, (size_t)4 + 2 * 64 * 6))) return rc;
     return asb_alloc(ctx, &ctx->coop_rec, *n_words);
 }
@@ -2717,10 +2773,10 @@ static int launch_panel_multi(asb_ctx* ctx, int grid, const MultiArgs& ma, bool*
         PanelState* a7 = sub;
         const long long* a8 = ctx->cand_idx;
         unsigned* a9 = ctx->coop_bar;
-        unsigned long long *a10 = words, *a11 = words + (size_t)3 * grid * 2;
+        unsigned long long *a10 = words, *a11 = words + (size_t)3 * grid * 2, *a11b = a11 + (size_t)3 * (ctx->Fp + 8);
         double* a12 = writeback ? ctx->candR : (double*)nullptr;
-        int a13 = ctx->coop_test_stall;
-        void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &a10, &a11, &a12, &a13};
+        int a13 = ctx->coop_test_stall, a14 = ctx->spec_w_rank;
+        void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &a10, &a11, &a11b, &a12, &a13, &a14};
         const hipError_t e = hipLaunchCooperativeKernel((const void*)k_panel_multi<NJ>, dim3(grid), dim3(256), args, 0, ctx->stream);
         if (e == hipSuccess) {
             *launched = true;
@@ -2731,7 +2787,8 @@ static int launch_panel_multi(asb_ctx* ctx, int grid, const MultiArgs& ma, bool*
     }
     hipLaunchKernelGGL(k_panel_multi<NJ>, dim3(grid), dim3(256), 0, ctx->stream, ctx->candR, (int)ctx->F, (int)ctx->Fp, ctx->W, ctx->scal,
                        ma, ctx->pstate, sub, ctx->cand_idx, ctx->coop_bar, words, words + (size_t)3 * grid * 2,
-                       writeback ? ctx->candR : (double*)nullptr, ctx->coop_test_stall);
+                       words + (size_t)3 * grid * 2 + (size_t)3 * (ctx->Fp + 8), writeback ? ctx->candR : (double*)nullptr,
+                       ctx->coop_test_stall, ctx->spec_w_rank);
     ASB_CHECK_LAUNCH(ctx);
     *launched = true;
     return ASB_OK;
@@ -2769,7 +2826,8 @@ extern "C" int asb_panel_run(asb_ctx* ctx, int64_t k0, int steps, int global_all
     const long long spec_max = want_coop && !global_all ? ctx->run_spec_max : 0;
     hipLaunchKernelGGL(k_panel_arm, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->scalar_dev, global_all,
                        (long long)(assembled ? ctx->n_slots_host : -1), ASB_MARGIN_REL, want_coop ? ctx->coop_bar : (unsigned*)nullptr,
-                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr, (int)n_words,
+                       want_coop ? (unsigned long long*)ctx->coop_rec : (unsigned long long*)nullptr,
+                       want_coop ? 3 * cgrid_all * 2 + 3 * ((int)ctx->Fp + 8) : 0,
                        ctx->run_theta_band, spec_max);
     const int grid = stream_grid(ctx, c, ctx->m_cap);
     bool coop = false;
@@ -3178,8 +3236,11 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
         ++n;
     }
     ma.nsub = n;
+    // records and the winner's weight buffers start out as "not written" (all bits set: filled by the arm kernel); the
+    // speculative buffers are reset by their owners at the start of the panel kernel
+    const int n_small = 3 * cgrid_all * 2 + 3 * ((int)ctx->Fp + 8);
     hipLaunchKernelGGL(k_panel_arm_multi, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->pstate2, ctx->scalar_dev, ASB_MARGIN_REL,
-                       ctx->coop_bar, (unsigned long long*)ctx->coop_rec, (int)n_words, ma);
+                       ctx->coop_bar, (unsigned long long*)ctx->coop_rec, n_small, ma);
     bool launched = false;
     if ((rc = launch_panel_multi_any(ctx, cgrid_all, ma, &launched, ctx->pstate2, false))) return rc;
     if (!launched) return ASB_OK;
