@@ -87,6 +87,9 @@ struct asb_ctx {
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_event = nullptr;
     long long dl_done = 0;
+    double* res_pin = nullptr;        // pinned host slot of a run's small results (asb_project_results): [seq, -, (K+1) x 4 scalars, 8 range scalars]
+    double* res_pin_dev = nullptr;
+    size_t res_pin_count = 0;
     double* td_wy = nullptr;          // blocked back-transformation: T factors, reflector panels, work
     // the sparse differential operator S^T of the constraint path (asb_st_upload: CSR on the device) and its work arrays
     long long* st_indptr = nullptr;

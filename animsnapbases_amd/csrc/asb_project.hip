@@ -1847,6 +1847,25 @@ int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0
     return ASB_OK;
 }
 
+// start of a run on a tensor whose initial energies are known (E0): scal <- 0, hist <- 0, energy <- E0, range scalars restored --
+// one launch instead of two memsets, a device-to-device copy and a one-thread kernel (each an API call with its own host cost)
+__global__ __launch_bounds__(256) void k_begin_reset(double* __restrict__ scal, long long n_scal, int* __restrict__ hist, int n_hist,
+                                                     double* __restrict__ energy, const double* __restrict__ E0, long long n,
+                                                     double* __restrict__ sc, const double* __restrict__ e0) {
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, st = (long long)gridDim.x * 256;
+    for (long long i = i0; i < n_scal; i += st) scal[i] = 0.0;
+    for (long long i = i0; i < n_hist; i += st) hist[i] = 0;
+    for (long long i = i0; i < n; i += st) energy[i] = E0[i];
+    if (i0 == 0) {                       // (k_range_restore)
+        sc[SC_EMAX] = e0[1];
+        sc[SC_LO] = 0.0;
+        sc[SC_HI] = e0[1];
+        sc[SC_ABOVE] = 0.0;
+        sc[SC_NORMX2] = e0[0];
+        sc[SC_E0MAX] = e0[1];
+    }
+}
+
 int asb_project_begin(asb_ctx* ctx, int64_t K) {
     const size_t rows = (size_t)ctx->n_loc * 3;
     int rc;
@@ -1870,13 +1889,11 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if ((rc = asb_alloc(ctx, &ctx->cpsum, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->colpart, (size_t)ctx->nblk_cap * 16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
-    ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
     if ((rc = asb_alloc(ctx, &ctx->pstate, (size_t)1))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->gram, (size_t)K * ASB_PANEL_COLS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->gram_s, (size_t)K * ASB_PANEL_COLS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ctmp, (size_t)ASB_CBLOCKS * ctx->m_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->ccnt, (size_t)ASB_CBLOCKS))) return rc;
-    ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
     StreamCfg c;
     if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
     // the adaptive panel lengths start afresh: the same tensor gives the same panels, hence the same bits, on every call
@@ -1885,14 +1902,18 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if (ctx->e0_valid && ctx->E0 && ctx->e0_reuse) {
         // the energies of the prepared tensor came with the sweep that wrote it (asb_snapshots_scale) or with an earlier
         // begin on the same tensor: X has not changed since, so nothing is read again
-        ASB_HIP(ctx, hipMemcpyAsync(ctx->energy, ctx->E0, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_range_restore, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, ctx->e0_sc);
+        const long long nmax = ctx->n_loc > (K + 1) * 4 ? ctx->n_loc : (K + 1) * 4;
+        hipLaunchKernelGGL(k_begin_reset, dim3((unsigned)((nmax + 255) / 256 < 2048 ? (nmax + 255) / 256 : 2048)), dim3(256), 0, ctx->stream,
+                           ctx->scal, (long long)(K + 1) * 4, ctx->hist, (int)ASB_NBINS, ctx->energy, ctx->E0, (long long)ctx->n_loc,
+                           ctx->scalar_dev, ctx->e0_sc);
         ASB_CHECK_LAUNCH(ctx);
         ctx->nblk = 0;                 // no partial records yet: every consumer of them runs after a refresh
         ctx->n_energy_pass = 0;
         return ASB_OK;
     }
     // initial energies straight from X (read-only pass)
+    ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(ctx->scal, 0, (size_t)(K + 1) * 4 * sizeof(double), ctx->stream));
     const int grid = stream_grid(ctx, c, ctx->n_loc);
     StreamArgs a{ctx->X, nullptr, nullptr, nullptr, nullptr, ctx->energy, ctx->pmax, ctx->pidx, ctx->psum,
                  (long long)ctx->n_loc, nullptr};
@@ -3694,12 +3715,53 @@ __global__ __launch_bounds__(256) void k_weights_fk(const double* __restrict__ W
         out[e] = W[(e % K) * Fp + e / K];
 }
 
+// the (K + 1) x 4 scalars of a run and the range scalars into a pinned host buffer of the context, its sequence word last
+__global__ __launch_bounds__(256) void k_publish_results(const double* __restrict__ scal, long long n_scal, const double* __restrict__ sc,
+                                                         double* __restrict__ pin, unsigned long long seq) {
+    for (long long i = threadIdx.x; i < n_scal; i += 256) pin[2 + i] = scal[i];
+    if (threadIdx.x < 8) pin[2 + n_scal + threadIdx.x] = sc[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(pin), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx, double* sigma, double* normR2_local) {
     const int64_t K = ctx->K;
-    std::vector<double> h((size_t)(K + 1) * 4);
+    const size_t n_scal = (size_t)(K + 1) * 4;
+    std::vector<double> h(n_scal);
     double sc[8];
-    ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ASB_HIP(ctx, hipMemcpyAsync(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+    // one-thread-per-word kernel into mapped pinned memory + a polled sequence word: no copy call (each blocks the host for its
+    // own round trip when the destination is pageable) -- the weights below are the only copy of a run's results
+    bool published = false;
+    unsigned long long seq = 0;
+    if (ctx->host_poll) {
+        if (ctx->res_pin_count < n_scal + 16) {
+            if (ctx->res_pin) (void)hipHostFree(ctx->res_pin);
+            ctx->res_pin = nullptr;
+            ctx->res_pin_dev = nullptr;
+            if (hipHostMalloc((void**)&ctx->res_pin, (n_scal + 16) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+                ctx->res_pin_count = n_scal + 16;
+                ctx->res_pin[0] = 0.0;
+                if (hipHostGetDevicePointer((void**)&ctx->res_pin_dev, ctx->res_pin, 0) != hipSuccess) ctx->res_pin_dev = nullptr;
+            } else {
+                (void)hipGetLastError();
+                ctx->res_pin = nullptr;
+                ctx->res_pin_count = 0;
+            }
+        }
+        if (ctx->res_pin_dev) {
+            seq = ++ctx->pin_seq;
+            hipLaunchKernelGGL(k_publish_results, dim3(1), dim3(256), 0, ctx->stream, ctx->scal, (long long)n_scal, ctx->scalar_dev,
+                               ctx->res_pin_dev, seq);
+            ASB_CHECK_LAUNCH(ctx);
+            published = true;
+        }
+    }
+    if (!published) {
+        ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(sc, ctx->scalar_dev, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (comps)
         ASB_HIP(ctx, hipMemcpyAsync(comps, ctx->comps, (size_t)K * 3 * ctx->n_loc * sizeof(double), hipMemcpyDeviceToHost,
                                     ctx->stream));
@@ -3712,7 +3774,21 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
         ASB_CHECK_LAUNCH(ctx);
         ASB_HIP(ctx, hipMemcpyAsync(weigs, ctx->w_fk, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (published) {
+        volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(ctx->res_pin);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (*word == seq) { arrived = true; break; }
+            if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 4.0) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!arrived || comps || weigs) ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (the copies above; a fault shows here)
+        memcpy(h.data(), ctx->res_pin + 2, n_scal * sizeof(double));
+        memcpy(sc, ctx->res_pin + 2 + n_scal, sizeof(sc));
+    } else {
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     double r2 = sc[SC_NORMX2];
     for (int64_t k = 0; k < K; ++k) {
         if (sigma) sigma[k] = h[k * 4 + 0];

@@ -320,6 +320,7 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
     asb_splocs_free(ctx);
     asb_geo_free(ctx);
     if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
+    if (ctx->res_pin) (void)hipHostFree(ctx->res_pin);
     if (ctx->dl_stream) { (void)hipStreamSynchronize(ctx->dl_stream); (void)hipStreamDestroy(ctx->dl_stream); }
     if (ctx->dl_event) (void)hipEventDestroy(ctx->dl_event);
     if (ctx->dl_host) (void)hipHostFree(ctx->dl_host);
