@@ -1170,9 +1170,15 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
                                          const double* __restrict__ wn2, const WideArgs& wa, double* __restrict__ comps,
                                          long long comp_stride, long long group0, double* lds, unsigned cnt_byte) {
     constexpr int RT = 4, NTM = 4, NI = 4 * P * NCT, PER = NI / (2 * RT), NS = NSB;
-    constexpr bool CNT = (SYNC & 1) != 0, BAR = SYNC != 1;
-    constexpr int DIST = CNT ? NS - 2 : 1;                      // the direct loads run DIST stages ahead of the MFMAs
-    static_assert(!CNT || NS >= 3, "counters need a third buffer");
+    // SYNC: 0 = block barrier per stage (two buffers); 1 = arrival counters over all 8 waves; 5 = arrival counters PER FRAME-HALF
+    // GROUP of four waves (each group stages the chunks only it reads: a slow wave holds up three others, not seven);
+    // 2 / 3 = debugging forms (barrier with three buffers / counters and barrier)
+    constexpr bool CNT = (SYNC & 1) != 0, BAR = SYNC == 0 || SYNC == 2 || SYNC == 3, GRP = SYNC == 5;
+    constexpr int DIST = CNT ? (NS - 1) / 2 : 1;                // the direct loads run DIST stages ahead of the MFMAs
+    // a wave inside stage s knows only that every wave has ARRIVED for s, which a wave does while it computes stage s - DIST: the
+    // buffer the loads of stage s + DIST overwrite must belong to stage s - DIST - 1 or older (round 3 measured "four buffers,
+    // two stages ahead" at 1.37-1.39 ms -- and one rejected tile in twenty steps: it overwrote a stage still being read)
+    static_assert(!CNT || NS >= 2 * DIST + 1, "counters: the stage being overwritten must have been left by every wave");
     constexpr int STAGE_D = NI * 128;                           // doubles per stage
     constexpr int NTA = NTV > 0 ? NTV : 1;                      // (array bounds of a wave without rows)
     typedef double (*red_t)[NTM][4][64];
@@ -1183,11 +1189,14 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
     auto issue_stage = [&](int s) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int q = w * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
-            const int c = 2 * s * P + cc;
+            // all 8 waves share a stage (instruction q of NI: chunk cc of the stage's 2 P, column tile, half), or each group of
+            // four stages its own P chunks (instruction q of NI / 2 behind the group's base)
+            const int q = (GRP ? rt : w) * PER + u, h = q & 1, ct = (q >> 1) % NCT, cc = (q >> 1) / NCT;
+            const int c = GRP ? 2 * (s * P + cc) + sub : 2 * s * P + cc;
             if (c < nchunk) {
                 const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
-                const unsigned lds_byte = __builtin_amdgcn_readfirstlane((unsigned)(((s % NS) * STAGE_D + q * 128) * 8));
+                const unsigned lds_byte = __builtin_amdgcn_readfirstlane(
+                    (unsigned)((GRP ? ((s % NS) * 2 + sub) * (STAGE_D / 2) + q * 128 : (s % NS) * STAGE_D + q * 128) * 8));
                 unsigned m0_keep;                                // m0 is the compiler's: put back what it held
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(m0_keep) : "v"(src), "s"(lds_byte) : "memory");
@@ -1196,14 +1205,14 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
     };
     // arrival for stage s: this wave's direct loads of it have landed (callers: behind a wait that covers them)
     auto arrive = [&](int s) {
-        const unsigned addr = cnt_byte + 4u * (unsigned)(s % NS);      // LDS byte address (the dynamic LDS starts at 0, as for the stages)
-        const unsigned one = 1u;                                       // (every lane adds: 64 per wave, 512 per stage)
+        const unsigned addr = cnt_byte + 4u * (unsigned)(GRP ? (s % NS) * 2 + sub : s % NS);      // LDS byte address (the dynamic LDS starts at 0)
+        const unsigned one = 1u;                                       // (every lane adds: 64 per wave, 512 / 256 per stage)
         asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory");
     };
     // entry into stage s: all 8 waves have arrived for it (the buffer's (s / NS + 1)-th use in this tile)
     auto enter = [&](int s) {
-        const unsigned addr = cnt_byte + 4u * (unsigned)(s % NS);
-        const unsigned want = 512u * (unsigned)(s / NS + 1);       // (ds_add_u32 is per lane: a wave adds 64)
+        const unsigned addr = cnt_byte + 4u * (unsigned)(GRP ? (s % NS) * 2 + sub : s % NS);
+        const unsigned want = (GRP ? 256u : 512u) * (unsigned)(s / NS + 1);       // (ds_add_u32 is per lane: a wave adds 64)
         unsigned got, sg;
         asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_lt_u32 %1, %3\n\ts_cbranch_scc1 1b"
                      : "=&v"(got), "=&s"(sg) : "v"(addr), "s"(want) : "memory", "scc");
@@ -1283,7 +1292,9 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
                     b0 = make_double2(cur[0].x, cur[0].y);
                     b1 = make_double2(cur[0].z, cur[0].w);
                 } else {
-                    const unsigned lds_addr = (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
+                    const unsigned lds_addr = GRP
+                        ? (unsigned)((((s % NS) * 2 + sub) * (STAGE_D / 2) + (((j - s * P) * NCT + ct) * 2) * 128 + l * 2) * 8)
+                        : (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));
                 }
@@ -1345,7 +1356,7 @@ __global__ __launch_bounds__(512, 2) void k_project_l2d(
     constexpr int BODY_D = NS * STAGE_D > RED_D ? NS * STAGE_D : RED_D;
     static_assert(NI % 8 == 0, "stage instructions must divide over the 8 waves");
     static_assert(P >= 2, "a stage must hold at least two chunk pairs (arrival / completion of the direct loads)");
-    static_assert((BODY_D + 2) * 8 <= 160 * 1024, "the stages must fit the LDS of a CU (gfx950: 160 KB)");
+    static_assert((BODY_D + 4) * 8 <= 160 * 1024, "the stages must fit the LDS of a CU (gfx950: 160 KB)");
     extern __shared__ double l2d_lds[];
     unsigned* cnt = reinterpret_cast<unsigned*>(l2d_lds + BODY_D);          // NS arrival counters
     const int tid = threadIdx.x, rt = (tid >> 6) & 3;
@@ -1358,7 +1369,7 @@ __global__ __launch_bounds__(512, 2) void k_project_l2d(
         const int ntv = bs + (rt < ex ? 1 : 0);
         const long long start = gr + rt * bs + (rt < ex ? rt : ex);
         __syncthreads();                                                    // the last round's reads of `red` are done
-        if (tid < NS) cnt[tid] = 0u;
+        if (tid < 2 * NS) cnt[tid] = 0u;
         __syncthreads();
         switch (ntv) {
             case 4: l2d_tile<NCT, P, 4, SYNC, NSB, MODE, XD>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, start, l2d_lds, CNT_BYTE); break;
@@ -1676,7 +1687,7 @@ template <int NCT, int P, int SYNC, int NSB = (SYNC ? 3 : 2), int XD = 1>
 static int launch_l2d(asb_ctx* ctx, const WideArgs& wa) {
     const long long rows = 3 * ctx->n_loc, ngroups = (rows + 15) / 16;
     const size_t stage = (size_t)NSB * 4 * P * NCT * 128, redd = (size_t)4 * 4 * 4 * 64;
-    const size_t lds = ((stage > redd ? stage : redd) + 2) * sizeof(double);
+    const size_t lds = ((stage > redd ? stage : redd) + 4) * sizeof(double);
     static bool attr_set_dev[64] = {false};
     bool& attr_set = attr_set_dev[ctx->dev & 63];
     if (!attr_set) {
@@ -1693,7 +1704,7 @@ template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
     if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage (two buffers)
     if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
-    if (variant == 48 && NCT == 4) return launch_l2d<4, 2, 1, 4>(ctx, wa);   // 32-KB stages, four buffers: direct loads two stages ahead
+    if (variant == 51 && NCT == 4) return launch_l2d<4, 3, 5, 3>(ctx, wa);   // arrival counters per frame-half group of four waves (no gain: 1.43)
     // (round 2's variants -- one wave per tile, 32- / 48- / 96- / 128-row tiles, deeper prefetch, weights shared through LDS with a
     // barrier per chunk pair (k_project_l2b) or per stage from a tile queue (k_project_l2c) -- were measured and removed; their
     // numbers are in DESIGN.md section 5 and profiles/r02*)
@@ -1782,7 +1793,7 @@ extern "C" int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, dou
             const long long rows = 3 * ctx->n_loc;
 #define ASB_L2D_PROBE(M)                                                                                                        \
             {                                                                                                                   \
-                const size_t lds3 = ((size_t)3 * 4 * 3 * 4 * 128 + 2) * sizeof(double);                                         \
+                const size_t lds3 = ((size_t)3 * 4 * 3 * 4 * 128 + 4) * sizeof(double);                                         \
                 const long long ngr = (rows + 15) / 16;                                                                         \
                 ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2d<4, 3, 1, 3, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
                 hipLaunchKernelGGL((k_project_l2d<4, 3, 1, 3, M>), dim3((unsigned)(ngr < ctx->n_cu ? ngr : ctx->n_cu)), dim3(512), lds3, ctx->stream, \
