@@ -92,6 +92,7 @@ PROTOTYPES = {
     "asb_panel_set_coop": (c_int, [ctypes.c_void_p, c_int]),
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
+    "asb_deflate_sketch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_panel_guess_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(c_int)]),
     "asb_panel_guess_begin": (c_int, [ctypes.c_void_p, c_int]),
@@ -139,6 +140,8 @@ PROTOTYPES = {
                                      ctypes.POINTER(c_dbl)]),
     "asb_splocs_results": (c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "asb_test_eig3": (None, [c_dp, c_dp]),
+    "asb_test_sketch_predict": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_i64, c_int, c_int, c_dp, ctypes.POINTER(c_i64),
+                                        ctypes.POINTER(c_int)]),
     "asb_test_spd_inverse": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_dp]),
 }
 

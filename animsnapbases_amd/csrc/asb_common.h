@@ -184,6 +184,16 @@ struct asb_ctx {
     int sub_ntile = 0;                     // tiles of the read in progress (multi-rank steps: asb_panel_sub_*)
     int sub_budget[8] = {16, 16, 16, 16, 16, 16, 16, 16};      // steps given to the later sub-panels (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
+    // sketch predictor (asb_sketch.hip): candidates of the next read named by a greedy replay in the space of the columns
+    // the last read computed for its rejected steps
+    int sketch = 1;                        // ASB_SKETCH=0: candidates by energy (and the first panel's guess) only
+    bool sketch_valid = false;             // sk_score holds the scores for the read about to start
+    unsigned long long* sk_words = nullptr;
+    unsigned* sk_flags = nullptr;          // [-, abort, ran to the end, -]
+    double* sk_score = nullptr;            // (n_loc)
+    long long* sk_pred = nullptr;          // (64) the replay's winners
+    int sk_test_stall = 0;                 // tests: the next launch is made to time out
+    int64_t n_sketch_runs = 0, n_sketch_reads = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
     asb_geo* geo = nullptr;         // device geodesics (asb_geodesic.hip)
@@ -225,6 +235,9 @@ struct asb_ctx {
 
 // projection path entry points (asb_project.hip), dispatched on ctx->mode
 int asb_project_begin(asb_ctx* ctx, int64_t K);
+long long asb_sketch_capacity(asb_ctx* ctx);       // asb_sketch.hip
+int asb_sketch_predict(asb_ctx* ctx, const double* cols, long long stride, const double* wn2, int wn2_stride, const double* E,
+                       long long n, int r, int steps);
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1);
 void asb_splocs_free(asb_ctx* ctx);
 void asb_geo_free(asb_ctx* ctx);

@@ -45,6 +45,8 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->n_panels = ctx->n_refresh = 0;
     ctx->n_spec_steps = ctx->n_spec_kept = 0;
     ctx->n_guess_panels = 0;
+    ctx->n_sketch_runs = ctx->n_sketch_reads = 0;
+    ctx->sketch_valid = false;
     ctx->spec_budget = ASB_PANEL_COLS;
     {
         const int rcd = asb_dl_begin(ctx);          // overlapped download of the basis (asb_components_stream): a new run
@@ -292,6 +294,13 @@ extern "C" int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n) {
 extern "C" int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n) {
     if (!ctx || !n) return ASB_ERR_ARG;
     *n = ctx->n_guess_panels;
+    return ASB_OK;
+}
+
+extern "C" int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads) {
+    if (!ctx) return ASB_ERR_ARG;
+    if (runs) *runs = ctx->n_sketch_runs;
+    if (reads) *reads = ctx->n_sketch_reads;
     return ASB_OK;
 }
 

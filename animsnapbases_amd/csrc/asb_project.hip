@@ -30,19 +30,19 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // layout of ctx->scalar_dev (doubles)
 enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
-       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16 };  // 8..10: k_best_energy; 11..13: super-panels (band);
-                                                                     // 16..16+ASB_NG-1: thresholds of a guessed selection
+       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16, SC_GG = 24 };  // 8..10: k_best_energy; 11..13: super-panels (band);
+                                                                     // 16..16+ASB_NG-1: thresholds of a guessed selection,
+                                                                     // 24..24+ASB_NG-1: their g (k_tau_multi writes both)
 // Guessed candidates of a first panel (see asb_project_run): the scores EV + g (E - EV), g on a geometric grid -- E - EV
 // is the energy along the constant-in-time direction, of which the first components leave a falling share g behind
 #define ASB_NG 5
-__device__ __forceinline__ double guess_g(int q) {
-    return q == 0 ? 0.0 : (q == 1 ? 0.02 : (q == 2 ? 0.05 : (q == 3 ? 0.12 : 0.3)));
-}
+// (the g of each score sits beside its threshold: a selection by the sketch predictor's scores -- asb_sketch.hip -- is the
+// same predicate with ev = score, g = 0 and one live threshold, the others at +inf)
 __device__ __forceinline__ bool in_guess(double e, double ev, const double* __restrict__ sc) {
     const double m = e - ev;
     bool in = false;
 #pragma unroll
-    for (int q = 0; q < ASB_NG; ++q) in = in || (ev + guess_g(q) * m > sc[SC_TAUG + q]);
+    for (int q = 0; q < ASB_NG; ++q) in = in || (ev + sc[SC_GG + q] * m > sc[SC_TAUG + q]);
     return in;
 }
 
@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
 struct GuessTargets { double g[ASB_NG + 1]; long long m_target[ASB_NG + 1], m_cap[ASB_NG + 1]; };
 __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E, const double* __restrict__ EV, long long n,
                                                     const double* __restrict__ scm, int* __restrict__ hist, int by_exponent,
-                                                    GuessTargets gt, int nq) {
+                                                    GuessTargets gt, int nq, unsigned qmask = 0xffffffffu) {
     // one score at a time through the same LDS histogram: E / EV are re-read from cache, LDS holds 8 KB
     __shared__ int lh[ASB_NBINS];
     for (int q = 0; q < nq; ++q) {
+        if (!((qmask >> q) & 1u)) continue;
         for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
         __syncthreads();
         const double lo = scm[q * 8 + SC_LO], hi = scm[q * 8 + SC_HI], g = gt.g[q];
@@ -320,12 +321,19 @@ __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E
     }
 }
 __global__ __launch_bounds__(256) void k_tau_multi(int* __restrict__ hist, double* __restrict__ scm, double* __restrict__ sc, int level,
-                                                   GuessTargets gt) {
+                                                   GuessTargets gt, unsigned qmask = 0xffffffffu) {
     __shared__ int lh[ASB_NBINS];
     __shared__ int seg[256];
     const int q = blockIdx.x;
+    if (!((qmask >> q) & 1u)) {              // a score that takes no part: nothing lies above its threshold
+        if (level == 2 && threadIdx.x == 0 && q < ASB_NG) { sc[SC_TAUG + q] = 1.0e300; sc[SC_GG + q] = 0.0; }
+        return;
+    }
     tau_body(hist + q * ASB_NBINS, scm + q * 8, level, gt.m_target[q], gt.m_cap[q], lh, seg);
-    if (level == 2 && threadIdx.x == 0) sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
+    if (level == 2 && threadIdx.x == 0) {
+        sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
+        if (q < ASB_NG) sc[SC_GG + q] = gt.g[q];
+    }
 }
 
 // ordered compaction, two stages: cand_idx = global ids of { v : E[v] > tau } in increasing
@@ -3458,6 +3466,26 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     if (rejected) ctx->sub_cur = full + 1 < nsub_lim ? full + 1 : nsub_lim;
     else if (ntile == nsub_max) ctx->sub_cur = 2 * nsub_max < nsub_lim ? 2 * nsub_max : nsub_lim;
     if (total > 0) ctx->k_done = k + total;
+    // Structured data: the ranking reshuffled under this read's candidates.  The columns of its rejected steps are a sketch
+    // of the residual of EVERY vertex (asb_sketch.hip): a greedy replay in that space names the next read's candidates, and
+    // the next read gets all its sub-panels again (its rejected columns are the sketch after it).
+    if (ctx->sketch && rejected && total > 0 && k + total < k1) {
+        long long ncols = 0;
+        for (int ct = 0; ct < ntile; ++ct) ncols += nc[ct];
+        const long long left = ncols - total;
+        if (left >= 8 && ctx->n_loc <= asb_sketch_capacity(ctx) && ctx->n_loc > ctx->m_cap) {
+            const long long ks = k + total, todo = k1 - ks;
+            const int r = (int)(left < 64 ? left : 64), steps = (int)(todo < 64 ? todo : 64);
+            if ((rc = asb_sketch_predict(ctx, ctx->comps + (size_t)ks * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc), ctx->scal + ks * 4 + 1, 4,
+                                         ctx->energy, (long long)ctx->n_loc, r, steps)))
+                return rc;
+            ctx->sketch_valid = true;
+            ctx->sub_cur = nsub_lim;
+            for (int sp = 0; sp < 8; ++sp) ctx->sub_budget[sp] = ASB_PANEL_COLS;
+            if (getenv("ASB_DEBUG_PANELS"))
+                fprintf(stderr, "[asb] sketch of %d columns at k=%lld: %d steps replayed\n", r, ks, steps);
+        }
+    }
     *done_out = total;
     return ASB_OK;
 }
@@ -3588,6 +3616,32 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
+// candidates named by the sketch predictor (asb_sketch.hip): the m_target * 11 / 12 largest scores united with the m_target / 12
+// largest energies (the provable first steps) -- the guessed selection's machinery with one live score (g = 0: the score itself)
+static int score_thresholds(asb_ctx* ctx) {
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)(ASB_NG + 1) * 8))) return rc;
+    if (!ctx->hist6_clear) {
+        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)(ASB_NG + 1) * ASB_NBINS * sizeof(int), ctx->stream));
+        ctx->hist6_clear = true;
+    }
+    GuessTargets gt;
+    const long long me = ctx->m_target / 12, ms = ctx->m_target - me;
+    for (int q = 0; q <= ASB_NG; ++q) {
+        gt.g[q] = q == ASB_NG ? 1.0 : 0.0;
+        gt.m_target[q] = q == ASB_NG ? me : ms;
+        gt.m_cap[q] = q == ASB_NG ? me + me / 2 : ms + ms / 8;
+    }
+    const unsigned qmask = 1u | (1u << ASB_NG);
+    for (int level = 1; level <= 2; ++level) {
+        hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, ctx->sk_score, (long long)ctx->n_loc,
+                           ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, ASB_NG + 1, qmask);
+        hipLaunchKernelGGL(k_tau_multi, dim3(ASB_NG + 1), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt, qmask);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
 // multi-rank driver: what this shard contributes to the decision (the ranks sum both and compare), then begin / end
 // around the first panel: begin installs the score thresholds and the smaller target for the energies proper, which
 // asb_panel_tau / asb_panel_global_tau / asb_panel_target then use; asb_panel_select takes the union; the pass checks
@@ -3629,7 +3683,13 @@ extern "C" int asb_panel_guess_end(asb_ctx* ctx) {
 static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     int rc;
     const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
-    if (guess) {
+    const bool by_score = ctx->sketch_valid && stalled == 0 && k > 0;
+    ctx->sketch_valid = false;
+    if (by_score) {
+        if ((rc = score_thresholds(ctx))) return rc;
+        ctx->sel_e2 = ctx->sk_score;
+        ctx->n_sketch_reads++;
+    } else if (guess) {
         if ((rc = guess_thresholds(ctx, 1, true))) return rc;
         ctx->sel_e2 = ctx->EV;
         ctx->n_guess_panels++;

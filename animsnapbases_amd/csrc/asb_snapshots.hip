@@ -297,6 +297,8 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if (const char* dp = getenv("ASB_COOP_LAUNCH")) ctx->coop_launch = atoi(dp) ? 1 : 0;
     if (const char* dp = getenv("ASB_SPEC_PASS")) ctx->spec_pass = atoi(dp);
     if (const char* dp = getenv("ASB_SPEC_W_RANK")) ctx->spec_w_rank = atoi(dp);
+    if (const char* sk = getenv("ASB_SKETCH")) ctx->sketch = atoi(sk);
+    if (const char* sk = getenv("ASB_SKETCH_TEST_STALL")) ctx->sk_test_stall = atoi(sk);
     if (const char* dp = getenv("ASB_SUB_FIRST")) ctx->sub_first = atoi(dp) < 1 ? 1 : atoi(dp);
     if (const char* bt = getenv("ASB_BAND_TARGET")) { ctx->band_target = atoll(bt); ctx->band_cap = ctx->band_target * 4 / 3; }
     ctx->nblk_cap = prop.multiProcessorCount * 8;   // grid cap for streaming passes (guide: G11)

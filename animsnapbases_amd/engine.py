@@ -330,8 +330,10 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_coop_fallbacks(self.h, ctypes.byref(f)))
         g = ctypes.c_int64()
         self._ck(self.lib.asb_deflate_guessed_panels(self.h, ctypes.byref(g)))
+        h, i = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_sketch_stats(self.h, ctypes.byref(h), ctypes.byref(i)))
         return dict(panels=a.value, refreshes=b.value, unproven_tried=c.value, unproven_kept=d.value, energy_passes=e.value,
-                    coop_fallbacks=f.value, guessed_panels=g.value)
+                    coop_fallbacks=f.value, guessed_panels=g.value, sketch_runs=h.value, sketch_reads=i.value)
 
     def download_residual(self):
         out = np.empty((self.F, self.n_loc, 3))

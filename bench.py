@@ -209,7 +209,8 @@ def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50):
     reads = st["panels"] + st.get("energy_passes", 0) + st.get("refreshes", 0)
     out = {"workload": "config4 shape, low rank (%d) + 1e-4 noise: %d verts x %d frames, PCA K=%d global" % (r, N, F, K),
            "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "prepare_ms": t_prep, "reads_of_X": reads, "panels": st["panels"],
-           "refreshes": st.get("refreshes", 0),
+           "refreshes": st.get("refreshes", 0), "sketch_replays": st.get("sketch_runs", 0),
+           "reads_with_predicted_candidates": st.get("sketch_reads", 0),
            "roofline": {"bound": "hbm", "level": "call", "achieved": reads * 24.0 * N * F / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": reads * 24.0 * N * F / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "(reads of X) x 24 N F bytes / wall time: what THIS algorithm reads on this data"}}

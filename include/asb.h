@@ -215,6 +215,13 @@ int asb_deflate_coop_fallbacks(asb_ctx* ctx, int64_t* n);
  * like any others (asb_deflate_spec_stats), so the sequence is still that of posComponents.py:75-77.  *n = 1 if the last
  * run did so.  ASB_FIRST_PANEL_MEAN=0 switches it off. */
 int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
+/* Structured data (every component removes a direction all vertices share): the energies at the start of a read no longer
+ * say who wins a few steps later, and its pass rejects most of its unproven steps.  The coefficient columns of those rejected
+ * steps are a rank-r sketch of every vertex's residual; a greedy replay of posComponents.py:76-96 in that space (asb_sketch.hip:
+ * one thread per vertex, the sketch in registers) names the NEXT read's candidates.  Only the candidates change: every step is
+ * still checked by the pass against every vertex outside them, so the selected sequence stays the reference's.
+ * *runs = replays in the last run, *reads = reads of X whose candidates came from one.  ASB_SKETCH=0 switches it off. */
+int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads);
 /* The same for the multi-rank driver (animsnapbases_amd/_panels.py).  asb_panel_guess_stats: this shard's energy along the
  * constant direction, its |X|^2 and whether the context could guess at all (0: both values are 0); the ranks sum all three
  * and guess only if every rank can and the share exceeds 1/4.  asb_panel_guess_begin (before the first panel's
@@ -466,6 +473,11 @@ int asb_test_l2w_probe(asb_ctx* ctx, int nct, int mode, int reps, double* ms_out
 /* The 3x3 symmetric eigen-solver used by asb_deflate_pick, run on the HOST (unit test
  * without a GPU).  a6 = (a00,a01,a02,a11,a12,a22); out4 = (lambda_max, u0, u1, u2). */
 void asb_test_eig3(const double* a6, double* out4);
+/* tests: the sketch replay on host arrays -- cols (r x 3 n: column i, entry 3 v + d, the coefficient of vertex v's row d on the
+ * unit direction i divided by sqrt(wn2[i])), wn2 (r), exact energies E (n) -> scores (n; max over the steps of energy / winner's
+ * energy), the replay's winners pred (steps; -1 behind its end), *status = 1 (0: the exchange timed out, scores = energies) */
+int asb_test_sketch_predict(asb_ctx* ctx, const double* cols, const double* wn2, const double* E, int64_t n, int r, int steps,
+                            double* scores, int64_t* pred, int* status);
 /* test hook: inverse of a host symmetric positive definite matrix (n x n) through the device's blocked
  * Gauss-Jordan / f64-MFMA GEMM path that the device geodesics use for their two SPD systems */
 int asb_test_spd_inverse(asb_ctx* ctx, const double* A_host, int64_t n, double* Ainv_host);

@@ -1,0 +1,142 @@
+"""GPU (-m gpu): the sketch predictor of the panel algorithm (animsnapbases_amd/csrc/asb_sketch.hip).
+
+On structured data a read of X commits few of its steps (the ranking reshuffles under its candidates); the columns of the
+rejected steps are a sketch of every vertex's residual, and a greedy replay in that space names the next read's candidates.
+  * the replay kernel against a NumPy model of it (same arithmetic in f64): predicted winners, scores;
+  * its exchange timing out (forced) -> scores fall back to the energies, nothing hangs;
+  * end to end on low rank + noise: the selected sequence and the basis are the oracle's (posComponents.py:67-122) with the
+    predictor on and off, and the predictor cuts the reads of X.
+"""
+import ctypes
+import types
+
+import numpy as np
+import pytest
+
+from conftest import align_signs, relerr
+from oracle import asb_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def replay_model(Z, E, steps):
+    """Z (r, 3n) coordinates on unit directions, E (n) exact energies: the replay of asb_sketch.hip in f64."""
+    Z = Z.copy()
+    n = E.shape[0]
+    tail = np.maximum(E - (Z * Z).sum(0).reshape(n, 3).sum(1), 0.0)
+    e = (Z * Z).sum(0).reshape(n, 3).sum(1) + tail
+    score = np.zeros(n)
+    pred = []
+    for _ in range(steps):
+        v = int(np.argmax(e))
+        if not e[v] > 0:
+            break
+        score = np.maximum(score, e / e[v])
+        pred.append(v)
+        A = Z[:, 3 * v:3 * v + 3].copy()
+        lam, U = np.linalg.eigh(A.T @ A + tail[v] / 3 * np.eye(3))
+        u, lam = U[:, -1], lam[-1]
+        q = A @ u
+        Z -= np.outer(q, (q @ Z) / lam)
+        Z[:, 3 * v:3 * v + 3] = A - np.outer(q, u)
+        tail[v] *= 2.0 / 3.0
+        e = (Z * Z).sum(0).reshape(n, 3).sum(1) + tail
+    return score, pred
+
+
+def _predict(eng, cols, wn2, E, steps):
+    r, n3 = cols.shape
+    n = n3 // 3
+    scores = np.zeros(n)
+    pred = (ctypes.c_int64 * steps)()
+    status = ctypes.c_int(0)
+    cols = np.ascontiguousarray(cols)
+    wn2 = np.ascontiguousarray(wn2)
+    E = np.ascontiguousarray(E)
+    eng._ck(eng.lib.asb_test_sketch_predict(eng.h, cols.ctypes.data, wn2.ctypes.data, E.ctypes.data, n, r, steps,
+                                            scores.ctypes.data, pred, ctypes.byref(status)))
+    return scores, [int(p) for p in pred], status.value
+
+
+@pytest.mark.parametrize("n,r,steps,tail_rel,tol", [(5000, 40, 30, 1e-6, 5e-3), (70001, 64, 64, 1e-3, 5e-3), (1300, 7, 12, 0.5, 1e-3)])
+def test_replay_kernel_against_its_numpy_model(n, r, steps, tail_rel, tol):
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(n)
+    # a decaying shared structure: mode j has strength 0.85^j; every vertex takes part in every mode
+    Z = rng.normal(size=(r, 3 * n)) * (0.85 ** np.arange(r))[:, None]
+    wn2 = rng.uniform(0.5, 2.0, size=r)                  # the kernel is handed coefficients c = z / |w| and |w|^2
+    cols = Z / np.sqrt(wn2)[:, None]
+    own = (Z * Z).sum(0).reshape(n, 3).sum(1)
+    E = own + tail_rel * own.mean() * rng.uniform(0.5, 1.5, size=n)
+    eng = HipEngine(0)
+    scores, pred, status = _predict(eng, cols, wn2, E, steps)
+    assert status == 1
+    ms, mp = replay_model(Z, E, steps)
+    # f32 sketch against f64; the tail E - |Z|^2 is a difference of f32 sums (1e-7 of the energy: a tenth of a 1e-6 tail),
+    # which shows once the energies have fallen to it
+    print("largest score difference %.2e, winners agree for %d of %d steps" %
+          (np.abs(scores - ms).max(), next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp)), len(mp)))
+    assert pred[:len(mp) // 2] == mp[:len(mp) // 2]
+    assert np.abs(scores - ms).max() < tol
+    eng.close()
+
+
+def test_replay_exchange_timeout_leaves_the_energies(monkeypatch):
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(3)
+    n, r = 4000, 16
+    Z = rng.normal(size=(r, 3 * n))
+    E = (Z * Z).sum(0).reshape(n, 3).sum(1) * 1.01
+    monkeypatch.setenv("ASB_SKETCH_TEST_STALL", "1")
+    eng = HipEngine(0)
+    monkeypatch.delenv("ASB_SKETCH_TEST_STALL")
+    scores, pred, status = _predict(eng, Z, np.ones(r), E, 10)
+    assert status == 0 and np.array_equal(scores, E)
+    scores, pred, status = _predict(eng, Z, np.ones(r), E, 10)      # the stall was a one-off: the next launch runs
+    assert status == 1 and scores.max() == 1.0
+    eng.close()
+
+
+def _param(K):
+    return types.SimpleNamespace(vertPos_bases_type="PCA", q_standarize=True, q_massWeight=False, q_orthogonal=False,
+                                 q_support="global", vertPos_numComponents=K, store_vertPos_PCA_sing_val=False,
+                                 vertPos_smooth_min_dist=0.1, vertPos_smooth_max_dist=0.25, vertPos_rest_shape="first",
+                                 name="t", vertPos_output_directory=".")
+
+
+def _run(verts, K):
+    from animsnapbases_amd import posComponents, posSnapshots
+    snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False)
+    comp = posComponents(_param(K), snaps)
+    comp.deflate_mode = "project"
+    comp.compute_components_store_singvalues()
+    return comp, snaps._engine.deflate_stats()
+
+
+@pytest.mark.parametrize("stall", [False, True])
+def test_low_rank_data_same_basis_fewer_reads(stall, monkeypatch):
+    rng = np.random.default_rng(17)
+    F, N, K = 240, 40000, 96
+    verts = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=40, noise=1e-4, decay=0.9, seed=17)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+
+    def check(comp):
+        assert comp.selected_vertices.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comp.comps, comp.weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+
+    monkeypatch.setenv("ASB_SKETCH", "0")
+    comp0, st0 = _run(verts, K)
+    check(comp0)
+    assert st0["sketch_runs"] == 0
+    monkeypatch.setenv("ASB_SKETCH", "1")
+    if stall:
+        monkeypatch.setenv("ASB_SKETCH_TEST_STALL", "1")      # the first replay times out: that read's candidates are the plain ones
+    comp1, st1 = _run(verts, K)
+    check(comp1)
+    assert st1["sketch_runs"] >= 1 and st1["sketch_reads"] >= 1
+    reads0 = st0["panels"] + st0["refreshes"]
+    reads1 = st1["panels"] + st1["refreshes"]
+    print("reads of X: %d without the predictor, %d with it (%d replays)" % (reads0, reads1, st1["sketch_runs"]))
+    if not stall:
+        assert reads1 * 3 <= reads0 * 2
