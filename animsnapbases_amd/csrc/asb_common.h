@@ -212,6 +212,7 @@ struct asb_ctx {
     double* la_vtmp = nullptr;
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
+    double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
     double* td_ppart = nullptr;                   // partial mat-vec vectors of the tridiagonalisation (one per column chunk)
     double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
@@ -281,7 +282,7 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
 
 // C = beta C + alpha A B (row-major, even dimensions; asb_dense.hip) and the in-place SPD inverse built on it
 int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
-                int N, int Kc, double alpha, double beta);
+                int N, int Kc, double alpha, double beta, int tri = 0);
 int asb_dense_spd_inverse(asb_ctx* ctx, double* M, int np);
 int asb_deflate_apply_dev(asb_ctx* ctx, int64_t k, const double* s_dev);      // asb_deflate.hip
 // G = X^T X (n x n, both triangles) for a tall row-major X: LDS-tiled f64 MFMA kernel (asb_linalg.hip)
