@@ -20,8 +20,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A, long long lda, const double* __restrict__ B,
                                                    long long ldb, double* __restrict__ C, long long ldc, int M, int N, int Kc,
                                                    double alpha, double beta, int slab, double* __restrict__ part, int tri) {
-    // tri: only the tiles on and above the diagonal (a symmetric rank-k update of the upper triangle)
-    if (tri && (int)blockIdx.x < (int)blockIdx.y) return;
+    // tri > 0: only the tiles on and above the diagonal (a symmetric rank-k update of the upper triangle); C, B and N describe
+    // the columns from tile tri - 1 on
+    if (tri && (int)blockIdx.x + (tri - 1) < (int)blockIdx.y) return;
     __shared__ double As[2][DG_BM][DG_SA];
     __shared__ double Bs[2][DG_KC][DG_SB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -54,29 +55,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
         for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&Bs[buf][wave + 4 * q][2 * lane]) = rb[q];
     };
     d4 acc[4][4];
-    const bool split = gridDim.z > 1;
-    // beta C enters the accumulators up front (acc = A B + (beta / alpha) C, out = alpha acc): the tile of C is read while the
-    // first operand stage is in flight instead of behind the last MFMA, and the epilogue only stores
-    const bool cinit = !split && beta != 0.0 && alpha != 0.0;
-    if (k_begin < k_end) fetch(k_begin);
-    if (cinit) {
-        const double sc = beta / alpha;
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int oi = i0 + wi * 64 + x * 16 + g + 4 * q, oj = j0 + wj * 64 + y * 16 + li;
-                    acc[x][y][q] = (oi < M && oj < N) ? sc * C[(long long)oi * ldc + oj] : 0.0;
-                }
-    } else {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+    if (k_begin < k_end) {
+        fetch(k_begin);
+        stash(0);
     }
-    if (k_begin < k_end) stash(0);
     __syncthreads();
     int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += DG_KC) {
@@ -99,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
         __syncthreads();
         cur ^= 1;
     }
+    const bool split = gridDim.z > 1;
     double* o = split ? part + (long long)blockIdx.z * M * N : C;
     const long long ldo = split ? N : ldc;
 #pragma unroll
@@ -111,8 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
                 if (oi < M && oj < N) {
                     double* dst = o + (long long)oi * ldo + oj;
                     if (split) *dst = acc[x][y][q];
-                    else if (cinit || beta == 0.0) *dst = alpha * acc[x][y][q];
-                    else *dst = beta * *dst + alpha * acc[x][y][q];
+                    else *dst = (beta == 0.0 ? 0.0 : beta * *dst) + alpha * acc[x][y][q];
                 }
             }
 }
@@ -131,7 +117,8 @@ __global__ __launch_bounds__(256) void k_gemm_finish(const double* __restrict__ 
 int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
                 int N, int Kc, double alpha, double beta, int tri) {
     if ((lda | ldb | ldc | M | N | Kc) & 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: odd dimension");
-    if (tri && M != N) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: the triangular form needs a square result");
+    if (tri && M != N + (tri - 1) * DG_BM && !(M > N + (tri - 1) * DG_BM))
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: the triangular form needs the columns of a square result");
     const int tm = (M + DG_BM - 1) / DG_BM, tn = (N + DG_BM - 1) / DG_BM;
     // split the contraction when the tile grid alone cannot fill the chip (skinny products with a long contraction)
     int S = 1;
