@@ -6,6 +6,7 @@
 // inverted once (N = 15 000: 1.75 GB each) and every later solve is a column gather / one GEMM.  gfx950 only.
 #include "asb_common.h"
 
+#include <chrono>
 #include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -20,9 +21,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A, long long lda, const double* __restrict__ B,
                                                    long long ldb, double* __restrict__ C, long long ldc, int M, int N, int Kc,
                                                    double alpha, double beta, int slab, double* __restrict__ part, int tri) {
-    // tri > 0: only the tiles on and above the diagonal (a symmetric rank-k update of the upper triangle); C, B and N describe
-    // the columns from tile tri - 1 on
-    if (tri && (int)blockIdx.x + (tri - 1) < (int)blockIdx.y) return;
+    // tri: only the tiles on and above the diagonal (a symmetric rank-k update of the upper triangle)
+    if (tri && (int)blockIdx.x < (int)blockIdx.y) return;
     __shared__ double As[2][DG_BM][DG_SA];
     __shared__ double Bs[2][DG_KC][DG_SB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -117,8 +117,7 @@ __global__ __launch_bounds__(256) void k_gemm_finish(const double* __restrict__ 
 int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
                 int N, int Kc, double alpha, double beta, int tri) {
     if ((lda | ldb | ldc | M | N | Kc) & 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: odd dimension");
-    if (tri && M != N + (tri - 1) * DG_BM && !(M > N + (tri - 1) * DG_BM))
-        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: the triangular form needs the columns of a square result");
+    if (tri && M != N) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_gemm_nn: the triangular form needs a square result");
     const int tm = (M + DG_BM - 1) / DG_BM, tn = (N + DG_BM - 1) / DG_BM;
     // split the contraction when the tile grid alone cannot fill the chip (skinny products with a long contraction)
     int S = 1;
@@ -247,17 +246,33 @@ __global__ __launch_bounds__(1024) void k_block_inverse16(const double* __restri
     const int nT = b / 16;
     for (int p = 0; p < nT; ++p) {
         const int p0 = p * 16;
-        const int r = (tid >> 4) & 15, c = tid & 15;
-        const bool dt = tid < 256;
-        if (dt) D[r][c] = Sm[(p0 + r) * ld + p0 + c];
-        for (int j = 0; j < 16; ++j) {
-            __syncthreads();
-            const double piv = D[j][j];
-            const double d = 1.0 / piv;
-            const double prow = D[j][c] * d, pcol = D[r][j];
-            if (tid == 0 && !(piv > 0.0)) bad = 1;
-            __syncthreads();
-            if (dt) D[r][c] = (r == j) ? (c == j ? d : prow) : (c == j ? -pcol * d : D[r][c] - pcol * prow);
+        // the pivot tile's own inverse: ONE wave (lane l: column l & 15, rows (l >> 4) + 4 q), 16 Gauss-Jordan steps through LDS
+        // with no block barrier inside -- LDS operations of a wave complete in order; the other 15 waves wait below
+        if (tid < 64) {
+            const int c = tid & 15, rb = tid >> 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) D[rb + 4 * q][c] = Sm[(p0 + rb + 4 * q) * ld + p0 + c];
+            for (int j = 0; j < 16; ++j) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double piv = D[j][j];
+                const double d = 1.0 / piv;
+                const double prow = D[j][c] * d;
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = rb + 4 * q;
+                    const double pcol = D[r][j];
+                    v[q] = (r == j) ? (c == j ? d : prow) : (c == j ? -pcol * d : D[r][c] - pcol * prow);
+                }
+                if (tid == 0 && !(piv > 0.0)) bad = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) D[rb + 4 * q][c] = v[q];
+            }
         }
         __syncthreads();
         // row panel R = Dinv S[p, :] outside the pivot columns
@@ -490,6 +505,9 @@ int asb_dense_spd_inverse(asb_ctx* ctx, double* Mx, int np) {
     if ((rc = asb_alloc(ctx, &ctx->la_status, (size_t)4))) return rc;
     ASB_HIP(ctx, hipMemsetAsync(ctx->la_status, 0, 4 * sizeof(int), ctx->stream));
     static const int sym = getenv("ASB_DENSE_SYM") ? atoi(getenv("ASB_DENSE_SYM")) : 1;
+    const bool timing = getenv("ASB_DEBUG_GJ") != nullptr;
+    if (timing) (void)hipStreamSynchronize(ctx->stream);
+    const auto t_start = std::chrono::steady_clock::now();
     if (np <= GJ_BK || !sym) {
         if ((rc = spd_inverse_full(ctx, Mx, np))) return rc;
     } else {
@@ -515,6 +533,9 @@ int asb_dense_spd_inverse(asb_ctx* ctx, double* Mx, int np) {
     int st[4];
     ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (timing)
+        fprintf(stderr, "[asb] dense SPD inverse of %d x %d: %.1f ms\n", np, np,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     if (st[0]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "dense inverse: the matrix is not positive definite");
     return ASB_OK;
 }

@@ -419,6 +419,7 @@ int asb_jacobi_rows_dev(asb_ctx* ctx, double* A, int nv, int m, long long lda, d
         unsigned h;
         memcpy(&h, ctx->host_pin + 384, sizeof(h));
         converged = h == 0;
+        if (getenv("ASB_DEBUG_JACOBI")) fprintf(stderr, "[asb] one-sided Jacobi %d x %d: sweep %d, %u rotations\n", nv, m, sweep, h);
     }
     if (!converged) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "one-sided Jacobi: no convergence in %d sweeps (%d x %d)", sweep, nv, m);
     if (sweeps_out) *sweeps_out = sweep;
