@@ -188,10 +188,12 @@ struct asb_ctx {
     // the last read computed for its rejected steps
     int sketch = 1;                        // ASB_SKETCH=0: candidates by energy (and the first panel's guess) only
     bool sketch_valid = false;             // sk_score holds the scores for the read about to start
+    bool sketch_run_off = false;           // this run's data are noise-like (a sketch held too little of the residual): no more replays
     unsigned long long* sk_words = nullptr;
     unsigned* sk_flags = nullptr;          // [-, abort, ran to the end, -]
     double* sk_score = nullptr;            // (n_loc)
     long long* sk_pred = nullptr;          // (64) the replay's winners
+    unsigned* sk_counts = nullptr;         // [replays run, launches that found the sketch too thin and left score = energy]
     int sk_test_stall = 0;                 // tests: the next launch is made to time out
     int64_t n_sketch_runs = 0, n_sketch_reads = 0;
 

@@ -46,7 +46,9 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->n_spec_steps = ctx->n_spec_kept = 0;
     ctx->n_guess_panels = 0;
     ctx->n_sketch_runs = ctx->n_sketch_reads = 0;
+    if (ctx->sk_counts) ASB_HIP(ctx, hipMemsetAsync(ctx->sk_counts, 0, 4 * sizeof(unsigned), ctx->stream));
     ctx->sketch_valid = false;
+    ctx->sketch_run_off = false;
     ctx->spec_budget = ASB_PANEL_COLS;
     {
         const int rcd = asb_dl_begin(ctx);          // overlapped download of the basis (asb_components_stream): a new run
@@ -299,8 +301,14 @@ extern "C" int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n) {
 
 extern "C" int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads) {
     if (!ctx) return ASB_ERR_ARG;
-    if (runs) *runs = ctx->n_sketch_runs;
-    if (reads) *reads = ctx->n_sketch_reads;
+    // (the kernel itself decides whether the sketch holds enough of the residual to replay: device counters)
+    unsigned c[4] = {0, 0, 0, 0};
+    if (ctx->sk_counts) {
+        ASB_HIP(ctx, hipMemcpyAsync(c, ctx->sk_counts, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (runs) *runs = c[0];
+    if (reads) *reads = ctx->n_sketch_reads > (int64_t)c[1] ? ctx->n_sketch_reads - (int64_t)c[1] : 0;
     return ASB_OK;
 }
 

@@ -83,6 +83,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64_dpp(unsigned long lon
     }
     return v;
 }
+__device__ __forceinline__ bool tl0(unsigned b, int t) { return b == 0 && t == 0; }
 // out of line: one lane per block runs it per step, and inlined its ~60 registers of f64 temporaries would come on top of the
 // 192 the sketch occupies everywhere
 __device__ __attribute__((noinline)) void sk_eig3(const float* g, float t3f, double* out4) {
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
                                                            const double* __restrict__ wn2, int wn2_stride,
                                                            const double* __restrict__ E, long long n, int r, int steps,
                                                            double* __restrict__ score_out, long long* __restrict__ pred_out,
-                                                           unsigned long long* words, unsigned* flags, int test_stall) {
+                                                           unsigned long long* words, unsigned* flags, int test_stall, float min_share,
+                                                           unsigned* counts) {
     __shared__ __attribute__((aligned(16))) float q_sh[SK_R];
     __shared__ double lam_sh;
     __shared__ float zs[4][64];
@@ -160,6 +162,54 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
     float score = 0.0f;
     const long long spin_max = test_stall ? (1LL << 10) : (1LL << 20);
     bool aborted = false;
+    // ---- is a replay worth its 0.7 ms?  Only if the sketch HOLDS the residual: its share of the energy, sum |Z_v|^2 / sum E_v, is
+    // near 1 on structured data and a few per cent on noise (r of F directions), where candidates by energy do as well (measured on
+    // eight random tensors: 6.6 ms per step without replays, 7.0 with).  One exchange: every block publishes its two sums, all
+    // blocks add them in the same order and take the same decision; below min_share the launch leaves score = energy.
+    {
+        __shared__ double gsum[2][256];
+        __shared__ double gate[2];
+        double v2[2] = {have ? (double)((g[0] + g[3]) + g[5]) : 0.0, have ? e_in : 0.0};
+        block_sum<2>(v2, &gsum[0][0]);
+        __syncthreads();
+        unsigned long long* grec = qbuf + (size_t)3 * SK_QW;           // 2 G words behind the q messages
+        if (tid == 0 && !(test_stall && (int)blockIdx.x == G - 1)) {
+            sk_store(grec + 2 * blockIdx.x, (unsigned long long)__double_as_longlong(v2[0]));
+            sk_store(grec + 2 * blockIdx.x + 1, (unsigned long long)__double_as_longlong(v2[1]));
+        }
+        int dead = 0;
+        for (int b = tid; b < G; b += SK_T) {
+            unsigned long long w0, w1;
+            long long spins = 0;
+            for (;;) {
+                w0 = sk_load(grec + 2 * b);
+                w1 = sk_load(grec + 2 * b + 1);
+                if (w0 != SK_SENT && w1 != SK_SENT) break;
+                if ((++spins & 63) == 0 &&
+                    (spins > spin_max || __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { dead = 1; break; }
+            }
+            if (dead) break;
+            gsum[0][b] = __longlong_as_double((long long)w0);
+            gsum[1][b] = __longlong_as_double((long long)w1);
+        }
+        if (__syncthreads_or(dead)) {
+            if (tid == 0) __hip_atomic_store(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (have) score_out[v] = e_in;
+            return;
+        }
+        if (tid == 0) {
+            double a = 0.0, b2 = 0.0;
+            for (int b = 0; b < G; ++b) { a += gsum[0][b]; b2 += gsum[1][b]; }
+            gate[0] = a; gate[1] = b2;
+        }
+        __syncthreads();
+        if (!(gate[0] >= (double)min_share * gate[1])) {
+            if (have) score_out[v] = e_in;
+            if (tl0(blockIdx.x, tid)) { __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(counts + 1, 1u); }
+            return;
+        }
+        if (tl0(blockIdx.x, tid)) atomicAdd(counts + 0, 1u);
+    }
     unsigned long long* tlog = reinterpret_cast<unsigned long long*>(flags + 4);      // [64][6] timestamps of block 0 (debug)
     const bool tl = blockIdx.x == 0 && tid == 0;
     // a record is ONE word: (bits of the energy, an f32 >= 0: ordered like the value) << 32 | (2^32 - 1 - vertex): the largest
@@ -325,7 +375,8 @@ long long asb_sketch_capacity(asb_ctx* ctx) {
         (void)hipGetLastError();
         return 0;
     }
-    return (long long)per_cu * ctx->n_cu * SK_T;
+    const long long cap = (long long)per_cu * ctx->n_cu * SK_T;
+    return cap < 256LL * SK_T ? cap : 256LL * SK_T;          // (the gate's exchange holds 256 blocks)
 }
 
 // scores of the n vertices whose sketch columns are cols[i * stride + 3 v + d] (i < r <= 64), exact energies E, into
@@ -336,24 +387,33 @@ int asb_sketch_predict(asb_ctx* ctx, const double* cols, long long stride, const
     if (steps > 64) steps = 64;
     if (n > asb_sketch_capacity(ctx)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: %lld vertices exceed one co-resident launch", n);
     const int G = (int)((n + SK_T - 1) / SK_T);
-    const size_t n_words = (size_t)3 * G + (size_t)3 * SK_QW;
+    if (G > 256) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: more than 256 blocks");
+    const size_t n_words = (size_t)3 * G + (size_t)3 * SK_QW + (size_t)2 * G;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_words, n_words))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_flags, (size_t)4 + 2 * 64 * 6))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_score, (size_t)n))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_pred, (size_t)64))) return rc;
+    if (!ctx->sk_counts) {
+        if ((rc = asb_alloc(ctx, &ctx->sk_counts, (size_t)4))) return rc;
+        ASB_HIP(ctx, hipMemsetAsync(ctx->sk_counts, 0, 4 * sizeof(unsigned), ctx->stream));
+    }
+    static const float min_share = getenv("ASB_SKETCH_MIN_SHARE") ? (float)atof(getenv("ASB_SKETCH_MIN_SHARE")) : 0.15f;
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_words, 0xFF, n_words * sizeof(unsigned long long), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_flags, 0, 4 * sizeof(unsigned), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_pred, 0xFF, 64 * sizeof(long long), ctx->stream));
     hipLaunchKernelGGL(k_sketch_greedy, dim3(G), dim3(SK_T), 0, ctx->stream, cols, stride, wn2, wn2_stride, E, n, r, steps,
-                       ctx->sk_score, ctx->sk_pred, ctx->sk_words, ctx->sk_flags, ctx->sk_test_stall);
+                       ctx->sk_score, ctx->sk_pred, ctx->sk_words, ctx->sk_flags, ctx->sk_test_stall, min_share, ctx->sk_counts);
     ASB_CHECK_LAUNCH(ctx);
     ctx->sk_test_stall = 0;
     ctx->n_sketch_runs++;
     if (getenv("ASB_DEBUG_PANELS")) {
         unsigned long long tlh[64 * 6];
+        unsigned flh[4] = {0, 0, 0, 0};
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(flh, ctx->sk_flags, sizeof(flh), hipMemcpyDeviceToHost);
         (void)hipMemcpy(tlh, ctx->sk_flags + 4, sizeof(tlh), hipMemcpyDeviceToHost);
+        if (!flh[2]) steps = 0;
         for (int t = 0; t < steps; t += 9)
             fprintf(stderr, "[asb]   replay step %2d: best+publish %.2f | poll+eigen %.2f | resets+score %.2f | winner q %.2f | deflate %.2f | total %.2f us\n", t,
                     (tlh[t * 6 + 1] - tlh[t * 6 + 0]) * 0.01, (tlh[t * 6 + 2] - tlh[t * 6 + 1]) * 0.01, 0.0,

@@ -220,6 +220,8 @@ int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
  * steps are a rank-r sketch of every vertex's residual; a greedy replay of posComponents.py:76-96 in that space (asb_sketch.hip:
  * one thread per vertex, the sketch in registers) names the NEXT read's candidates.  Only the candidates change: every step is
  * still checked by the pass against every vertex outside them, so the selected sequence stays the reference's.
+ * A replay runs only if the sketch holds at least ASB_SKETCH_MIN_SHARE (0.15) of the residual's energy -- on noise it holds r / F of it and
+ * candidates by energy do as well; the kernel decides that itself (one exchange) and otherwise leaves the plain selection.
  * *runs = replays in the last run, *reads = reads of X whose candidates came from one.  ASB_SKETCH=0 switches it off. */
 int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads);
 /* The same for the multi-rank driver (animsnapbases_amd/_panels.py).  asb_panel_guess_stats: this shard's energy along the
