@@ -30,19 +30,25 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // layout of ctx->scalar_dev (doubles)
 enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
-       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16, SC_GG = 24 };  // 8..10: k_best_energy; 11..13: super-panels (band);
+       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16, SC_GG = 24, SC_HH = 32 };  // 8..10: k_best_energy; 11..13: super-panels (band);
                                                                      // 16..16+ASB_NG-1: thresholds of a guessed selection,
-                                                                     // 24..24+ASB_NG-1: their g (k_tau_multi writes both)
+                                                                     // 24.. / 32..: their g and h (k_tau_multi writes all three)
 // Guessed candidates of a first panel (see asb_project_run): the scores EV + g (E - EV), g on a geometric grid -- E - EV
 // is the energy along the constant-in-time direction, of which the first components leave a falling share g behind
-#define ASB_NG 5
+#define ASB_NG 6
 // (the g of each score sits beside its threshold: a selection by the sketch predictor's scores -- asb_sketch.hip -- is the
 // same predicate with ev = score, g = 0 and one live threshold, the others at +inf)
+// score q of a vertex with energy e, of which m = e - ev along the constant direction: ev + g m + h sqrt(m ev).  The last term
+// (round 3) is an UPPER CONFIDENCE bound: the first components' coefficients c_v = alpha (-a_v sqrt(F)) + beta (n_v . n_w) carry
+// the cross term 2 alpha beta a_v sqrt(F) (n_v . n_w), zero-mean with variance 4 alpha^2 beta^2 M_v EV_v / (3 F) per step -- about
+// 1 % of a vertex's energy in all, as large as the spread of EV among the leading few hundred vertices -- so a vertex with much
+// energy along the constant direction can rise by that much; h = kappa / sqrt(F) (guess_thresholds)
+__device__ __forceinline__ double guess_score(double ev, double m, double s, double g, double h) { return ev + g * m + h * s; }
 __device__ __forceinline__ bool in_guess(double e, double ev, const double* __restrict__ sc) {
-    const double m = e - ev;
+    const double m = e - ev, s = sqrt(fmax(m, 0.0) * fmax(ev, 0.0));
     bool in = false;
 #pragma unroll
-    for (int q = 0; q < ASB_NG; ++q) in = in || (ev + sc[SC_GG + q] * m > sc[SC_TAUG + q]);
+    for (int q = 0; q < ASB_NG; ++q) in = in || (guess_score(ev, m, s, sc[SC_GG + q], sc[SC_HH + q]) > sc[SC_TAUG + q]);
     return in;
 }
 
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
 // ---- the thresholds of a guessed selection in one go: ASB_NG + 1 scores EV + g (E - EV) (the last one, g = 1, is the
 // energy itself), each with its own histogram, range block scm[q * 8 ..] (slots as in sc) and target; block q of k_tau_multi
 // is k_tau for score q, and at level 2 it leaves the threshold where the compaction looks for it
-struct GuessTargets { double g[ASB_NG + 1]; long long m_target[ASB_NG + 1], m_cap[ASB_NG + 1]; };
+struct GuessTargets { double g[ASB_NG + 1], h[ASB_NG + 1]; long long m_target[ASB_NG + 1], m_cap[ASB_NG + 1]; };
 __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E, const double* __restrict__ EV, long long n,
                                                     const double* __restrict__ scm, int* __restrict__ hist, int by_exponent,
                                                     GuessTargets gt, int nq, unsigned qmask = 0xffffffffu) {
@@ -299,10 +305,11 @@ __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E
         if (!((qmask >> q) & 1u)) continue;
         for (int i = threadIdx.x; i < ASB_NBINS; i += blockDim.x) lh[i] = 0;
         __syncthreads();
-        const double lo = scm[q * 8 + SC_LO], hi = scm[q * 8 + SC_HI], g = gt.g[q];
+        const double lo = scm[q * 8 + SC_LO], hi = scm[q * 8 + SC_HI], g = gt.g[q], h = gt.h[q];
         const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-            const double ev = EV[i], e = ev + g * (E[i] - ev);
+            const double ev = EV[i], m = E[i] - ev;
+            const double e = guess_score(ev, m, h != 0.0 ? sqrt(fmax(m, 0.0) * fmax(ev, 0.0)) : 0.0, g, h);
             int b;
             if (by_exponent) {
                 if (!(e >= 0.0)) continue;
@@ -326,13 +333,13 @@ __global__ __launch_bounds__(256) void k_tau_multi(int* __restrict__ hist, doubl
     __shared__ int seg[256];
     const int q = blockIdx.x;
     if (!((qmask >> q) & 1u)) {              // a score that takes no part: nothing lies above its threshold
-        if (level == 2 && threadIdx.x == 0 && q < ASB_NG) { sc[SC_TAUG + q] = 1.0e300; sc[SC_GG + q] = 0.0; }
+        if (level == 2 && threadIdx.x == 0 && q < ASB_NG) { sc[SC_TAUG + q] = 1.0e300; sc[SC_GG + q] = 0.0; sc[SC_HH + q] = 0.0; }
         return;
     }
     tau_body(hist + q * ASB_NBINS, scm + q * 8, level, gt.m_target[q], gt.m_cap[q], lh, seg);
     if (level == 2 && threadIdx.x == 0) {
         sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
-        if (q < ASB_NG) sc[SC_GG + q] = gt.g[q];
+        if (q < ASB_NG) { sc[SC_GG + q] = gt.g[q]; sc[SC_HH + q] = gt.h[q]; }
     }
 }
 
@@ -3603,8 +3610,13 @@ static bool guess_possible(const asb_ctx* ctx) {
 // thresholds of the scores EV + g (E - EV) into sc[SC_TAUG ..]: about mq[q] / world of this shard's vertices above each.
 // ~590 candidates on config 4 (the sets overlap), at most 830 + bin overshoot + the energies' own of the 1024 resident waves
 static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
-    static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3};
-    static const int mq[ASB_NG] = {400, 140, 140, 90, 60};
+    // five shares g of the constant direction (what the first components leave behind: 0.107, 0.055, 0.028, 0.016 ... 0.004 on
+    // config 4) and, round 3, the upper confidence bound on the cross terms: kappa = 1.35 is 2.6 standard deviations of the model
+    // in in_guess's comment (sum over the steps of 4 alpha^2 beta^2 = 0.8).  CPU replay of six tensors (tools/sim_first_read.py):
+    // first winner outside the union at step 42, 21, 41, 42, 57, 52 of 64 without it, 49-55, none, 53-none, none, 57, none with it
+    static const double gq[ASB_NG] = {0.0, 0.02, 0.05, 0.12, 0.3, 0.0};
+    static const double kq[ASB_NG] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.35};
+    static const int mq[ASB_NG] = {400, 140, 140, 90, 60, 400};
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)(ASB_NG + 1) * 8))) return rc;
@@ -3617,6 +3629,7 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
         long long m = mq[q] * ctx->m_target / 768 / world;
         if (m < 8) m = 8;
         gt.g[q] = gq[q];
+        gt.h[q] = kq[q] / sqrt((double)ctx->F);
         gt.m_target[q] = m;
         gt.m_cap[q] = m + m / 8;
     }
@@ -3624,13 +3637,16 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     // through the usual exchange instead)
     const long long me = ctx->m_target / 12;
     gt.g[ASB_NG] = 1.0;
+    gt.h[ASB_NG] = 0.0;
     gt.m_target[ASB_NG] = me;
     gt.m_cap[ASB_NG] = me + me / 2;
     const int nq = with_energy ? ASB_NG + 1 : ASB_NG;
+    static const int ucb = getenv("ASB_GUESS_UCB") ? atoi(getenv("ASB_GUESS_UCB")) : 1;      // 0: without the confidence-bound family
+    const unsigned qmask = ucb ? 0xffffffffu : ~(1u << (ASB_NG - 1));
     for (int level = 1; level <= 2; ++level) {
         hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, ctx->EV, (long long)ctx->n_loc,
-                           ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, nq);
-        hipLaunchKernelGGL(k_tau_multi, dim3(nq), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt);
+                           ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, nq, qmask);
+        hipLaunchKernelGGL(k_tau_multi, dim3(nq), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt, qmask);
     }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -3649,6 +3665,7 @@ static int score_thresholds(asb_ctx* ctx) {
     const long long me = ctx->m_target / 12, ms = ctx->m_target - me;
     for (int q = 0; q <= ASB_NG; ++q) {
         gt.g[q] = q == ASB_NG ? 1.0 : 0.0;
+        gt.h[q] = 0.0;
         gt.m_target[q] = q == ASB_NG ? me : ms;
         gt.m_cap[q] = q == ASB_NG ? me + me / 2 : ms + ms / 8;
     }

@@ -306,7 +306,7 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if ((rc = asb_alloc(ctx, &ctx->pmax, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pidx, (size_t)ctx->nblk_cap))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->psum, (size_t)ctx->nblk_cap))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)32))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)48))) return rc;
     return ASB_OK;
 }
 

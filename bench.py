@@ -178,14 +178,14 @@ def other_config_pos(tag, fixture, support, kind, cpu=True):
     return out
 
 
-def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50):
+def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50, seed=77):
     """config 4's shape on STRUCTURED data ("parity on low-rank + noise"): rest + coef (F x r) . modes (r x N x 3)
     + 1e-4 noise, modes ~ N(0, 0.02^2), coef[:, j] ~ N(0, 0.9^2j) -- every strong component reshuffles all energies, so a read
     of X commits fewer components than on the random tensor of the headline."""
     import torch
     from animsnapbases_amd import posComponents, posSnapshots
     gen = torch.Generator(device=dev)
-    gen.manual_seed(77)
+    gen.manual_seed(int(seed))
     rest = torch.randn((N * 3,), dtype=torch.float64, device=dev, generator=gen)
     coef = torch.randn((F, r), dtype=torch.float64, device=dev, generator=gen) * (0.9 ** torch.arange(r, dtype=torch.float64, device=dev))[None]
     modes = 0.02 * torch.randn((r, N * 3), dtype=torch.float64, device=dev, generator=gen)
@@ -215,6 +215,27 @@ def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50):
                         "unit": "GB/s", "frac": reads * 24.0 * N * F / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "(reads of X) x 24 N F bytes / wall time: what THIS algorithm reads on this data"}}
     del comp, snaps, holder
+    return out
+
+
+def other_config_c4_lowrank_seeds(dev, seeds=(77, 78, 79)):
+    """the low-rank leg on three tensors: the greedy sequence is chaotic in which read a rejection falls (6 or 7 reads per tensor,
+    15-19 ms), so the leg reports the mean; `each` holds the single runs."""
+    import torch
+    runs = []
+    for sd in seeds:
+        runs.append(other_config_c4_lowrank(dev, seed=sd))
+        torch.cuda.empty_cache()
+    out = dict(runs[0])
+    ms = float(np.mean([r["ms"] for r in runs]))
+    reads = float(np.mean([r["reads_of_X"] for r in runs]))
+    out.update(ms=ms, snapshots_per_s=runs[0]["snapshots_per_s"] * runs[0]["ms"] / ms, reads_of_X=reads, seeds=list(seeds),
+               each=[{k: r[k] for k in ("ms", "reads_of_X", "sketch_replays", "reads_with_predicted_candidates")} for r in runs])
+    out["roofline"] = dict(runs[0]["roofline"])
+    scale = (reads / runs[0]["reads_of_X"]) * (runs[0]["ms"] / ms)
+    out["roofline"]["achieved"] = runs[0]["roofline"]["achieved"] * scale
+    out["roofline"]["frac"] = runs[0]["roofline"]["frac"] * scale
+    out["workload"] += " (mean of %d tensors)" % len(seeds)
     return out
 
 
@@ -550,7 +571,7 @@ def main():
         torch.cuda.empty_cache()
         cpu = not args.no_cpu_baseline
         oc = {}
-        for tag, fn in (("c4_lowrank", lambda: other_config_c4_lowrank(dev)),
+        for tag, fn in (("c4_lowrank", lambda: other_config_c4_lowrank_seeds(dev)),
                         ("c4_other_seeds", lambda: other_config_c4_seeds(dev)),
                         ("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
                         ("c2_local", lambda: other_config_pos("config2 (local support)", "c2_bunny_pca_local", "local", "PCA", cpu)),
