@@ -3651,8 +3651,8 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
-// candidates named by the sketch predictor (asb_sketch.hip): the m_target * 11 / 12 largest scores united with the m_target / 12
-// largest energies (the provable first steps) -- the guessed selection's machinery with one live score (g = 0: the score itself)
+// candidates named by the sketch predictor (asb_sketch.hip): the 2/3 m_target largest scores united with the m_target / 3
+// largest energies (which also carry the provable first steps) -- the guessed selection's machinery with one live score (g = 0: the score itself)
 static int score_thresholds(asb_ctx* ctx) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
@@ -3662,7 +3662,10 @@ static int score_thresholds(asb_ctx* ctx) {
         ctx->hist6_clear = true;
     }
     GuessTargets gt;
-    const long long me = ctx->m_target / 12, ms = ctx->m_target - me;
+    // (a third of the candidates by energy: the replay names who comes CLOSE to winning under its model, the energies who is large
+    // now -- eight low-rank tensors: 16.0 ms / 6.25 reads in the mean with a third or a half by energy, 17.0 / 6.5 with a twelfth)
+    static const int me_div = getenv("ASB_SKETCH_ME_DIV") ? atoi(getenv("ASB_SKETCH_ME_DIV")) : 3;
+    const long long me = ctx->m_target / (me_div > 1 ? me_div : 2), ms = ctx->m_target - me;
     for (int q = 0; q <= ASB_NG; ++q) {
         gt.g[q] = q == ASB_NG ? 1.0 : 0.0;
         gt.h[q] = 0.0;
