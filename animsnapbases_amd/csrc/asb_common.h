@@ -188,6 +188,9 @@ struct asb_ctx {
     // the last read computed for its rejected steps
     int sketch = 1;                        // ASB_SKETCH=0: candidates by energy (and the first panel's guess) only
     bool sketch_valid = false;             // sk_score holds the scores for the read about to start
+    bool read_by_score = false, last_by_score = false;      // the read in progress / the one before took predicted candidates
+    double rate_plain = -1.0, rate_sketch = -1.0;           // components per modelled ms of the two kinds of read (exponential means)
+    int mode_streak = 0, probe_after = 2;
     bool sketch_run_off = false;           // this run's data are noise-like (a sketch held too little of the residual): no more replays
     unsigned long long* sk_words = nullptr;
     unsigned* sk_flags = nullptr;          // [-, abort, ran to the end, -]

@@ -49,6 +49,10 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     if (ctx->sk_counts) ASB_HIP(ctx, hipMemsetAsync(ctx->sk_counts, 0, 4 * sizeof(unsigned), ctx->stream));
     ctx->sketch_valid = false;
     ctx->sketch_run_off = false;
+    ctx->read_by_score = ctx->last_by_score = false;
+    ctx->rate_plain = ctx->rate_sketch = -1.0;
+    ctx->mode_streak = 0;
+    ctx->probe_after = 2;
     ctx->spec_budget = ASB_PANEL_COLS;
     {
         const int rcd = asb_dl_begin(ctx);          // overlapped download of the basis (asb_components_stream): a new run

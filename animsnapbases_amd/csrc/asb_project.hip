@@ -3476,7 +3476,40 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     // Structured data: the ranking reshuffled under this read's candidates.  The columns of its rejected steps are a sketch
     // of the residual of EVERY vertex (asb_sketch.hip): a greedy replay in that space names the next read's candidates, and
     // the next read gets all its sub-panels again (its rejected columns are the sketch after it).
-    if (ctx->sketch && !ctx->sketch_run_off && rejected && total > 0 && k + total < k1) {
+    // Is a predicted read worth what it costs?  It reads X for all four sub-panels and pays the replay (about 2.9 ms at config 4's
+    // size) where a plain read behind a rejection takes one or two sub-panels (1.3 - 1.6 ms): on low-rank data it commits 4x the
+    // components, on a slowly decaying spectrum or on localised modes 1.3 - 1.5x (tools/structured_probe.py: 9 reads in 23.7 ms
+    // against 12 in 16.3, 16 in 42.9 against 23 in 30.3 when every rejection was answered by a replay).  So both kinds of read are
+    // rated, components per (modelled) millisecond, as exponential means; the better one is taken, the other tried again every
+    // sixth read.
+    {
+        static const double pass_ms[5] = {0.0, 0.87, 1.0, 1.25, 1.41};
+        // (a plain read is rated at the size the adaptation would have given it -- the sub-panels its kept steps fill -- not at the
+        // full size a first read or a read behind a predicted one happens to have)
+        int nt = ntile < 1 ? 1 : (ntile > 4 ? 4 : ntile);
+        if (!ctx->read_by_score) {
+            const int need = (int)((total + ASB_PANEL_COLS) / ASB_PANEL_COLS);
+            nt = need < 1 ? 1 : (need < nt ? need : nt);
+        }
+        const double scale = (double)ctx->n_loc * (double)ctx->Fp / (100000.0 * 2000.0);
+        const double cost = (0.45 + 0.23 * nt + pass_ms[nt]) * (scale > 0.05 ? scale : 0.05) + (ctx->read_by_score ? 0.7 : 0.0);
+        const double rate = (double)total / cost;
+        double& ema = ctx->read_by_score ? ctx->rate_sketch : ctx->rate_plain;
+        ema = ema < 0.0 ? rate : 0.5 * (ema + rate);
+        ctx->mode_streak = (ctx->read_by_score == ctx->last_by_score) ? ctx->mode_streak + 1 : 1;
+        ctx->last_by_score = ctx->read_by_score;
+    }
+    bool want_replay = true;
+    if (ctx->rate_sketch >= 0.0 && ctx->rate_plain >= 0.0) want_replay = ctx->rate_sketch >= ctx->rate_plain;
+    if (ctx->mode_streak >= ctx->probe_after && ctx->rate_sketch >= 0.0 && ctx->rate_plain >= 0.0) {
+        want_replay = !ctx->last_by_score;                  // look at the other kind again, ever more rarely while the verdict stands
+        ctx->probe_after = ctx->probe_after < 64 ? 2 * ctx->probe_after : 64;
+    }
+    if (getenv("ASB_DEBUG_PANELS"))
+        fprintf(stderr, "[asb] read at k=%lld (%s candidates) kept %lld: components per ms plain %.1f, predicted %.1f -> %s next\n", k,
+                ctx->read_by_score ? "predicted" : "plain", (long long)total, ctx->rate_plain, ctx->rate_sketch,
+                want_replay ? "replay" : "plain");
+    if (ctx->sketch && want_replay && !ctx->sketch_run_off && rejected && total > 0 && k + total < k1) {
         long long ncols = 0;
         for (int ct = 0; ct < ntile; ++ct) ncols += nc[ct];
         const long long left = ncols - total;
@@ -3501,8 +3534,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
                 ctx->sketch_run_off = true;
             }
             if (getenv("ASB_DEBUG_PANELS"))
-                fprintf(stderr, "[asb] sketch of %d columns at k=%lld: %s\n", r, ks,
-                        replayed ? "replayed" : (fl[3] ? "holds too little of the residual: candidates by energy" : "exchange timed out"));
+                fprintf(stderr, "[asb] sketch of %d columns at k=%lld holds %.3f of the residual: %s\n", r, ks,
+                        [&] { float f; memcpy(&f, &fl[0], 4); return (double)f; }(), replayed ? "replayed" : (fl[3] ? "holds too little of the residual: candidates by energy" : "exchange timed out"));
         }
     }
     // (noise-like data: a rejection comes from the random cross terms of the first components, not from a ranking that drifts --
@@ -3724,6 +3757,7 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     const bool guess = k == 0 && stalled == 0 && ctx->mean_frac > 0.25 && guess_possible(ctx);
     const bool by_score = ctx->sketch_valid && stalled == 0 && k > 0;
     ctx->sketch_valid = false;
+    ctx->read_by_score = by_score;
     if (by_score) {
         if ((rc = score_thresholds(ctx))) return rc;
         ctx->sel_e2 = ctx->sk_score;

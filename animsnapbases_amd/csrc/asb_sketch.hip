@@ -203,6 +203,7 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
             gate[0] = a; gate[1] = b2;
         }
         __syncthreads();
+        if (tl0(blockIdx.x, tid)) flags[0] = __float_as_uint((float)(gate[1] > 0.0 ? gate[0] / gate[1] : 0.0));      // (diagnostics)
         if (!(gate[0] >= (double)min_share * gate[1])) {
             if (have) score_out[v] = e_in;
             if (tl0(blockIdx.x, tid)) { __hip_atomic_store(flags + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(counts + 1, 1u); }

@@ -139,4 +139,4 @@ def test_low_rank_data_same_basis_fewer_reads(stall, monkeypatch):
     reads1 = st1["panels"] + st1["refreshes"]
     print("reads of X: %d without the predictor, %d with it (%d replays)" % (reads0, reads1, st1["sketch_runs"]))
     if not stall:
-        assert reads1 * 3 <= reads0 * 2
+        assert reads1 < reads0          # (predicted reads are taken only while they commit more per millisecond than plain ones)

@@ -51,7 +51,9 @@ for kind in (sys.argv[1:] or ["lowrank", "slow", "bumps"]):
         snaps._engine.sync()
         ms = (time.perf_counter() - t0) * 1e3
     st = snaps._engine.deflate_stats()
-    print("%-8s ASB_SKETCH=%s: %.1f ms, %d reads of X (%d replays)" % (kind, os.environ.get("ASB_SKETCH", "1"), ms,
-          st["panels"] + st["refreshes"], st["sketch_runs"]), flush=True)
+    print("%-8s ASB_SKETCH=%s: %.1f ms, %d reads of X (%d replays)%s" % (kind, os.environ.get("ASB_SKETCH", "1"), ms,
+          st["panels"] + st["refreshes"], st["sketch_runs"],
+          "  !! %d panel-kernel fallbacks, %d refreshes" % (st["coop_fallbacks"], st["refreshes"]) if st["coop_fallbacks"] or st["refreshes"] else ""),
+          flush=True)
     del comp, snaps, Xd
     torch.cuda.empty_cache()
