@@ -140,3 +140,44 @@ def test_low_rank_data_same_basis_fewer_reads(stall, monkeypatch):
     print("reads of X: %d without the predictor, %d with it (%d replays)" % (reads0, reads1, st1["sketch_runs"]))
     if not stall:
         assert reads1 < reads0          # (predicted reads are taken only while they commit more per millisecond than plain ones)
+
+
+def test_two_contexts_replay_at_once():
+    """Two independent contexts, each on its own stream, run the same low-rank problem in two threads: their replay kernels
+    (one 512-thread block per CU each: 2 x 137 blocks here, more than the chip holds at once) and panel kernels can be in flight
+    together.  Whatever the scheduler does -- all blocks of a launch resident, or an exchange that times out and leaves the plain
+    selection / the two-kernel loop -- both must deliver the oracle's sequence and the same basis."""
+    import contextlib
+    import io
+    import threading
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    rng = np.random.default_rng(23)
+    F, N, K = 96, 70001, 48
+    verts = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=30, noise=1e-4, decay=0.9, seed=23)
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False, engine=HipEngine(0))
+                comp = posComponents(_param(K), snaps)
+                comp.deflate_mode = "project"
+                for _ in range(2):
+                    comp.compute_components_store_singvalues()
+            outs[i] = (comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), snaps._engine.deflate_stats())
+        except Exception as ex:          # noqa: BLE001 -- reported by the main thread
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for idx, comps, weigs, st in outs:
+        assert idx.tolist() == d["idx"].tolist()
+        comps, weigs = align_signs(comps, weigs, d["comps"])
+        assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+    print("replays: %d / %d, panel-kernel fallbacks: %d / %d" % (outs[0][3]["sketch_runs"], outs[1][3]["sketch_runs"],
+                                                               outs[0][3]["coop_fallbacks"], outs[1][3]["coop_fallbacks"]))
