@@ -432,14 +432,15 @@ extern "C" int asb_test_sketch_predict(asb_ctx* ctx, const double* cols, const d
     if (!ctx || !cols || !wn2 || !E || !scores || !pred || !status || n < 1 || r < 1 || r > SK_R || steps < 1 || steps > 64)
         return ASB_ERR_ARG;
     double *dc = nullptr, *dw = nullptr, *de = nullptr;
-    ASB_HIP(ctx, hipMalloc((void**)&dc, (size_t)r * 3 * n * sizeof(double)));
-    ASB_HIP(ctx, hipMalloc((void**)&dw, (size_t)r * sizeof(double)));
-    ASB_HIP(ctx, hipMalloc((void**)&de, (size_t)n * sizeof(double)));
-    ASB_HIP(ctx, hipMemcpy(dc, cols, (size_t)r * 3 * n * sizeof(double), hipMemcpyHostToDevice));
-    ASB_HIP(ctx, hipMemcpy(dw, wn2, (size_t)r * sizeof(double), hipMemcpyHostToDevice));
-    ASB_HIP(ctx, hipMemcpy(de, E, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    int rc = asb_sketch_predict(ctx, dc, 3 * n, dw, 1, de, n, r, steps);
-    if (rc == ASB_OK) {
+    auto body = [&]() -> int {
+        ASB_HIP(ctx, hipMalloc((void**)&dc, (size_t)r * 3 * n * sizeof(double)));
+        ASB_HIP(ctx, hipMalloc((void**)&dw, (size_t)r * sizeof(double)));
+        ASB_HIP(ctx, hipMalloc((void**)&de, (size_t)n * sizeof(double)));
+        ASB_HIP(ctx, hipMemcpy(dc, cols, (size_t)r * 3 * n * sizeof(double), hipMemcpyHostToDevice));
+        ASB_HIP(ctx, hipMemcpy(dw, wn2, (size_t)r * sizeof(double), hipMemcpyHostToDevice));
+        ASB_HIP(ctx, hipMemcpy(de, E, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        const int rc = asb_sketch_predict(ctx, dc, 3 * n, dw, 1, de, n, r, steps);
+        if (rc != ASB_OK) return rc;
         unsigned fl[4];
         long long pr[64];
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -448,7 +449,9 @@ extern "C" int asb_test_sketch_predict(asb_ctx* ctx, const double* cols, const d
         ASB_HIP(ctx, hipMemcpy(fl, ctx->sk_flags, sizeof(fl), hipMemcpyDeviceToHost));
         for (int t = 0; t < steps; ++t) pred[t] = pr[t];
         *status = fl[2] ? 1 : 0;
-    }
+        return ASB_OK;
+    };
+    const int rc = body();              // (the staging buffers go on every path)
     (void)hipFree(dc);
     (void)hipFree(dw);
     (void)hipFree(de);
