@@ -508,7 +508,11 @@ int asb_dense_spd_inverse(asb_ctx* ctx, double* Mx, int np) {
     const bool timing = getenv("ASB_DEBUG_GJ") != nullptr;
     if (timing) (void)hipStreamSynchronize(ctx->stream);
     const auto t_start = std::chrono::steady_clock::now();
-    if (np <= GJ_BK || !sym) {
+    if (np <= GJ_BK && sym) {
+        // one pivot block: the Schur step over the tiled in-LDS inverse alone (SPLOCS' K x K systems: 40 - 130 us)
+        if ((rc = asb_alloc(ctx, &ctx->dn_sym, (size_t)5 * 128 * 128))) return rc;
+        if ((rc = pivot_block_inverse(ctx, Mx, np, ctx->dn_sym))) return rc;
+    } else if (!sym) {
         if ((rc = spd_inverse_full(ctx, Mx, np))) return rc;
     } else {
         if ((rc = asb_alloc(ctx, &ctx->dn_sym, (size_t)3 * GJ_BK * np + (size_t)GJ_BK * GJ_BK + (size_t)5 * 128 * 128))) return rc;

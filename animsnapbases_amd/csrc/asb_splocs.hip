@@ -154,47 +154,6 @@ __global__ __launch_bounds__(256) void k_centres(const double* __restrict__ C, l
     if (threadIdx.x == 0) { idx_out[blockIdx.x] = v0 + sh_i[0]; val_out[blockIdx.x] = sh_d[0]; }
 }
 
-// --------------------------------------------------------------------------------------
-// k_cholinv: Ginv = (G + rho I)^-1 through a Cholesky factorisation, one block (K <= 128).
-// status[0] = 1 when a pivot is not positive.
-// --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cholinv(const double* __restrict__ G, double rho, int K,
-                                                 double* __restrict__ Ginv, int* __restrict__ status) {
-    extern __shared__ double L[];        // K x K
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int e = tid; e < K * K; e += nt) L[e] = G[e] + ((e / K == e % K) ? rho : 0.0);
-    __syncthreads();
-    for (int j = 0; j < K; ++j) {
-        const double d = L[j * K + j];
-        if (!(d > 0.0)) {
-            if (tid == 0) status[0] = 1;
-            return;
-        }
-        const double sq = sqrt(d);
-        __syncthreads();
-        for (int i = j + tid; i < K; i += nt) L[i * K + j] = (i == j) ? sq : L[i * K + j] / sq;
-        __syncthreads();
-        for (int e = tid; e < (K - j - 1) * (K - j - 1); e += nt) {
-            const int i = j + 1 + e / (K - j - 1), c = j + 1 + e % (K - j - 1);
-            if (c <= i) L[i * K + c] -= L[i * K + j] * L[c * K + j];
-        }
-        __syncthreads();
-    }
-    // columns of the inverse: thread c solves L y = e_c, L^T x = y, entirely in its own column of
-    // global scratch (Ginv)
-    for (int c = tid; c < K; c += nt) {
-        for (int i = 0; i < K; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) s -= L[i * K + j] * Ginv[(long long)j * K + c];
-            Ginv[(long long)i * K + c] = s / L[i * K + i];
-        }
-        for (int i = K - 1; i >= 0; --i) {
-            double s = Ginv[(long long)i * K + c];
-            for (int j = i + 1; j < K; ++j) s -= L[j * K + i] * Ginv[(long long)j * K + c];
-            Ginv[(long long)i * K + c] = s / L[i * K + i];
-        }
-    }
-}
 
 // out (np x np) = [G + rho I, 0; 0, I]
 __global__ __launch_bounds__(256) void k_pad_spd(const double* __restrict__ G, double rho, int K, int np, double* __restrict__ out) {
@@ -433,14 +392,7 @@ static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
         if (rc) return rc;
     }
     ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
-    if (K <= 128) {
-        if ((size_t)K * K * sizeof(double) > 48 * 1024)
-            ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_cholinv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(K * K * sizeof(double))));
-        hipLaunchKernelGGL(k_cholinv, dim3(1), dim3(256), (size_t)K * K * sizeof(double), ctx->stream, s->G, rho, (int)K,
-                           s->Ginv, s->status);
-        ASB_CHECK_LAUNCH(ctx);
-    } else {            // larger K: blocked Gauss-Jordan on f64 MFMA (asb_dense.hip) on the matrix padded to a multiple of 16
+    {                   // blocked Gauss-Jordan on the matrix padded to a multiple of 16 (asb_dense.hip: one in-LDS pivot block up to K = 256)
         const int np = (int)((K + 15) / 16 * 16);
         int rc2;
         if ((rc2 = asb_alloc(ctx, &ctx->dn_test, (size_t)np * np))) return rc2;
