@@ -12,6 +12,8 @@
 // needs only the next iteration's P and M.  Support maps (Lambda) come from the host geodesics.
 #include "asb_kernels.h"
 
+#include <cstdlib>
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // defined in asb_project.hip
@@ -185,6 +187,91 @@ __global__ __launch_bounds__(256) void k_admm_prox(const double* __restrict__ C,
         const double z0 = x0 * shrink, z1 = x1 * shrink, z2 = x2 * shrink;
         Z[3 * e] = z0; Z[3 * e + 1] = z1; Z[3 * e + 2] = z2;
         U[3 * e] = u0 + c0 - z0; U[3 * e + 1] = u1 + c1 - z1; U[3 * e + 2] = u2 + c2 - z2;
+    }
+}
+
+// The whole inner ADMM loop in ONE launch for K <= 64 (round 3).  Its three steps -- rhs = c + rho (Z - U), C = (G + rho I)^-1 rhs,
+// Z = prox(C + U), U += C - Z (:171-178) -- couple nothing but the K components of ONE vertex's three columns, so a block takes 16
+// vertices (48 columns: 384 contiguous bytes per component row) through all iterations: Z, U, c in registers (thread = component
+// row k, four vertices), the K x 48 right-hand side and result through LDS, the K x K product on the f64 matrix cores (wave w: rows
+// 16 w .. 16 w + 15 of the inverse as its A operand, in registers for the whole launch).  20 x 10 x (16 + 64 + 17) us of launches
+// per config-3 run become 20 launches.
+__global__ __launch_bounds__(256) void k_admm_fused(const double* __restrict__ c, double* __restrict__ Z, double* __restrict__ U,
+                                                    const double* __restrict__ Ginv, const double* __restrict__ Lambda, double rho,
+                                                    int K, long long n_vert, int n_iter) {
+    __shared__ double rhs_s[64][48 + 1];
+    __shared__ double c_s[64][48 + 1];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const long long n3 = 3 * n_vert, v0 = (long long)blockIdx.x * 16;
+    // MFMA A operand: Ginv[16 w + (l & 15)][4 s + (l >> 4)], s = 0 .. 15 (rows / columns beyond K are zero)
+    double ga[16];
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) {
+        const int r = 16 * w + (l & 15), cidx = 4 * sidx + (l >> 4);
+        ga[sidx] = (r < K && cidx < K) ? Ginv[(long long)r * K + cidx] : 0.0;
+    }
+    // state: component row k = tid / 4, vertices v0 + 4 (tid % 4) .. + 3 (12 contiguous columns)
+    const int k = tid >> 2, vq = (tid & 3) * 4;
+    double zc[12], uc[12], cc[12], lam[4];
+    const bool krow = k < K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long v = v0 + vq + q;
+        const bool on = krow && v < n_vert;
+        lam[q] = on ? Lambda[(long long)k * n_vert + v] : 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const long long e = (long long)k * n3 + 3 * v + d;
+            zc[3 * q + d] = on ? Z[e] : 0.0;
+            uc[3 * q + d] = on ? U[e] : 0.0;
+            cc[3 * q + d] = on ? c[e] : 0.0;
+        }
+    }
+    const double beta = 1.0 / rho;
+    for (int it = 0; it < n_iter; ++it) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) rhs_s[k][3 * vq + j] = cc[j] + rho * (zc[j] - uc[j]);
+        __syncthreads();
+        d4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double b = rhs_s[4 * sidx + (l >> 4)][16 * j + (l & 15)];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[sidx], b, acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c_s[16 * w + (l >> 4) + 4 * q][16 * j + (l & 15)] = acc[j][q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double c0 = c_s[k][3 * (vq + q)], c1 = c_s[k][3 * (vq + q) + 1], c2 = c_s[k][3 * (vq + q) + 2];
+            const double u0 = uc[3 * q], u1 = uc[3 * q + 1], u2 = uc[3 * q + 2];
+            const double x0 = c0 + u0, x1 = c1 + u1, x2 = c2 + u2;
+            const double len = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+            const double shrink = fmax(0.0, 1.0 - beta * lam[q] / len);      // len == 0 -> -inf -> 0
+            const double z0 = x0 * shrink, z1 = x1 * shrink, z2 = x2 * shrink;
+            zc[3 * q] = z0; zc[3 * q + 1] = z1; zc[3 * q + 2] = z2;
+            uc[3 * q] = u0 + c0 - z0; uc[3 * q + 1] = u1 + c1 - z1; uc[3 * q + 2] = u2 + c2 - z2;
+        }
+        // (the next iteration's first writes go to rhs_s, which nobody reads any more; c_s is rewritten behind the next barrier)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long v = v0 + vq + q;
+        if (krow && v < n_vert) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const long long e = (long long)k * n3 + 3 * v + d;
+                Z[e] = zc[3 * q + d];
+                U[e] = uc[3 * q + d];
+            }
+        }
     }
 }
 
@@ -406,6 +493,12 @@ static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
     const long long n = (long long)K * n3;
     const int eg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     const int pg = (int)((kn + 255) / 256 < 4096 ? (kn + 255) / 256 : 4096);
+    static const int fused = getenv("ASB_ADMM_FUSED") ? atoi(getenv("ASB_ADMM_FUSED")) : 1;
+    if (fused && K <= 64 && n_iter > 0) {
+        hipLaunchKernelGGL(k_admm_fused, dim3((unsigned)((ctx->n_loc + 15) / 16)), dim3(256), 0, ctx->stream, s->c, s->Z, s->U, s->Ginv,
+                           s->Lambda, rho, (int)K, (long long)ctx->n_loc, n_iter);
+        n_iter = 0;
+    }
     for (int it = 0; it < n_iter; ++it) {
         hipLaunchKernelGGL(k_admm_rhs, dim3(eg), dim3(256), 0, ctx->stream, s->c, s->Z, s->U, rho, n, s->rhs);
         int rc = asb_gemm_tn(ctx, s->Ginv, K, s->rhs, n3, K, (int)K, (int)n3, s->C);      // C = (G + rho I)^-1 rhs
