@@ -215,6 +215,7 @@ struct asb_ctx {
     double* ovec = nullptr;       // (3, K, K) eigenvectors
     double* osing = nullptr;      // (3, K) singular values
     double* la_vtmp = nullptr;
+    double* kk_tmp = nullptr;     // K x K transposed factor (asb_combine_rows)
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     int* la_status = nullptr;
     double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
@@ -286,6 +287,8 @@ int asb_project_results(asb_ctx* ctx, double* comps, double* weigs, int64_t* idx
     } while (0)
 
 // C = beta C + alpha A B (row-major, even dimensions; asb_dense.hip) and the in-place SPD inverse built on it
+bool asb_combine_rows_ok(const asb_ctx* ctx);          // asb_linalg.hip
+int asb_combine_rows(asb_ctx* ctx, const double* T_dev);
 int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M,
                 int N, int Kc, double alpha, double beta, int tri = 0);
 int asb_dense_spd_inverse(asb_ctx* ctx, double* M, int np);

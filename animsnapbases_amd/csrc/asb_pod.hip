@@ -172,10 +172,14 @@ static int qr_apply(asb_ctx* ctx, const double* G_dev, int joint) {
             return rc;
         }
     }
-    for (int l = 0; l < 3; ++l)
-        if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, ctx->ovec + (joint ? 0 : (size_t)l * K * K), K, K, (int)n, (int)K,
-                                ctx->comps2 + l, 3, 3 * n)))
-            return rc;
+    if (joint && asb_combine_rows_ok(ctx)) {
+        if ((rc = asb_combine_rows(ctx, ctx->ovec))) return rc;
+    } else {
+        for (int l = 0; l < 3; ++l)
+            if ((rc = asb_gemm_tn_s(ctx, ctx->comps + l, 3 * n, 3, ctx->ovec + (joint ? 0 : (size_t)l * K * K), K, K, (int)n, (int)K,
+                                    ctx->comps2 + l, 3, 3 * n)))
+                return rc;
+    }
     int st[4];
     ASB_HIP(ctx, hipMemcpyAsync(st, ctx->la_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
