@@ -295,6 +295,7 @@ int asb_dense_spd_inverse(asb_ctx* ctx, double* M, int np);
 int asb_deflate_apply_dev(asb_ctx* ctx, int64_t k, const double* s_dev);      // asb_deflate.hip
 // G = X^T X (n x n, both triangles) for a tall row-major X: LDS-tiled f64 MFMA kernel (asb_linalg.hip)
 int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n, double* out);
+int asb_gemm_tn_big(asb_ctx* ctx, const double* X, long long ldx, const double* Y, long long ldy, long long R, int I, int J, double* out);
 
 #define ASB_CHECK_LAUNCH(ctx) ASB_HIP(ctx, hipGetLastError())
 

@@ -63,13 +63,25 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const double* __restrict__ pa
 #define SY_BM 128
 #define SY_KC 16
 #define SY_LD 144
+// SYM = false (round 3): the same tiling for a general Out (n x nj) = X^T Y, Y = R rows of stride ldy -- every tile, no mirror
+// (B = Q^T A of the POD's Rayleigh-Ritz step: 345 GFLOP that the one-wave-per-tile k_gemm_tn did at 15 TFLOP/s).
+template <bool SYM>
 __global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X, long long ld, long long R, int n, long long slab,
-                                                   double* __restrict__ part, int nb) {
+                                                   double* __restrict__ part, int nb, const double* __restrict__ Y = nullptr,
+                                                   long long ldy = 0, int nj = 0, int nbj = 0) {
     __shared__ double As[2][SY_KC][SY_LD];
     __shared__ double Bs[2][SY_KC][SY_LD];
-    int t = blockIdx.x, ib = 0;
-    while (t >= nb - ib) { t -= nb - ib; ++ib; }
-    const int jb = ib + t;
+    int t = blockIdx.x, ib = 0, jb;
+    if (SYM) {
+        while (t >= nb - ib) { t -= nb - ib; ++ib; }
+        jb = ib + t;
+        Y = X;
+        ldy = ld;
+        nj = n;
+    } else {
+        ib = t / nbj;
+        jb = t % nbj;
+    }
     const int i0 = ib * SY_BM, j0 = jb * SY_BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
@@ -77,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X
     long long r_end = r_begin + slab;
     if (r_end > R) r_end = R;
     const int ca = i0 + 2 * lane, cb = j0 + 2 * lane;
-    const bool oka = ca < ld, okb = cb < ld;
+    const bool oka = ca < ld, okb = cb < ldy;
     double2 ra[4], rb[4];
     auto fetch = [&](long long r0) {
 #pragma unroll
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X
             const long long r = r0 + wave + 4 * q;
             const bool in = r < r_end;
             ra[q] = (in && oka) ? *reinterpret_cast<const double2*>(X + r * ld + ca) : make_double2(0.0, 0.0);
-            rb[q] = (in && okb) ? *reinterpret_cast<const double2*>(X + r * ld + cb) : make_double2(0.0, 0.0);
+            rb[q] = (in && okb) ? *reinterpret_cast<const double2*>(Y + r * ldy + cb) : make_double2(0.0, 0.0);
         }
     };
     auto stash = [&](int buf) {
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X
         __syncthreads();
         cur ^= 1;
     }
-    double* o = part + (long long)blockIdx.y * n * n;
+    double* o = part + (long long)blockIdx.y * n * nj;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_tn(const double* __restrict__ X
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int oi = i0 + wi * 64 + x * 16 + g + 4 * q, oj = j0 + wj * 64 + y * 16 + li;
-                if (oi < n && oj < n) o[(long long)oi * n + oj] = acc[x][y][q];
+                if (oi < n && oj < nj) o[(long long)oi * nj + oj] = acc[x][y][q];
             }
 }
 
@@ -168,8 +180,38 @@ int asb_syrk_tn(asb_ctx* ctx, const double* X, long long ld, long long R, int n,
         if (rc) return rc;
         ctx->la_part_cap = need;
     }
-    hipLaunchKernelGGL(k_syrk_tn, dim3(tiles, S), dim3(256), 0, ctx->stream, X, ld, R, n, slab, ctx->la_part, nb);
+    hipLaunchKernelGGL(k_syrk_tn<true>, dim3(tiles, S), dim3(256), 0, ctx->stream, X, ld, R, n, slab, ctx->la_part, nb);
     hipLaunchKernelGGL(k_syrk_finish, dim3(2048), dim3(256), 0, ctx->stream, ctx->la_part, S, n, out);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int S, long long total, double* __restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int q = 0; q < S; ++q) s += part[(long long)q * total + e];
+        out[e] = s;
+    }
+}
+// Out (I x J, row-major) = X^T Y for tall X (R x I, stride ldx) and Y (R x J, stride ldy); even strides, 16-byte aligned rows
+int asb_gemm_tn_big(asb_ctx* ctx, const double* X, long long ldx, const double* Y, long long ldy, long long R, int I, int J, double* out) {
+    const int nbi = (I + SY_BM - 1) / SY_BM, nbj = (J + SY_BM - 1) / SY_BM, tiles = nbi * nbj;
+    int S = (8 * 512 + tiles - 1) / tiles;
+    const long long maxS = (R + 511) / 512;
+    if (S > maxS) S = (int)(maxS < 1 ? 1 : maxS);
+    if (S > 64) S = 64;
+    long long slab = ((R + S - 1) / S + SY_KC - 1) / SY_KC * SY_KC;
+    if (slab < SY_KC) slab = SY_KC;
+    S = (int)((R + slab - 1) / slab);
+    if (S < 1) S = 1;
+    const size_t need = (size_t)S * I * J;
+    if (need > ctx->la_part_cap) {
+        int rc = asb_alloc(ctx, &ctx->la_part, need);
+        if (rc) return rc;
+        ctx->la_part_cap = need;
+    }
+    hipLaunchKernelGGL(k_syrk_tn<false>, dim3(tiles, S), dim3(256), 0, ctx->stream, X, ldx, R, I, slab, ctx->la_part, nbi, Y, ldy, J, nbj);
+    hipLaunchKernelGGL(k_sum_parts, dim3(2048), dim3(256), 0, ctx->stream, ctx->la_part, S, (long long)I * J, out);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }

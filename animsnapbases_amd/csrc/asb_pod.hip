@@ -66,7 +66,11 @@ extern "C" int asb_pod_project(asb_ctx* ctx, double* B_dev, double* B_host) {
         if ((rc = asb_alloc(ctx, &ctx->pod_v, (size_t)F * K))) return rc;
         B = ctx->pod_v;
     }
-    if ((rc = asb_gemm_tn(ctx, ctx->oct, K, ctx->X, ctx->Fp, n3, (int)K, (int)F, B))) return rc;
+    // (K >= 64, even: the 128 x 128-tile kernel of the Gram matrix with two operands -- 345 GFLOP at config 5)
+    static const int big = getenv("ASB_ORTH_SYRK") ? atoi(getenv("ASB_ORTH_SYRK")) : 1;
+    if (big && K >= 64 && !(K & 1)) rc = asb_gemm_tn_big(ctx, ctx->oct, K, ctx->X, ctx->Fp, n3, (int)K, (int)F, B);
+    else rc = asb_gemm_tn(ctx, ctx->oct, K, ctx->X, ctx->Fp, n3, (int)K, (int)F, B);
+    if (rc) return rc;
     if (B_host) {
         ASB_HIP(ctx, hipMemcpyAsync(B_host, B, (size_t)K * F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
