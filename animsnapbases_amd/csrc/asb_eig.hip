@@ -362,28 +362,35 @@ extern "C" int asb_sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double*
 #define TB_NB 64
 // T factors of all groups in one launch (block b: reflectors j0 = b TB_NB ...): G = V^T V in LDS, then LAPACK's larft
 // recurrence T_ii = tau_i, T[0:i, i] = -tau_i T[0:i, 0:i] G[0:i, i] (a reflector with tau = 0 is the identity)
-__global__ __launch_bounds__(256) void k_td_wy_t(const double* __restrict__ A, const double* __restrict__ tau, int n, int nrefl,
+// G_b = V_b^T V_b of every group, 16 blocks per group (each a slice of the 64 x 64 pairs): one WAVE per pair (i, m >= i), its
+// lanes along the rows (coalesced), ordered wave sum.  (Round 3: this part alone took 6.6 ms when each group was one block.)
+__global__ __launch_bounds__(256) void k_td_wy_g(const double* __restrict__ A, int n, int nrefl, double* __restrict__ G_all) {
+    const int b = blockIdx.x, sl = blockIdx.y, j0 = b * TB_NB, tid = threadIdx.x;
+    const int nbb = nrefl - j0 < TB_NB ? nrefl - j0 : TB_NB;
+    const int lane = tid & 63, wv = tid >> 6;
+    double* G = G_all + (size_t)b * TB_NB * TB_NB;
+    for (int e = sl * 4 + wv; e < TB_NB * TB_NB; e += 4 * gridDim.y) {
+        const int i = e / TB_NB, m = e % TB_NB;
+        double acc = 0.0;
+        if (i < nbb && m < nbb && m >= i) {
+            const double* vi = A + (long long)(j0 + i) * n;
+            const double* vm = A + (long long)(j0 + m) * n;
+            for (int c = j0 + m + 1 + lane; c < n; c += 64) acc += vi[c] * vm[c];
+            acc = wave_sum(acc);
+        }
+        if (lane == 0) G[e] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_td_wy_t(const double* __restrict__ G_all, const double* __restrict__ tau, int n, int nrefl,
                                                  double* __restrict__ T_all) {
     __shared__ double G[TB_NB][TB_NB + 1];
     __shared__ double Ts[TB_NB][TB_NB + 1];
     __shared__ double col[TB_NB];
     const int b = blockIdx.x, j0 = b * TB_NB, tid = threadIdx.x;
     const int nbb = nrefl - j0 < TB_NB ? nrefl - j0 : TB_NB;
-    // v_{j0+i}[c] = A[j0+i][c] for c >= j0+i+1, 0 before; G[i][m] = v_i . v_m (c >= max start)
-    for (int e = tid; e < TB_NB * TB_NB; e += 256) Ts[e / TB_NB][e % TB_NB] = 0.0;
-    {   // one WAVE per pair (i, m >= i), its lanes along the rows (coalesced), ordered wave sum
-        const int lane = tid & 63, wv = tid >> 6;
-        for (int e = wv; e < TB_NB * TB_NB; e += 4) {
-            const int i = e / TB_NB, m = e % TB_NB;
-            double acc = 0.0;
-            if (i < nbb && m < nbb && m >= i) {
-                const double* vi = A + (long long)(j0 + i) * n;
-                const double* vm = A + (long long)(j0 + m) * n;
-                for (int c = j0 + m + 1 + lane; c < n; c += 64) acc += vi[c] * vm[c];
-                acc = wave_sum(acc);
-            }
-            if (lane == 0) G[i][m] = acc;
-        }
+    for (int e = tid; e < TB_NB * TB_NB; e += 256) {
+        Ts[e / TB_NB][e % TB_NB] = 0.0;
+        G[e / TB_NB][e % TB_NB] = G_all[(size_t)b * TB_NB * TB_NB + e];
     }
     __syncthreads();
     for (int i = 0; i < nbb; ++i) {
@@ -416,13 +423,15 @@ static int sym_backtransform_blocked(asb_ctx* ctx, const double* A, int n, const
     const double* tau = ctx->td_work + (size_t)5 * n;
     const int nrefl = n - 2, nblk = (nrefl + TB_NB - 1) / TB_NB;
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->td_wy, (size_t)nblk * TB_NB * TB_NB + (size_t)2 * TB_NB * n + (size_t)2 * TB_NB * k))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->td_wy, (size_t)2 * nblk * TB_NB * TB_NB + (size_t)2 * TB_NB * n + (size_t)2 * TB_NB * k))) return rc;
+    double* Gw = ctx->td_wy + (size_t)nblk * TB_NB * TB_NB + (size_t)2 * TB_NB * n + (size_t)2 * TB_NB * k;
     double* T_all = ctx->td_wy;
     double* Vp = T_all + (size_t)nblk * TB_NB * TB_NB;
     double* VpT = Vp + (size_t)TB_NB * n;
     double* W1 = VpT + (size_t)TB_NB * n;
     double* W2 = W1 + (size_t)TB_NB * k;
-    hipLaunchKernelGGL(k_td_wy_t, dim3(nblk), dim3(256), 0, ctx->stream, A, tau, n, nrefl, T_all);
+    hipLaunchKernelGGL(k_td_wy_g, dim3(nblk, 16), dim3(256), 0, ctx->stream, A, n, nrefl, Gw);
+    hipLaunchKernelGGL(k_td_wy_t, dim3(nblk), dim3(256), 0, ctx->stream, Gw, tau, n, nrefl, T_all);
     ASB_HIP(ctx, hipMemcpyAsync(V, Z, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     for (int b = nblk - 1; b >= 0; --b) {           // Q = Q_0 Q_1 ... : the last group acts first
         hipLaunchKernelGGL(k_td_wy_panel, dim3(256), dim3(256), 0, ctx->stream, A, n, nrefl, b * TB_NB, Vp, VpT);
