@@ -23,6 +23,18 @@ rng = np.random.default_rng(77)
 def make():
     if kind == "random":
         X = rng.uniform(-1, 1, (3 * N, F))
+    elif kind == "bumps":
+        r = 50
+        rest = rng.uniform(0, 1, (N, 3))
+        modes = np.empty((r, 3 * N))
+        for j in range(r):
+            c = rest[rng.integers(N)]
+            rad = 0.1 + 0.25 * rng.uniform()
+            dvec = rng.standard_normal(3)
+            modes[j] = (np.exp(-((rest - c) ** 2).sum(1) / rad ** 2)[:, None] * (dvec / np.linalg.norm(dvec))[None] * 0.1).ravel()
+        coef = rng.standard_normal((F, r)) * 0.9 ** np.arange(r)[None]
+        X = (coef @ modes).T + rng.standard_normal((3 * N, 1))
+        X += 1e-4 * rng.standard_normal((3 * N, F))
     else:
         r = 50
         decay = 0.9 if kind == "lowrank" else 0.97
@@ -168,6 +180,70 @@ def run(method):
         log.append(kept)
     return reads, log
 
+
+PASS_MS = {1: 0.87, 2: 1.0, 3: 1.25, 4: 1.41}
+
+
+def cost_ms(sub, replay_steps=0):
+    return 0.45 + 0.23 * sub + PASS_MS[sub] + 0.7 * replay_steps / 64.0
+
+
+def run_short(steps_per_read):
+    """persistent sketch (old directions deflated by the kept components, re-orthogonalised beside the new ones), reads of
+    `steps_per_read` steps; candidates by the replay's scores.  Returns reads, kept per read and the modelled time."""
+    k, reads, ms = 0, 0, 0.0
+    W = np.zeros((0, F)); C = np.zeros((0, 3 * N)); E = E0.copy()
+    D = None
+    log = []
+    while k < K:
+        steps = min(steps_per_read, K - k)
+        sub = (steps + 15) // 16
+        if D is not None and D.shape[0] >= 4:
+            Zc = (X @ D.T).T - (D @ W.T) @ C if len(W) else (X @ D.T).T
+            score, _ = sketch_greedy(Zc, E, steps)
+            cand = np.argpartition(-score, M_CAND)[:M_CAND]
+            ms += cost_ms(sub, steps)
+        else:
+            cand = np.argpartition(-E, M_CAND)[:M_CAND]
+            ms += cost_ms(sub)
+        rr = rows_of(cand)
+        Rc = (X[rr] - C[:, rr].T @ W).reshape(len(cand), 3, F)
+        win, Wl, et = cand_greedy(Rc, steps)
+        Cl = (X @ Wl.T).T
+        reads += 1
+        inside = np.zeros(N, bool); inside[cand] = True
+        Et = E.copy(); kept = steps
+        for t in range(steps):
+            if (Et[~inside] >= et[t]).any():
+                kept = t
+                break
+            Et = Et - (Cl[t] ** 2).reshape(N, 3).sum(1)
+        if kept == 0:
+            v = int(np.argmax(E))
+            R = X[3 * v:3 * v + 3] - C[:, 3 * v:3 * v + 3].T @ W
+            w = np.linalg.svd(R, full_matrices=False)[2][0]
+            Wl, Cl, kept = w[None], (X @ w)[None], 1
+            reads += 1
+            ms += cost_ms(1)
+        for t in range(kept):
+            E = E - (Cl[t] ** 2).reshape(N, 3).sum(1)
+        parts = [Wl[kept:]] if kept < len(Wl) else []
+        if D is not None:
+            Wk = Wl[:kept]
+            parts.append(D - (D @ Wk.T) @ Wk)
+        D = orth_rows(np.vstack(parts))[:RMAX] if parts else None
+        W = np.vstack([W, Wl[:kept]]); C = np.vstack([C, Cl[:kept]])
+        k += kept
+        log.append(kept)
+    return reads, log, ms
+
+
+if os.environ.get("SHORT"):
+    for spr in (16, 32, 64):
+        t0 = time.time()
+        reads, log, ms = run_short(spr)
+        print("%s persistent sketch, %d-step reads: reads %d, modelled %.1f ms, kept %s (%.0f s)" % (kind, spr, reads, ms, log, time.time() - t0), flush=True)
+    sys.exit(0)
 
 for method in (os.environ.get("METHODS", "energy,sketch,sketch2").split(",")):
     t0 = time.time()
