@@ -51,7 +51,11 @@ PROTOTYPES = {
     "asb_deflate_residual_norm2": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "asb_deim_block_residual_st": (c_int, [ctypes.c_void_p, c_i64, c_int, c_dp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64),
                                            ctypes.POINTER(c_dbl)]),
+    "asb_deflate_reserve": (c_int, [ctypes.c_void_p, c_i64]),
     "asb_components_stream": (c_int, [ctypes.c_void_p, c_int]),
+    "asb_components_stream_into": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64]),
+    "asb_host_alloc": (c_int, [c_i64, ctypes.POINTER(ctypes.c_void_p)]),
+    "asb_host_free": (c_int, [ctypes.c_void_p]),
     "asb_components_pinned": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "asb_panel_scale": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_dbl]),
     "asb_panel_hist": (c_int, [ctypes.c_void_p, c_int, c_dp]),
@@ -93,6 +97,8 @@ PROTOTYPES = {
     "asb_deflate_coop_fallbacks": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_sketch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "asb_project_switch_residual": (c_int, [ctypes.c_void_p, c_i64]),
+    "asb_deflate_switch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_panel_guess_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(c_int)]),
     "asb_panel_guess_begin": (c_int, [ctypes.c_void_p, c_int]),

@@ -389,8 +389,12 @@ class constraintsComponents:  # Components == bases
         tol = float(self.param.bases_R_tol)
         # every deflation removes one direction of frame space from the whole residual: F of them empty it in exact
         # arithmetic; what a tolerance above rounding level needs is bounded by that plus one sweep over the blocks
+        # (cap is only the loop bound: the basis and weight buffers start small and grow geometrically with the components
+        # actually computed -- asb_deflate_reserve -- as the reference's lists do; cap components of e p x 3 doubles each
+        # would be (e p)^2 x 24 bytes up front)
         cap = int(ns.frs) + p * int(ns.num_constained_elements) + p
-        eng.deflate_begin(cap, False, _lib.DEFLATE_RESIDUAL)
+        room = min(cap, max(4 * p, 64))
+        eng.deflate_begin(room, False, _lib.DEFLATE_RESIDUAL)
         S_v_idx, S_ele_idns, meas = [], [], []
         n_done = bases_count = 0
         normR = np.sqrt(max(eng.residual_norm2(), 0.0))
@@ -404,6 +408,9 @@ class constraintsComponents:  # Components == bases
             for idx in range(len(elems)):
                 if n_done + p > cap:
                     raise ArithmeticError("the residual does not fall below bases_R_tol = %g within %d components" % (tol, cap))
+                if n_done + p > room:
+                    room = min(cap, max(2 * room, n_done + p))
+                    eng.deflate_reserve(room)
                 S_ele_idns.append(idx)
                 sigma = []
                 for i in range(p):
@@ -823,8 +830,8 @@ class constraintsComponents:  # Components == bases
                 coef = np.empty((3, kp, p))
                 for i in range(3):          # (:662-668: more rows than columns possible -- least squares, as the reference)
                     coef[i] = np.linalg.lstsq(rows[:, :kp, i], rows[:, kp:kp + p, i], rcond=None)[0]
-            v_interpolate, val, _ = eng.deim_block_step_st(k, p, coef)
-            if k > 0 and np.sqrt(max(val, 0.0)) <= 1e-8:     # np.allclose(S^T r, 0) (:677): no row of S^T r above 1e-8
+            v_interpolate, val, am = eng.deim_block_step_st(k, p, coef)
+            if k > 0 and am <= 1e-8:     # np.allclose(S^T r, 0) (:677): no ENTRY of S^T r above 1e-8 (am = the largest |entry|)
                 print("ERROR!: zero residual!!")
                 return
             self.geom_interpol_verts.append(v_interpolate)

@@ -84,6 +84,7 @@ struct asb_ctx {
     int dl_enabled = 0;
     double* dl_host = nullptr;
     size_t dl_host_count = 0;
+    int dl_host_owned = 1;            // 0: the caller's buffer (asb_components_stream_into): never freed here
     hipStream_t dl_stream = nullptr;
     hipEvent_t dl_event = nullptr;
     long long dl_done = 0;
@@ -97,6 +98,7 @@ struct asb_ctx {
     double* st_data = nullptr;
     long long st_rows = 0, st_cols = 0, st_nnz = 0;
     double* st_energy = nullptr;      // (st_rows) squared row norms of S^T M
+    double* st_amax = nullptr;        // (st_rows) largest |entry| per row of S^T M
     double* st_resid = nullptr;       // (n_loc, 3 p) residual block of the position-space interpolation error
     unsigned* coop_bar = nullptr;     // k_panel_multi: flags [-, abort, too many candidates, -] + debug timestamps
     double* coop_rec = nullptr;       // (2, grid) records {e, lam, wn2, slot}
@@ -182,8 +184,18 @@ struct asb_ctx {
     int sub_first = 4;                     // sub-panels of the first read (ASB_SUB_FIRST); then adapted: sub_cur
     int sub_cur = 0;
     int sub_ntile = 0;                     // tiles of the read in progress (multi-rank steps: asb_panel_sub_*)
+    int chain_timed_out = 0;               // the last one-launch run of a read's sub-panels met a poll that did not complete
+    // the read in progress of the multi-rank driver (asb_panel_read_*): its tiles, whether its pass is already enqueued
+    long long rd_k0 = 0;
+    int rd_ntile = 0, rd_nc[8] = {0}, rd_proven[8] = {0}, rd_rgrid = 0;
+    double* rd_words = nullptr;            // (8) per tile: columns that stand on this shard; [ASB_MAX_SUB]: status
     int sub_budget[8] = {16, 16, 16, 16, 16, 16, 16, 16};      // steps given to the later sub-panels (adapted to what the last ones kept)
     int64_t n_panels = 0, n_refresh = 0;
+    // stall cliff: a run whose reads of X commit fewer than 3/4 of a component each (K beyond the numerical rank: nothing is
+    // provable at rounding level, every panel ends in an exact refresh) continues in the residual loop (asb_project_switch_residual)
+    int stall_fallback = 1;                // ASB_STALL_FALLBACK=0: keep grinding through panels
+    int64_t fb_mark_reads = 0, fb_mark_k = 0;
+    int64_t k_switch = -1;                 // component at which this run left the projection mode (-1: it did not)
     // sketch predictor (asb_sketch.hip): candidates of the next read named by a greedy replay in the space of the columns
     // the last read computed for its rejected steps
     int sketch = 1;                        // ASB_SKETCH=0: candidates by energy (and the first panel's guess) only
@@ -199,6 +211,11 @@ struct asb_ctx {
     unsigned* sk_counts = nullptr;         // [replays run, launches that found the sketch too thin and left score = energy]
     int sk_test_stall = 0;                 // tests: the next launch is made to time out
     int64_t n_sketch_runs = 0, n_sketch_reads = 0;
+    // diversity family of a candidate selection (asb_project.hip: in_div): energy-weighted random vertices beside the largest
+    int diverse = 1;                       // ASB_DIVERSE=0: candidates by energy / guess / replay scores only
+    bool diverse_next = false;             // the next plain read takes half of its candidates by the weighted sample
+    bool read_diverse = false;             // the read in progress does
+    int64_t n_diverse_reads = 0;
 
     asb_splocs* splocs = nullptr;   // SPLOCS state (asb_splocs.hip)
     asb_geo* geo = nullptr;         // device geodesics (asb_geodesic.hip)

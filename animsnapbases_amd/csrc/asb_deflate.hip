@@ -54,6 +54,8 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
     ctx->mode_streak = 0;
     ctx->probe_after = 2;
     ctx->spec_budget = ASB_PANEL_COLS;
+    ctx->fb_mark_reads = ctx->fb_mark_k = 0;
+    ctx->k_switch = -1;
     {
         const int rcd = asb_dl_begin(ctx);          // overlapped download of the basis (asb_components_stream): a new run
         if (rcd) return rcd;
@@ -73,6 +75,47 @@ extern "C" int asb_deflate_begin(asb_ctx* ctx, int64_t K, int mode, int local_su
                                 ctx->stream));
     // initial energies (:78-80 for k = 0)
     return stream_pass(ctx, false, nullptr, nullptr, nullptr, nullptr);
+}
+
+// Residual mode: room for K_new components in all (W, comps, scal grow, what the run has produced so far is kept) -- for loops
+// that end on a tolerance and cannot say beforehand how many components they take ('pca_blocks_with_St',
+// constraintsComponents.py:179: `while norm(R) > tol`; the reference appends to Python lists).
+template <typename T>
+static int grow_keep(asb_ctx* ctx, T** p, size_t count_new, size_t count_keep) {
+    const size_t want = count_new * sizeof(T);
+    auto it = ctx->alloc_bytes.find((void*)p);
+    if (*p && it != ctx->alloc_bytes.end() && it->second >= want) return ASB_OK;
+    T* q = nullptr;
+    ASB_HIP(ctx, hipMalloc((void**)&q, want));
+    if (*p && count_keep) {
+        hipError_t e = hipMemcpyAsync(q, *p, count_keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(q);
+            ASB_FAIL(ctx, ASB_ERR_HIP, "asb_deflate_reserve: %s", hipGetErrorString(e));
+        }
+    }
+    if (*p) (void)hipFree(*p);
+    *p = q;
+    ctx->alloc_bytes[(void*)p] = want;
+    return ASB_OK;
+}
+extern "C" int asb_deflate_reserve(asb_ctx* ctx, int64_t K_new) {
+    if (!ctx || !ctx->R || !ctx->W || !ctx->comps || !ctx->scal) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_RESIDUAL) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_reserve needs the residual mode");
+    if (K_new <= ctx->K) return ASB_OK;
+    const size_t rows = (size_t)ctx->n_loc * 3, kd = (size_t)ctx->k_done, Kn = (size_t)K_new;
+    int rc;
+    if ((rc = grow_keep(ctx, &ctx->W, Kn * ctx->Fp, kd * ctx->Fp))) return rc;
+    if ((rc = grow_keep(ctx, &ctx->comps, Kn * rows, kd * rows))) return rc;
+    const size_t old_scal = (size_t)(ctx->K + 1) * 4;
+    if ((rc = grow_keep(ctx, &ctx->scal, (Kn + 1) * 4, old_scal))) return rc;
+    ASB_HIP(ctx, hipMemsetAsync(ctx->scal + old_scal, 0, ((Kn + 1) * 4 - old_scal) * sizeof(double), ctx->stream));
+    ctx->K = K_new;
+    if (ctx->dl_enabled) {          // (the streamed download is sized per run: a grown run copies at the end through the plain path)
+        ctx->dl_done = 0;
+    }
+    return ASB_OK;
 }
 
 extern "C" int64_t asb_deflate_xchg_len(const asb_ctx* ctx) { return ctx ? 2 + 3 * ctx->Fp : 0; }
@@ -287,7 +330,7 @@ extern "C" int asb_deflate_stats(asb_ctx* ctx, int64_t* n_panels, int64_t* n_ref
 
 extern "C" int asb_deflate_energy_passes(asb_ctx* ctx, int64_t* n_passes) {
     if (!ctx || !n_passes) return ASB_ERR_ARG;
-    *n_passes = ctx->mode == ASB_DEFLATE_PROJECT ? ctx->n_energy_pass : 1;
+    *n_passes = (ctx->mode == ASB_DEFLATE_PROJECT || ctx->k_switch >= 0) ? ctx->n_energy_pass : 1;
     return ASB_OK;
 }
 

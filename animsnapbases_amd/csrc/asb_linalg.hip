@@ -618,34 +618,74 @@ extern "C" int asb_components_download(asb_ctx* ctx, double* comps_out) {
 }
 
 // ---- the basis into pinned host memory, overlapped with the run (include/asb.h)
+// The buffer is either the context's own (asb_components_stream) or the CALLER's (asb_components_stream_into: the Python
+// engine hands out ndarray views of it, so its lifetime must follow those views, not this context).
+static void dl_drop(asb_ctx* ctx) {
+    if (ctx->dl_host && ctx->dl_host_owned) (void)hipHostFree(ctx->dl_host);
+    ctx->dl_host = nullptr;
+    ctx->dl_host_count = 0;
+    ctx->dl_host_owned = 1;
+}
 static int dl_reserve(asb_ctx* ctx) {
     const size_t want = (size_t)ctx->K * 3 * ctx->n_loc;
     if (ctx->dl_host && ctx->dl_host_count >= want) return ASB_OK;
-    if (ctx->dl_host) {
-        (void)hipHostFree(ctx->dl_host);
-        ctx->dl_host = nullptr;
-        ctx->dl_host_count = 0;
-    }
+    if (ctx->dl_host && !ctx->dl_host_owned)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "the caller's pinned basis buffer holds %lld doubles, this run needs %lld (asb_components_stream_into)",
+                 (long long)ctx->dl_host_count, (long long)want);
+    dl_drop(ctx);
     if (want == 0) return ASB_OK;
     ASB_HIP(ctx, hipHostMalloc((void**)&ctx->dl_host, want * sizeof(double), hipHostMallocDefault));
     ctx->dl_host_count = want;
+    ctx->dl_host_owned = 1;
+    return ASB_OK;
+}
+static int dl_streams(asb_ctx* ctx) {
+    if (!ctx->dl_stream) ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->dl_stream, hipStreamNonBlocking));
+    if (!ctx->dl_event) ASB_HIP(ctx, hipEventCreateWithFlags(&ctx->dl_event, hipEventDisableTiming));
     return ASB_OK;
 }
 extern "C" int asb_components_stream(asb_ctx* ctx, int enable) {
     if (!ctx) return ASB_ERR_ARG;
     if (!enable) {
         if (ctx->dl_stream) (void)hipStreamSynchronize(ctx->dl_stream);
-        if (ctx->dl_host) (void)hipHostFree(ctx->dl_host);
-        ctx->dl_host = nullptr;
-        ctx->dl_host_count = 0;
+        dl_drop(ctx);
         ctx->dl_enabled = 0;
         return ASB_OK;
     }
-    if (!ctx->dl_stream) ASB_HIP(ctx, hipStreamCreateWithFlags(&ctx->dl_stream, hipStreamNonBlocking));
-    if (!ctx->dl_event) ASB_HIP(ctx, hipEventCreateWithFlags(&ctx->dl_event, hipEventDisableTiming));
+    int rc;
+    if ((rc = dl_streams(ctx))) return rc;
     ctx->dl_enabled = 1;
     ctx->dl_done = 0;
     return (ctx->K > 0 && ctx->n_loc > 0) ? dl_reserve(ctx) : ASB_OK;
+}
+// the same into a pinned buffer the CALLER owns (count doubles; NULL: streaming off).  The context never frees it and stops
+// writing to it with the next asb_components_stream_into / asb_components_stream(ctx, 0) / asb_destroy.
+extern "C" int asb_components_stream_into(asb_ctx* ctx, double* pinned_host, int64_t count) {
+    if (!ctx || count < 0 || (pinned_host && count == 0)) return ASB_ERR_ARG;
+    if (ctx->dl_stream) ASB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
+    dl_drop(ctx);
+    if (!pinned_host) {
+        ctx->dl_enabled = 0;
+        return ASB_OK;
+    }
+    int rc;
+    if ((rc = dl_streams(ctx))) return rc;
+    ctx->dl_host = pinned_host;
+    ctx->dl_host_count = (size_t)count;
+    ctx->dl_host_owned = 0;
+    ctx->dl_enabled = 1;
+    ctx->dl_done = 0;
+    return ASB_OK;
+}
+// pinned host memory for such a buffer (plain hipHostMalloc / hipHostFree: no context needed)
+extern "C" int asb_host_alloc(int64_t count, double** out) {
+    if (!out || count < 1) return ASB_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc((void**)out, (size_t)count * sizeof(double), hipHostMallocDefault) == hipSuccess ? ASB_OK : ASB_ERR_HIP;
+}
+extern "C" int asb_host_free(double* p) {
+    if (!p) return ASB_OK;
+    return hipHostFree(p) == hipSuccess ? ASB_OK : ASB_ERR_HIP;
 }
 // called by asb_deflate_begin: a new run starts (K is known): the pinned buffer is (re)sized, nothing is copied yet
 int asb_dl_begin(asb_ctx* ctx) {
@@ -657,6 +697,8 @@ int asb_dl_begin(asb_ctx* ctx) {
 extern "C" int asb_components_pinned(asb_ctx* ctx, double** out) {
     if (!ctx || !out || !ctx->comps) return ASB_ERR_ARG;
     if (!ctx->dl_enabled || !ctx->dl_host) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_components_pinned: asb_components_stream is off");
+    if ((size_t)ctx->K * 3 * ctx->n_loc > ctx->dl_host_count)
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_components_pinned: the pinned buffer was sized for a smaller run (K grew: asb_components_download)");
     int rc;
     if ((rc = asb_dl_enqueue(ctx, ctx->K))) return rc;      // what is left (everything, for the paths that do not stream)
     ASB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));

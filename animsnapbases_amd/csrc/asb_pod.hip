@@ -677,12 +677,13 @@ extern "C" int asb_deim_row(asb_ctx* ctx, int64_t gidx, double* row_out) {
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_st_row_energy(const long long* __restrict__ indptr, const long long* __restrict__ indices,
                                                        const double* __restrict__ data, long long n_rows, const double* __restrict__ M,
-                                                       long long ldm, long long ncols, double* __restrict__ E) {
+                                                       long long ldm, long long ncols, double* __restrict__ E,
+                                                       double* __restrict__ Amax) {          // Amax (optional): largest |entry| per row
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < n_rows; v += (long long)gridDim.x * 4) {
         const long long a = indptr[v], b = indptr[v + 1];
-        double e = 0.0;
+        double e = 0.0, am = 0.0;
         for (long long c0 = 0; c0 < ncols; c0 += 64 * U) {
             double acc[U];
 #pragma unroll
@@ -697,10 +698,17 @@ __global__ __launch_bounds__(256) void k_st_row_energy(const long long* __restri
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) e += acc[u] * acc[u];
+            for (int u = 0; u < U; ++u) {
+                e += acc[u] * acc[u];
+                am = fmax(am, fabs(acc[u]));
+            }
         }
         e = wave_sum(e);
         if (lane == 0) E[v] = e;
+        if (Amax) {
+            am = wave_max(am);
+            if (lane == 0) Amax[v] = am;
+        }
     }
 }
 
@@ -749,11 +757,11 @@ static int st_argmax(asb_ctx* ctx, const double* E, long long n, int64_t* idx_ou
     if (val_out) *val_out = be;
     return ASB_OK;
 }
-static int st_row_energies(asb_ctx* ctx, const double* M, long long ldm, long long ncols) {
+static int st_row_energies(asb_ctx* ctx, const double* M, long long ldm, long long ncols, double* amax = nullptr) {
     const long long want = (ctx->st_rows + 3) / 4;
     const int grid = (int)(want < 8LL * ctx->n_cu ? want : 8LL * ctx->n_cu);
     hipLaunchKernelGGL(k_st_row_energy, dim3(grid), dim3(256), 0, ctx->stream, ctx->st_indptr, ctx->st_indices, ctx->st_data,
-                       (long long)ctx->st_rows, M, ldm, ncols, ctx->st_energy);
+                       (long long)ctx->st_rows, M, ldm, ncols, ctx->st_energy, amax);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
@@ -840,12 +848,14 @@ extern "C" int asb_deim_block_residual_st(asb_ctx* ctx, int64_t k, int p, const 
     hipLaunchKernelGGL(k_deim_block_residual_out, dim3(grid), dim3(256), 0, ctx->stream, ctx->comps, (long long)ctx->n_loc, kp, p,
                        ctx->pod_coef, ctx->st_resid, ctx->pmax);
     ASB_CHECK_LAUNCH(ctx);
-    if ((rc = st_row_energies(ctx, ctx->st_resid, 3 * p, 3 * p))) return rc;
-    std::vector<double> h(grid);
-    ASB_HIP(ctx, hipMemcpyAsync(h.data(), ctx->pmax, grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if ((rc = st_argmax(ctx, ctx->st_energy, ctx->st_rows, v_out, val_out))) return rc;      // (synchronises)
+    // (the reference's stop test np.allclose(r, 0) at :677 looks at r = S^T (c - v_k) ENTRY by entry, atol 1e-8: the largest
+    // |entry| of S^T r comes back, not the largest row norm)
+    if ((rc = asb_alloc(ctx, &ctx->st_amax, (size_t)ctx->st_rows))) return rc;
+    if ((rc = st_row_energies(ctx, ctx->st_resid, 3 * p, 3 * p, ctx->st_amax))) return rc;
+    int64_t am_row = 0;
     double am = 0.0;
-    for (int b = 0; b < grid; ++b) am = h[b] > am ? h[b] : am;
+    if ((rc = st_argmax(ctx, ctx->st_amax, ctx->st_rows, &am_row, &am))) return rc;
+    if ((rc = st_argmax(ctx, ctx->st_energy, ctx->st_rows, v_out, val_out))) return rc;      // (synchronises)
     *maxabs_out = am;
     return ASB_OK;
 }

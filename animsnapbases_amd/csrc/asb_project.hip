@@ -30,7 +30,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // layout of ctx->scalar_dev (doubles)
 enum { SC_NORMX2 = 0, SC_E0MAX = 1, SC_EMAX = 2, SC_LO = 3, SC_HI = 4, SC_ABOVE = 5, SC_TAU = 6, SC_OVERFLOW = 7,
-       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16, SC_GG = 24, SC_HH = 32 };  // 8..10: k_best_energy; 11..13: super-panels (band);
+       SC_TAU_HI = 11, SC_TAU2 = 12, SC_BANDMAX = 13, SC_TAUG = 16, SC_GG = 24, SC_HH = 32,
+       SC_TAU_DIV = 40, SC_DIV_SEED = 41 };  // 8..10: k_best_energy; 11..13: super-panels (band); 40 / 41: the diversity family
                                                                      // 16..16+ASB_NG-1: thresholds of a guessed selection,
                                                                      // 24.. / 32..: their g and h (k_tau_multi writes all three)
 // Guessed candidates of a first panel (see asb_project_run): the scores EV + g (E - EV), g on a geometric grid -- E - EV
@@ -51,6 +52,28 @@ __device__ __forceinline__ bool in_guess(double e, double ev, const double* __re
     for (int q = 0; q < ASB_NG; ++q) in = in || (guess_score(ev, m, s, sc[SC_GG + q], sc[SC_HH + q]) > sc[SC_TAUG + q]);
     return in;
 }
+// The DIVERSITY family of a candidate selection (round 4).  The panel kernel's greedy steps on the candidate rows do two jobs:
+// they find the winners, and the weight vectors of the steps the pass rejects become the sketch the next read's candidates are
+// predicted from (asb_sketch.hip).  For the second job the largest energies are the wrong rows on localised data: they all lie
+// in the one or two strongest modes, the steps behind those modes run on noise, and the sketch misses every other mode.  An
+// energy-WEIGHTED RANDOM SAMPLE of all vertices spans the dominant frame subspace of the whole residual (row sampling with
+// probability ~ squared row norm): vertex i belongs to it when e_i / Exp_i > tau_div, Exp_i = -log(u_i) a unit exponential from
+// a hash of (i, seed) -- the m largest keys are an exact weighted sample without replacement (Efraimidis-Spirakis).  Computed on
+// the fly from the energy at the start of the read and the vertex's index, by the compaction and by the pass's check alike;
+// off while sc[SC_TAU_DIV] is "infinite".  Like every other family it only names candidates: nothing rests on it.
+#define ASB_DIV_Q (ASB_NG + 1)              // its slot among the thresholds of a multi-score selection
+#define ASB_NQ (ASB_NG + 2)
+__device__ __forceinline__ double div_key(double e, long long i, double seed_bits) {
+    unsigned long long x = ((unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull ^ (unsigned long long)__double_as_longlong(seed_bits);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;      // splitmix64
+    const double u = ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    return e / -log(u);
+}
+__device__ __forceinline__ bool in_div(double e, long long i, const double* __restrict__ sc) {
+    const double t = sc[SC_TAU_DIV];
+    return t < 1.0e299 && div_key(e, i, sc[SC_DIV_SEED]) > t;
+}
+__global__ void k_sc_set(double* __restrict__ sc, int slot, double v) { sc[slot] = v; }
 
 // --------------------------------------------------------------------------------------
 // k_gather: item s -> vertex v = idx_map[s] - v0 (or s); rebuilds its residual row
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tau(int* __restrict__ hist, double* __r
 // ---- the thresholds of a guessed selection in one go: ASB_NG + 1 scores EV + g (E - EV) (the last one, g = 1, is the
 // energy itself), each with its own histogram, range block scm[q * 8 ..] (slots as in sc) and target; block q of k_tau_multi
 // is k_tau for score q, and at level 2 it leaves the threshold where the compaction looks for it
-struct GuessTargets { double g[ASB_NG + 1], h[ASB_NG + 1]; long long m_target[ASB_NG + 1], m_cap[ASB_NG + 1]; };
+struct GuessTargets { double g[ASB_NQ], h[ASB_NQ]; long long m_target[ASB_NQ], m_cap[ASB_NQ]; double div_seed; };
 __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E, const double* __restrict__ EV, long long n,
                                                     const double* __restrict__ scm, int* __restrict__ hist, int by_exponent,
                                                     GuessTargets gt, int nq, unsigned qmask = 0xffffffffu) {
@@ -308,8 +331,12 @@ __global__ __launch_bounds__(256) void k_hist_multi(const double* __restrict__ E
         const double lo = scm[q * 8 + SC_LO], hi = scm[q * 8 + SC_HI], g = gt.g[q], h = gt.h[q];
         const double scale = (hi > lo) ? (double)ASB_NBINS / (hi - lo) : 0.0;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-            const double ev = EV[i], m = E[i] - ev;
-            const double e = guess_score(ev, m, h != 0.0 ? sqrt(fmax(m, 0.0) * fmax(ev, 0.0)) : 0.0, g, h);
+            double e;
+            if (q == ASB_DIV_Q) e = div_key(E[i], i, gt.div_seed);
+            else {
+                const double ev = EV ? EV[i] : E[i], m = E[i] - ev;
+                e = guess_score(ev, m, h != 0.0 ? sqrt(fmax(m, 0.0) * fmax(ev, 0.0)) : 0.0, g, h);
+            }
             int b;
             if (by_exponent) {
                 if (!(e >= 0.0)) continue;
@@ -334,12 +361,19 @@ __global__ __launch_bounds__(256) void k_tau_multi(int* __restrict__ hist, doubl
     const int q = blockIdx.x;
     if (!((qmask >> q) & 1u)) {              // a score that takes no part: nothing lies above its threshold
         if (level == 2 && threadIdx.x == 0 && q < ASB_NG) { sc[SC_TAUG + q] = 1.0e300; sc[SC_GG + q] = 0.0; sc[SC_HH + q] = 0.0; }
+        if (level == 2 && threadIdx.x == 0 && q == ASB_DIV_Q) sc[SC_TAU_DIV] = 1.0e300;
         return;
     }
     tau_body(hist + q * ASB_NBINS, scm + q * 8, level, gt.m_target[q], gt.m_cap[q], lh, seg);
     if (level == 2 && threadIdx.x == 0) {
-        sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
-        if (q < ASB_NG) { sc[SC_GG + q] = gt.g[q]; sc[SC_HH + q] = gt.h[q]; }
+        if (q == ASB_DIV_Q) {
+            const double t = scm[q * 8 + SC_TAU];
+            sc[SC_TAU_DIV] = t < 0.0 ? 0.0 : t;           // (fewer vertices than the target: all with a positive key)
+            sc[SC_DIV_SEED] = gt.div_seed;
+        } else {
+            sc[q < ASB_NG ? SC_TAUG + q : SC_TAU] = scm[q * 8 + SC_TAU];
+            if (q < ASB_NG) { sc[SC_GG + q] = gt.g[q]; sc[SC_HH + q] = gt.h[q]; }
+        }
     }
 }
 
@@ -360,7 +394,9 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     const long long sub = (seg + 255) / 256;
     const long long a = s0 + tid * sub, b = (a + sub < s1) ? a + sub : s1;
     long long c = 0;
-    for (long long i = a; i < b; ++i) c += ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc)));
+    const bool div = !take_all && hi_slot < 0;
+    for (long long i = a; i < b; ++i)
+        c += ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc)) || (div && in_div(E[i], i, sc)));
     pre[tid] = c;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -372,7 +408,7 @@ __global__ __launch_bounds__(256) void k_compact_a(const double* __restrict__ E,
     long long pos = pre[tid] - c;
     long long* out = tmp + (long long)blockIdx.x * m_cap;
     for (long long i = a; i < b; ++i)
-        if ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc))) {
+        if ((E[i] > tau && !(E[i] > tau_hi)) || (E2 && in_guess(E[i], E2[i], sc)) || (div && in_div(E[i], i, sc))) {
             if (pos < m_cap) out[pos] = v0 + i;
             ++pos;
         }
@@ -568,7 +604,7 @@ __global__ __launch_bounds__(256) void k_correct(double* __restrict__ comps, lon
                 // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds) -- E as it
                 // was when the candidates were chosen (Ecl: a later tile of a double panel sees updated energies in E)
                 const double es = Ecl ? Ecl[vi] : e;
-                const bool outside = !(es > sp_tau) && !(E2 && in_guess(es, E2[vi], sc));
+                const bool outside = !(es > sp_tau) && !(E2 && in_guess(es, E2[vi], sc)) && !in_div(es, vi, sc);
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     if (t < ncols) {
@@ -701,7 +737,7 @@ __global__ __launch_bounds__(192) void k_correct_rows(double* __restrict__ comps
                     // the compaction took E > tau (and, for a guessed selection, the scores above their thresholds) -- E as
                     // it was when the candidates were chosen (Ecl: a later tile of a double panel sees updated energies)
                     const double es = Ecl ? Ecl[v] : e;
-                    const bool outside = !(es > sc[SC_TAU]) && !(E2 && in_guess(es, E2[v], sc));
+                    const bool outside = !(es > sc[SC_TAU]) && !(E2 && in_guess(es, E2[v], sc)) && !in_div(es, v, sc);
                     const double margin = spec->margin;
                     const int proven = (int)spec->proven;
                     const double e_start = e;
@@ -1922,6 +1958,9 @@ int asb_project_begin(asb_ctx* ctx, int64_t K) {
     if ((rc = asb_alloc(ctx, &ctx->ccnt, (size_t)ASB_CBLOCKS))) return rc;
     StreamCfg c;
     if (!pick_cfg(ctx->Fp, c)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    hipLaunchKernelGGL(k_sc_set, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU_DIV, 1.0e300);      // diversity family off
+    ctx->diverse_next = ctx->read_diverse = false;
+    ctx->n_diverse_reads = 0;
     // the adaptive panel lengths start afresh: the same tensor gives the same panels, hence the same bits, on every call
     ctx->sub_cur = 0;
     for (int q = 0; q < 8; ++q) ctx->sub_budget[q] = ASB_PANEL_COLS;
@@ -2457,10 +2496,12 @@ __device__ __forceinline__ void coop_store_u64(unsigned long long* p, unsigned l
 
 __global__ __launch_bounds__(256) void k_panel_arm_multi(PanelState* __restrict__ panel, PanelState* __restrict__ sub,
                                                          const double* __restrict__ sc, double margin_rel, unsigned* __restrict__ coop_flags,
-                                                         unsigned long long* __restrict__ words, int n_words, MultiArgs ma) {
+                                                         unsigned long long* __restrict__ words, int n_words, MultiArgs ma,
+                                                         long long n_slots = -1) {
     for (int r = threadIdx.x; r < n_words; r += blockDim.x) words[r] = ASB_SENT_D;     // (ASB_SENT_I has the same bits)
     if (threadIdx.x < 4) coop_flags[threadIdx.x] = 0u;
     if (threadIdx.x != 0) return;
+    if (n_slots >= 0) panel->n_cand = n_slots;          // an ASSEMBLED candidate buffer (several ranks): the host knows its size
     panel->pad &= 1;
     panel->theta = panel->pad ? 1.0e300 : sc[SC_TAU];
     panel->margin = margin_rel * sc[SC_E0MAX];
@@ -3264,9 +3305,10 @@ static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa);
 // wrote (they lie at and beyond the first column that is not committed, and a later tile exists only behind a FULL one, so no
 // committed column is ever orthogonalised against them); the caller checks the tiles on the counts really reached.
 static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max, int* ntile, int* nc, int* proven,
-                           int* spec_ntile = nullptr, int* spec_nc = nullptr) {
+                           int* spec_ntile = nullptr, int* spec_nc = nullptr, bool assembled = false) {
     int rc;
     *ntile = -1;
+    ctx->chain_timed_out = 0;
     if (spec_ntile) *spec_ntile = 0;
     int cgrid_all = 0;
     size_t n_words = 0;
@@ -3287,7 +3329,7 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
     // speculative buffers are reset by their owners at the start of the panel kernel
     const int n_small = 3 * cgrid_all * 2 + 3 * ((int)ctx->Fp + 8);
     hipLaunchKernelGGL(k_panel_arm_multi, dim3(1), dim3(256), 0, ctx->stream, ctx->pstate, ctx->pstate2, ctx->scalar_dev, ASB_MARGIN_REL,
-                       ctx->coop_bar, (unsigned long long*)ctx->coop_rec, n_small, ma);
+                       ctx->coop_bar, (unsigned long long*)ctx->coop_rec, n_small, ma, (long long)(assembled ? ctx->n_slots_host : -1));
     bool launched = false;
     if ((rc = launch_panel_multi_any(ctx, cgrid_all, ma, &launched, ctx->pstate2, false))) return rc;
     if (!launched) return ASB_OK;
@@ -3315,6 +3357,7 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
     for (int sp = 0; sp < n; ++sp) {
         const long long committed = (long long)(sum[sp] & 0xffffffffu), prov = (long long)(sum[sp] >> 32) - 1;
         if (prov < 0) {                                  // the launch did not finish this sub-panel (sum[8] says why)
+            ctx->chain_timed_out = 1;                    // (several ranks: the driver makes all of them leave the kernel together)
             if (sp == 0) return ASB_OK;                  // *ntile = -1: the one-by-one path meets the same and falls back
             ctx->panel_coop = 0;                         // a later one timed out: what stands stands, the context leaves the kernel
             ctx->coop_test_stall = 0;
@@ -3328,6 +3371,33 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
         if (committed < ASB_PANEL_COLS) break;
     }
     *ntile = nt;
+    return ASB_OK;
+}
+// the checks of all tiles of a read, enqueued back to back (pre-orthogonalised weights, one-thread-per-row check): per tile the
+// check with tentative energies, the one-block decision (chain flag: a tile counts only behind tiles that stood in full) and the
+// conditional adoption; ctx->tile_res holds the per-tile results afterwards
+static int tiles_enqueue(asb_ctx* ctx, int ntile, const long long* kb, const int* nc, PanelState* const* st, int* rgrid_out, int* cgrid_out) {
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->e_tmp, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
+    long long cwr = (ctx->n_loc + 63) / 64;
+    // (two blocks per CU, grid-strided: the one-block k_tile_decide sums a partial per block and column)
+    static const int bpc = getenv("ASB_CHECK_BLOCKS_PER_CU") ? atoi(getenv("ASB_CHECK_BLOCKS_PER_CU")) : 2;
+    const long long rcap = (long long)(bpc < 1 ? 1 : (bpc > 8 ? 8 : bpc)) * ctx->n_cu;
+    const int rgrid = (int)(cwr < rcap ? cwr : rcap);
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    for (int ct = 0; ct < ntile; ++ct) {
+        hipLaunchKernelGGL(k_correct_rows<true>, dim3(rgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)kb[ct], nc[ct], ctx->gram_s, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
+                           ctx->psum, ctx->colpart, st[ct], ctx->scalar_dev, ctx->sel_e2, ctx->e_class, 1, ctx->e_tmp);
+        hipLaunchKernelGGL(k_tile_decide, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, rgrid, ct, (long long)kb[ct], ctx->scal, st[ct],
+                           ctx->tile_res);
+        hipLaunchKernelGGL(k_apply_tmp, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->energy, ctx->e_tmp, (long long)ctx->n_loc, ctx->tile_res);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    *rgrid_out = rgrid;
+    *cgrid_out = cgrid;
     return ASB_OK;
 }
 static int panel_candidates(asb_ctx* ctx, long long k, int stalled);
@@ -3405,24 +3475,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     const bool chained = ctx->pre_orth && ctx->correct_rows && ctx->tile_chain;
     if (chained) {
         // all tiles enqueued back to back, ONE host read
-        if ((rc = asb_alloc(ctx, &ctx->e_tmp, (size_t)ctx->n_loc))) return rc;
-        if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
-        long long cwr = (ctx->n_loc + 63) / 64;
-        // (two blocks per CU, grid-strided: the one-block k_tile_decide sums a partial per block and column)
-        static const int bpc = getenv("ASB_CHECK_BLOCKS_PER_CU") ? atoi(getenv("ASB_CHECK_BLOCKS_PER_CU")) : 2;
-        const long long rcap = (long long)(bpc < 1 ? 1 : (bpc > 8 ? 8 : bpc)) * ctx->n_cu;
-        const int rgrid = (int)(cwr < rcap ? cwr : rcap);
-        long long cw = (ctx->n_loc + 255) / 256;
-        const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
-        for (int ct = 0; ct < ntile; ++ct) {
-            hipLaunchKernelGGL(k_correct_rows<true>, dim3(rgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
-                               (long long)ctx->n_loc, (int)kb[ct], nc[ct], ctx->gram_s, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
-                               ctx->psum, ctx->colpart, st[ct], ctx->scalar_dev, ctx->sel_e2, ctx->e_class, 1, ctx->e_tmp);
-            hipLaunchKernelGGL(k_tile_decide, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, rgrid, ct, (long long)kb[ct], ctx->scal, st[ct],
-                               ctx->tile_res);
-            hipLaunchKernelGGL(k_apply_tmp, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->energy, ctx->e_tmp, (long long)ctx->n_loc, ctx->tile_res);
-        }
-        ASB_CHECK_LAUNCH(ctx);
+        int rgrid = 0, cgrid = 0;
+        if ((rc = tiles_enqueue(ctx, ntile, kb, nc, st, &rgrid, &cgrid))) return rc;
         long long res[ASB_MAX_SUB + 1];
         if ((rc = fetch_words(ctx, ctx->tile_res, ASB_MAX_SUB + 1, res))) return rc;
         ctx->nblk = rgrid;                           // the records of the last tile that stood in full
@@ -3545,6 +3599,16 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         ctx->sub_cur = nsub_lim;
         for (int sp = 0; sp < 8; ++sp) ctx->sub_budget[sp] = ASB_PANEL_COLS;
     }
+    // Behind a rejection that no replay answers, the next read's candidates are half the largest energies, half an energy-weighted
+    // random sample of everyone (in_div), and it gets all its sub-panels: its winners still come from the first half, and the
+    // columns of its rejected steps -- greedy steps on rows from ALL over the mesh -- are the sketch the read after it is
+    // predicted from.  CPU replay (tools/sim_sketch2.py, N = 100 000, F = 256, K = 128, 50 localised bumps): 6 reads (1, 39, 9, 20,
+    // 35, 24 components) against 9 with candidates by energy and replay alone; low rank and the slow spectrum unchanged (6, 8).
+    if (ctx->diverse && rejected && !ctx->sketch_valid && !ctx->sketch_run_off && total > 0 && k + total < k1) {
+        ctx->diverse_next = true;
+        ctx->sub_cur = nsub_lim;
+        for (int sp = 0; sp < 8; ++sp) ctx->sub_budget[sp] = ASB_PANEL_COLS;
+    }
     *done_out = total;
     return ASB_OK;
 }
@@ -3651,10 +3715,10 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     static const double kq[ASB_NG] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.35};
     static const int mq[ASB_NG] = {400, 140, 140, 90, 60, 400};
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)(ASB_NG + 1) * 8))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)ASB_NQ * ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)ASB_NQ * 8))) return rc;
     if (!ctx->hist6_clear) {          // every k_tau_multi leaves the bins it consumed at zero again
-        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)(ASB_NG + 1) * ASB_NBINS * sizeof(int), ctx->stream));
+        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)ASB_NQ * ASB_NBINS * sizeof(int), ctx->stream));
         ctx->hist6_clear = true;
     }
     GuessTargets gt;
@@ -3673,9 +3737,18 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     gt.h[ASB_NG] = 0.0;
     gt.m_target[ASB_NG] = me;
     gt.m_cap[ASB_NG] = me + me / 2;
-    const int nq = with_energy ? ASB_NG + 1 : ASB_NG;
+    // the diversity family (in_div; single rank): the guess fills ~740 of the 1024 candidate slots of the panel kernel; ~190
+    // energy-weighted random vertices beside them cost the random tensor nothing (their rows ride along) and give a first read
+    // on LOCALISED data weight vectors that span all its modes instead of the strongest one or two (the sketch of the next read)
+    const long long md = (with_energy && ctx->diverse) ? 190 * ctx->m_target / 768 : 0;
+    gt.g[ASB_DIV_Q] = gt.h[ASB_DIV_Q] = 0.0;
+    gt.m_target[ASB_DIV_Q] = md;
+    gt.m_cap[ASB_DIV_Q] = md + md / 8;
+    gt.div_seed = (double)(ctx->n_panels + ctx->n_refresh + 1);
+    const int nq = with_energy ? ASB_NQ : ASB_NG;
     static const int ucb = getenv("ASB_GUESS_UCB") ? atoi(getenv("ASB_GUESS_UCB")) : 1;      // 0: without the confidence-bound family
-    const unsigned qmask = ucb ? 0xffffffffu : ~(1u << (ASB_NG - 1));
+    unsigned qmask = ucb ? 0xffffffffu : ~(1u << (ASB_NG - 1));
+    if (md < 8) qmask &= ~(1u << ASB_DIV_Q);
     for (int level = 1; level <= 2; ++level) {
         hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, ctx->EV, (long long)ctx->n_loc,
                            ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, nq, qmask);
@@ -3686,30 +3759,34 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
 }
 // candidates named by the sketch predictor (asb_sketch.hip): the 2/3 m_target largest scores united with the m_target / 3
 // largest energies (which also carry the provable first steps) -- the guessed selection's machinery with one live score (g = 0: the score itself)
-static int score_thresholds(asb_ctx* ctx) {
+static int score_thresholds(asb_ctx* ctx, bool with_score = true, long long m_div = 0) {
     int rc;
-    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)(ASB_NG + 1) * ASB_NBINS))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)(ASB_NG + 1) * 8))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist6, (size_t)ASB_NQ * ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scm, (size_t)ASB_NQ * 8))) return rc;
     if (!ctx->hist6_clear) {
-        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)(ASB_NG + 1) * ASB_NBINS * sizeof(int), ctx->stream));
+        ASB_HIP(ctx, hipMemsetAsync(ctx->hist6, 0, (size_t)ASB_NQ * ASB_NBINS * sizeof(int), ctx->stream));
         ctx->hist6_clear = true;
     }
     GuessTargets gt;
     // (a third of the candidates by energy: the replay names who comes CLOSE to winning under its model, the energies who is large
     // now -- eight low-rank tensors: 16.0 ms / 6.25 reads in the mean with a third or a half by energy, 17.0 / 6.5 with a twelfth)
     static const int me_div = getenv("ASB_SKETCH_ME_DIV") ? atoi(getenv("ASB_SKETCH_ME_DIV")) : 3;
-    const long long me = ctx->m_target / (me_div > 1 ? me_div : 2), ms = ctx->m_target - me;
-    for (int q = 0; q <= ASB_NG; ++q) {
+    // with_score: ms by the replay's scores, me by energy (+ m_div by the diversity family beside them); without: a PLAIN read
+    // behind a rejection -- m_target - m_div by energy, m_div (half) energy-weighted random (in_div)
+    const long long me = with_score ? ctx->m_target / (me_div > 1 ? me_div : 2) : ctx->m_target - m_div, ms = ctx->m_target - me;
+    for (int q = 0; q < ASB_NQ; ++q) {
         gt.g[q] = q == ASB_NG ? 1.0 : 0.0;
         gt.h[q] = 0.0;
-        gt.m_target[q] = q == ASB_NG ? me : ms;
-        gt.m_cap[q] = q == ASB_NG ? me + me / 2 : ms + ms / 8;
+        gt.m_target[q] = q == ASB_NG ? me : (q == ASB_DIV_Q ? m_div : ms);
+        gt.m_cap[q] = q == ASB_NG ? me + me / 2 : (q == ASB_DIV_Q ? m_div + m_div / 8 : ms + ms / 8);
     }
-    const unsigned qmask = 1u | (1u << ASB_NG);
+    gt.div_seed = (double)(ctx->n_panels + ctx->n_refresh + 1);
+    const unsigned qmask = (with_score ? 1u : 0u) | (1u << ASB_NG) | (m_div >= 8 ? (1u << ASB_DIV_Q) : 0u);
     for (int level = 1; level <= 2; ++level) {
-        hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy, ctx->sk_score, (long long)ctx->n_loc,
-                           ctx->scm, ctx->hist6, level == 1 ? 1 : 0, gt, ASB_NG + 1, qmask);
-        hipLaunchKernelGGL(k_tau_multi, dim3(ASB_NG + 1), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt, qmask);
+        hipLaunchKernelGGL(k_hist_multi, dim3(hist_grid(ctx)), dim3(256), 0, ctx->stream, ctx->energy,
+                           with_score ? ctx->sk_score : (const double*)nullptr, (long long)ctx->n_loc, ctx->scm, ctx->hist6,
+                           level == 1 ? 1 : 0, gt, ASB_NQ, qmask);
+        hipLaunchKernelGGL(k_tau_multi, dim3(ASB_NQ), dim3(256), 0, ctx->stream, ctx->hist6, ctx->scm, ctx->scalar_dev, level, gt, qmask);
     }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
@@ -3758,15 +3835,24 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     const bool by_score = ctx->sketch_valid && stalled == 0 && k > 0;
     ctx->sketch_valid = false;
     ctx->read_by_score = by_score;
+    // diversity (in_div): half of a plain read's candidates behind a rejection, an eighth beside the predicted ones
+    const bool div_plain = ctx->diverse && ctx->diverse_next && stalled == 0 && k > 0 && ctx->n_loc > 4 * ctx->m_cap;
+    ctx->diverse_next = false;
+    ctx->read_diverse = false;
     if (by_score) {
-        if ((rc = score_thresholds(ctx))) return rc;
+        if ((rc = score_thresholds(ctx, true, ctx->diverse ? ctx->m_target / 8 : 0))) return rc;
         ctx->sel_e2 = ctx->sk_score;
         ctx->n_sketch_reads++;
     } else if (guess) {
         if ((rc = guess_thresholds(ctx, 1, true))) return rc;
         ctx->sel_e2 = ctx->EV;
         ctx->n_guess_panels++;
+    } else if (div_plain) {
+        if ((rc = score_thresholds(ctx, false, ctx->m_target / 2))) return rc;
+        ctx->read_diverse = true;
+        ctx->n_diverse_reads++;
     } else {
+        hipLaunchKernelGGL(k_sc_set, dim3(1), dim3(1), 0, ctx->stream, ctx->scalar_dev, (int)SC_TAU_DIV, 1.0e300);
         for (int level = 1; level <= 2; ++level) {
             if ((rc = asb_panel_hist(ctx, level, nullptr))) return rc;
             if ((rc = asb_panel_tau(ctx, level, nullptr))) return rc;
@@ -3774,6 +3860,65 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     }
     return asb_panel_select(ctx, k, -1, 0, nullptr, nullptr, nullptr, nullptr);
 }
+
+// ---- leaving the projection mode in mid-run (single rank: asb_project_run's stall rule; several ranks: the driver's, which then
+// continues with the residual protocol): the residual R_k = X - sum_{j<k} w_j (x) c_j is written out once (one read of X, one
+// write of R, the exact energies and their partial records with it), the per-component scalars change from the projection
+// mode's |w|^2 |c|^2 to the residual mode's |R_j|^2, and the context IS in residual mode from here on: asb_deflate_pick /
+// _apply / _local_best / _results work as if the run had begun there.
+__global__ void k_scal_to_direct(double* __restrict__ scal, long long k, const double* __restrict__ sc) {
+    double r2 = sc[SC_NORMX2];
+    for (long long j = 0; j < k; ++j) {
+        r2 -= scal[j * 4 + 3];
+        scal[j * 4 + 3] = r2;
+    }
+}
+extern "C" int asb_project_switch_residual(asb_ctx* ctx, int64_t k) {
+    if (!ctx || !ctx->energy || !ctx->comps || !ctx->W) return ASB_ERR_ARG;
+    if (ctx->mode != ASB_DEFLATE_PROJECT) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_project_switch_residual: not in projection mode");
+    if (k < 0 || k > ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_project_switch_residual: k = %lld out of range", (long long)k);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->R, (size_t)ctx->n_loc * 3 * ctx->Fp))) return rc;
+    if (!pick_cfg(ctx->Fp, ctx->cfg)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "F too large");
+    const int ggrid = stream_grid(ctx, ctx->cfg, ctx->n_loc);
+    launch_gather(ctx, ctx->cfg, ggrid, nullptr, (long long)ctx->n_loc, nullptr, (int)k, ctx->R, ctx->energy, ctx->pmax, ctx->pidx,
+                  ctx->psum);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->nblk = ggrid;
+    ctx->n_refresh++;                                   // (a read of X)
+    hipLaunchKernelGGL(k_scal_to_direct, dim3(1), dim3(1), 0, ctx->stream, ctx->scal, (long long)k, ctx->scalar_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    ctx->mode = ASB_DEFLATE_RESIDUAL;
+    ctx->local = 0;
+    ctx->forced_row = -1;
+    ctx->sel_e2 = nullptr;
+    ctx->k_done = k;
+    ctx->k_switch = k;
+    if (getenv("ASB_DEBUG_PANELS"))
+        fprintf(stderr, "[asb] k=%lld: %lld reads of X so far -- the run continues in the residual loop\n", (long long)k,
+                (long long)(ctx->n_panels + ctx->n_refresh));
+    return ASB_OK;
+}
+extern "C" int asb_deflate_switch_stats(asb_ctx* ctx, int64_t* k_switch) {
+    if (!ctx || !k_switch) return ASB_ERR_ARG;
+    *k_switch = ctx->k_switch;
+    return ASB_OK;
+}
+// fewer than 3/4 of a component per read of X over the last >= 8 reads (refreshes included)?  A low-yield read costs ~1.5 ms at
+// config 4's size (one sub-panel's pass + its greedy steps + selection), a refresh ~1 ms, a residual step (one read + one write
+// of R) ~1.9 ms: below that rate the residual loop is cheaper, and far below it -- K beyond the numerical rank: ~5 reads per
+// component -- it is the only sane way on.
+static bool stall_rule(asb_ctx* ctx, long long k) {
+    if (!ctx->stall_fallback) return false;
+    const long long reads = ctx->n_panels + ctx->n_refresh;
+    if (reads - ctx->fb_mark_reads < 8) return false;
+    const bool slow = (k - ctx->fb_mark_k) * 4 < (reads - ctx->fb_mark_reads) * 3;
+    ctx->fb_mark_reads = reads;
+    ctx->fb_mark_k = k;
+    return slow;
+}
+extern "C" int asb_deflate_pick(asb_ctx* ctx, int64_t k, const double* recs_dev, int64_t n_rec);
+extern "C" int asb_deflate_apply(asb_ctx* ctx, int64_t k, const double* s);
 
 int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
     int rc;
@@ -3786,6 +3931,14 @@ int asb_project_run(asb_ctx* ctx, int64_t k0, int64_t k1) {
         // rows below k are final (projection mode never rewrites a committed column): their copy to the pinned buffer runs
         // on the copy stream while the next read of X computes (asb_components_stream; no-op otherwise)
         if ((rc = asb_dl_enqueue(ctx, k))) return rc;
+        if (stall_rule(ctx, k)) {
+            if ((rc = asb_project_switch_residual(ctx, k))) return rc;
+            for (long long kk = k; kk < k1; ++kk) {
+                if ((rc = asb_deflate_pick(ctx, kk, nullptr, 0))) return rc;
+                if ((rc = asb_deflate_apply(ctx, kk, nullptr))) return rc;
+            }
+            return ASB_OK;
+        }
         if (use_double && stalled == 0) {
             int64_t done = 0;
             if ((rc = double_panel(ctx, k, k1, &done))) return rc;

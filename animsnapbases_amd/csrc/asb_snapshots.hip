@@ -298,6 +298,8 @@ extern "C" int asb_create(int device_id, void* hip_stream, asb_ctx** out) {
     if (const char* dp = getenv("ASB_SPEC_PASS")) ctx->spec_pass = atoi(dp);
     if (const char* dp = getenv("ASB_SPEC_W_RANK")) ctx->spec_w_rank = atoi(dp);
     if (const char* sk = getenv("ASB_SKETCH")) ctx->sketch = atoi(sk);
+    if (const char* sf = getenv("ASB_STALL_FALLBACK")) ctx->stall_fallback = atoi(sf);
+    if (const char* dv = getenv("ASB_DIVERSE")) ctx->diverse = atoi(dv);
     if (const char* sk = getenv("ASB_SKETCH_TEST_STALL")) ctx->sk_test_stall = atoi(sk);
     if (const char* dp = getenv("ASB_SUB_FIRST")) ctx->sub_first = atoi(dp) < 1 ? 1 : atoi(dp);
     if (const char* bt = getenv("ASB_BAND_TARGET")) { ctx->band_target = atoll(bt); ctx->band_cap = ctx->band_target * 4 / 3; }
@@ -325,7 +327,7 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
     if (ctx->res_pin) (void)hipHostFree(ctx->res_pin);
     if (ctx->dl_stream) { (void)hipStreamSynchronize(ctx->dl_stream); (void)hipStreamDestroy(ctx->dl_stream); }
     if (ctx->dl_event) (void)hipEventDestroy(ctx->dl_event);
-    if (ctx->dl_host) (void)hipHostFree(ctx->dl_host);
+    if (ctx->dl_host && ctx->dl_host_owned) (void)hipHostFree(ctx->dl_host);
     for (auto& e : ctx->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);

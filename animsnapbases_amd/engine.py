@@ -6,11 +6,45 @@ the multi-rank host logic can be exercised on CPU by a test double that lives in
 ``tests/`` (never in this package).
 """
 import ctypes
+import weakref
 
 import numpy as np
 
 from . import _lib
 from ._lib import AsbLibraryError, ptr
+
+
+class _PinnedBasis(object):
+    """Pinned host memory for a streamed basis (asb_host_alloc).  The ndarray views ``HipEngine.components_pinned`` hands out
+    keep this object alive through their buffer, so the memory is freed when the engine AND every view have let go of it --
+    never under a live view (the context itself never frees a caller-owned buffer: asb_components_stream_into)."""
+
+    def __init__(self, lib, count):
+        p = ctypes.c_void_p()
+        if lib.asb_host_alloc(int(count), ctypes.byref(p)) != 0 or not p.value:
+            raise MemoryError("asb_host_alloc(%d doubles) failed" % count)
+        self._lib, self.ptr, self.count = lib, p.value, int(count)
+        self._views = []            # weak references to the ctypes arrays the handed-out ndarrays are built on
+
+    def view(self, shape):
+        n = int(np.prod(shape))
+        assert n <= self.count
+        buf = (ctypes.c_double * n).from_address(self.ptr)
+        buf._owner = self           # buffer -> owner: the owner lives as long as any ndarray over it
+        self._views = [w for w in self._views if w() is not None] + [weakref.ref(buf)]
+        return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+
+    def in_use(self):
+        self._views = [w for w in self._views if w() is not None]
+        return bool(self._views)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.asb_host_free(ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
 
 
 class HipEngine(object):
@@ -53,8 +87,9 @@ class HipEngine(object):
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.asb_destroy(self.h)
+            self.lib.asb_destroy(self.h)      # (synchronises the copy stream; a caller-owned pinned buffer is not freed there)
             self.h = None
+        self._pin = None                      # the views that are still alive keep their memory
 
     def __del__(self):
         try:
@@ -143,6 +178,15 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ deflation
     def deflate_begin(self, K, local_support, mode=_lib.DEFLATE_RESIDUAL):
+        if getattr(self, "_streaming", False):
+            # the streamed basis goes into pinned memory THIS side owns: a buffer some ndarray still looks at is neither
+            # freed nor overwritten by the new run -- the run gets a fresh one and the old one dies with its last view
+            need = int(K) * int(self.n_loc) * 3
+            pin = getattr(self, "_pin", None)
+            if need > 0 and (pin is None or pin.count < need or pin.in_use()):
+                self._pin = pin = _PinnedBasis(self.lib, need)
+            if need > 0:
+                self._ck(self.lib.asb_components_stream_into(self.h, ctypes.c_void_p(pin.ptr), pin.count))
         self._ck(self.lib.asb_deflate_begin(self.h, int(K), int(mode), int(bool(local_support))))
         self.K = int(K)
         self.mode = int(mode)
@@ -332,8 +376,16 @@ class HipEngine(object):
         self._ck(self.lib.asb_deflate_guessed_panels(self.h, ctypes.byref(g)))
         h, i = ctypes.c_int64(), ctypes.c_int64()
         self._ck(self.lib.asb_deflate_sketch_stats(self.h, ctypes.byref(h), ctypes.byref(i)))
+        j = ctypes.c_int64()
+        self._ck(self.lib.asb_deflate_switch_stats(self.h, ctypes.byref(j)))
         return dict(panels=a.value, refreshes=b.value, unproven_tried=c.value, unproven_kept=d.value, energy_passes=e.value,
-                    coop_fallbacks=f.value, guessed_panels=g.value, sketch_runs=h.value, sketch_reads=i.value)
+                    coop_fallbacks=f.value, guessed_panels=g.value, sketch_runs=h.value, sketch_reads=i.value,
+                    residual_switch_at=j.value)
+
+    def project_switch_residual(self, k):
+        """The run leaves the projection mode at component k and continues in the residual loop (asb.h)."""
+        self._ck(self.lib.asb_project_switch_residual(self.h, int(k)))
+        self.mode = _lib.DEFLATE_RESIDUAL
 
     def download_residual(self):
         out = np.empty((self.F, self.n_loc, 3))
@@ -609,18 +661,29 @@ class HipEngine(object):
         return row
 
     def components_stream(self, enable=True):
-        """Overlapped download of the basis into a pinned host buffer owned by the context (asb.h: asb_components_stream)."""
-        self._ck(self.lib.asb_components_stream(self.h, 1 if enable else 0))
+        """Overlapped download of the basis into pinned host memory (asb.h: asb_components_stream_into).  The buffer belongs
+        to THIS object and to the ndarrays ``components_pinned`` returns, not to the context: switching the stream off,
+        closing the engine or starting another run never frees or overwrites memory a live ndarray looks at."""
         self._streaming = bool(enable)
+        if not enable:
+            self._ck(self.lib.asb_components_stream_into(self.h, None, 0))
+            self._pin = None
 
     def components_pinned(self):
-        """(K, n_loc, 3) ndarray VIEW of the context's pinned buffer: valid until the next deflate_begin on this engine."""
+        """(K, n_loc, 3) ndarray over the pinned buffer the run streamed its basis into.  Safe to keep: the memory lives as
+        long as the array (or any view of it) does, and a later run on this engine takes a fresh buffer while it is alive."""
+        pin = getattr(self, "_pin", None)
+        if not getattr(self, "_streaming", False) or pin is None:
+            raise RuntimeError("components_pinned: components_stream(True) was not on when the run began")
         p = ctypes.c_void_p()
         self._ck(self.lib.asb_components_pinned(self.h, ctypes.byref(p)))
-        n = int(self.K) * int(self.n_loc) * 3
-        buf = (ctypes.c_double * n).from_address(p.value)
-        arr = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.K, self.n_loc, 3)
-        return arr
+        assert p.value == pin.ptr
+        return pin.view((int(self.K), int(self.n_loc), 3))
+
+    def deflate_reserve(self, K_new):
+        """Residual mode: room for K_new components in all, keeping what the run has produced (asb.h: asb_deflate_reserve)."""
+        self._ck(self.lib.asb_deflate_reserve(self.h, int(K_new)))
+        self.K = max(int(self.K), int(K_new))
 
     def results_comps(self):
         out = np.empty((self.K, self.n_loc, 3))

@@ -138,7 +138,8 @@ class GeodesicDistanceComputation(object):
     _PREPARED = frozenset(("G", "D", "_A_heat", "_L", "_engine", "_heat", "_poisson", "n_aggregates", "_tol"))
 
     def __getattr__(self, name):            # only reached for attributes that are not set (yet)
-        if name in GeodesicDistanceComputation._PREPARED and not self.__dict__.get("_ready", True):
+        if name in GeodesicDistanceComputation._PREPARED and not self.__dict__.get("_ready", True) \
+                and not self.__dict__.get("_preparing", False):
             self.prepare()
             return getattr(self, name)
         raise AttributeError(name)
@@ -147,9 +148,24 @@ class GeodesicDistanceComputation(object):
         """Operator assembly and solver set-up (idempotent)."""
         if self._ready:
             return self
+        if self.__dict__.get("_preparing"):
+            raise RuntimeError("GeodesicDistanceComputation.prepare() re-entered while the set-up is running")
+        self._preparing = True
+        try:
+            self._prepare(*self._args)
+        except BaseException:
+            # a failed set-up (size limit of the dense mode, hipMalloc, a singular factorisation) leaves the object as it was:
+            # the real error reaches the caller and prepare() can be tried again (e.g. with another ASB_GEODESIC)
+            for name in GeodesicDistanceComputation._PREPARED:
+                self.__dict__.pop(name, None)
+            raise
+        finally:
+            self._preparing = False
         self._ready = True
-        verts, tris, m, engine, tol, backend = self._args
         self._args = None
+        return self
+
+    def _prepare(self, verts, tris, m, engine, tol, backend):
         n, M = verts.shape[0], tris.shape[0]
         p0, p1, p2 = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
         e01, e12, e20 = p1 - p0, p2 - p1, p0 - p2

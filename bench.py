@@ -178,21 +178,57 @@ def other_config_pos(tag, fixture, support, kind, cpu=True):
     return out
 
 
-def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50, seed=77):
-    """config 4's shape on STRUCTURED data ("parity on low-rank + noise"): rest + coef (F x r) . modes (r x N x 3)
-    + 1e-4 noise, modes ~ N(0, 0.02^2), coef[:, j] ~ N(0, 0.9^2j) -- every strong component reshuffles all energies, so a read
-    of X commits fewer components than on the random tensor of the headline."""
+def structured_tensor(dev, kind, N, F, seed):
+    """Synthetic STRUCTURED inputs of config 4's shape (F, N, 3), seeded, generated on the device ("parity on
+    low-rank + noise"; what posComponents.py:67-129 is fed in practice is low-rank and localised):
+      lowrank         rest + coef (F x 50) . modes (50 x 3N) + 1e-4 noise, modes ~ N(0, 0.02^2), coef[:, j] ~ N(0, 0.9^2j)
+      slow_spectrum   the same with rank 200 and coef[:, j] ~ N(0, 0.97^2j)
+      bumps           50 localised modes: Gaussian bumps (radius 0.1 - 0.35 of the unit cube the rest vertices fill) along random
+                      directions, amplitude 0.1, coef as lowrank, + 1e-4 noise
+      rank_deficient  rank 40 (as lowrank) + 1e-12 noise: K = 128 reaches far beyond the numerical rank"""
     import torch
-    from animsnapbases_amd import posComponents, posSnapshots
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed))
-    rest = torch.randn((N * 3,), dtype=torch.float64, device=dev, generator=gen)
-    coef = torch.randn((F, r), dtype=torch.float64, device=dev, generator=gen) * (0.9 ** torch.arange(r, dtype=torch.float64, device=dev))[None]
-    modes = 0.02 * torch.randn((r, N * 3), dtype=torch.float64, device=dev, generator=gen)
-    Xd = rest[None] + coef @ modes
-    Xd += 1e-4 * torch.randn((F, N * 3), dtype=torch.float64, device=dev, generator=gen)
+    f64 = dict(dtype=torch.float64, device=dev)
+    if kind == "bumps":
+        r = 50
+        rest = torch.rand((N, 3), generator=gen, **f64)
+        modes = torch.empty((r, N, 3), **f64)
+        for j in range(r):
+            c = rest[int(torch.randint(N, (1,), generator=gen, device=dev))]
+            rad = 0.1 + 0.25 * float(torch.rand((1,), generator=gen, **f64))
+            d = torch.randn((3,), generator=gen, **f64)
+            modes[j] = torch.exp(-((rest - c) ** 2).sum(1) / rad ** 2)[:, None] * (d / d.norm())[None] * 0.1
+        coef = torch.randn((F, r), generator=gen, **f64) * (0.9 ** torch.arange(r, **f64))[None]
+        Xd = rest.reshape(1, -1) + coef @ modes.reshape(r, -1)
+        noise = 1e-4
+    else:
+        r, decay, noise = {"lowrank": (50, 0.9, 1e-4), "slow_spectrum": (200, 0.97, 1e-4), "rank_deficient": (40, 0.9, 1e-12)}[kind]
+        rest = torch.randn((N * 3,), generator=gen, **f64)
+        coef = torch.randn((F, r), generator=gen, **f64) * (decay ** torch.arange(r, **f64))[None]
+        modes = 0.02 * torch.randn((r, N * 3), generator=gen, **f64)
+        Xd = rest[None] + coef @ modes
+    Xd += noise * torch.randn((F, N * 3), generator=gen, **f64)
     del coef, modes, rest
     torch.cuda.synchronize()
+    return Xd.reshape(F, N, 3)
+
+
+STRUCTURED_NOTE = {
+    "lowrank": "low rank (50) + 1e-4 noise",
+    "slow_spectrum": "slowly decaying spectrum (rank 200, 0.97^j) + 1e-4 noise",
+    "bumps": "50 localised modes (Gaussian bumps) + 1e-4 noise",
+    "rank_deficient": "rank 40 + 1e-12 noise: K = 128 far beyond the numerical rank",
+}
+
+
+def other_config_c4_structured(dev, kind="lowrank", N=100000, F=2000, K=128, seed=77, residual_too=False):
+    """config 4's shape on STRUCTURED data (structured_tensor): every strong component reshuffles all energies, so a read of X
+    commits fewer components than on the random tensor of the headline.  residual_too: the same input through the residual loop
+    (ASB_DEFLATE_MODE=residual: one read + one write of R per component, the reference's own algorithm) beside it."""
+    import torch
+    from animsnapbases_amd import posComponents, posSnapshots
+    Xd = structured_tensor(dev, kind, N, F, seed)
     holder = {}
 
     def prep():
@@ -205,17 +241,33 @@ def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50, seed=77):
     _timed(lambda: comp.extract_k_components(None), sync)                 # warm-up
     ms, _ = _timed(lambda: comp.extract_k_components(None), sync)
     st = snaps._engine.deflate_stats()
-    assert len(set(comp.selected_vertices.tolist())) == K
+    # (beyond the numerical rank a vertex may be taken again: it has three directions to give)
+    assert kind == "rank_deficient" or len(set(comp.selected_vertices.tolist())) == K
+    assert np.isfinite(comp.measures_at_largeDeforVerts).all()
     reads = st["panels"] + st.get("energy_passes", 0) + st.get("refreshes", 0)
-    out = {"workload": "config4 shape, low rank (%d) + 1e-4 noise: %d verts x %d frames, PCA K=%d global" % (r, N, F, K),
+    ksw = st.get("residual_switch_at", -1)
+    # what THIS run moved: a read of X per panel pass / refresh, and one read + one write of R per component of the residual loop
+    nbytes = reads * 24.0 * N * F + (48.0 * N * F * (K - ksw) + 24.0 * N * F if ksw >= 0 else 0.0)
+    out = {"workload": "config4 shape, %s: %d verts x %d frames, PCA K=%d global" % (STRUCTURED_NOTE[kind], N, F, K),
            "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "prepare_ms": t_prep, "reads_of_X": reads, "panels": st["panels"],
            "refreshes": st.get("refreshes", 0), "sketch_replays": st.get("sketch_runs", 0),
-           "reads_with_predicted_candidates": st.get("sketch_reads", 0),
-           "roofline": {"bound": "hbm", "level": "call", "achieved": reads * 24.0 * N * F / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": reads * 24.0 * N * F / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "note": "(reads of X) x 24 N F bytes / wall time: what THIS algorithm reads on this data"}}
+           "reads_with_predicted_candidates": st.get("sketch_reads", 0), "residual_switch_at": ksw,
+           "roofline": {"bound": "hbm", "level": "call", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "(reads of X) x 24 N F bytes (+ 48 N F per component of the residual loop behind a switch) / wall "
+                                "time: what THIS algorithm moves on this data"}}
+    if residual_too:
+        comp.deflate_mode = "residual"
+        _timed(lambda: comp.extract_k_components(None), sync)
+        ms_r, _ = _timed(lambda: comp.extract_k_components(None), sync)
+        out["residual_mode_ms"] = ms_r
+        out["note"] = "residual_mode_ms: the same input through the residual loop from the start (ASB_DEFLATE_MODE=residual)"
     del comp, snaps, holder
     return out
+
+
+def other_config_c4_lowrank(dev, N=100000, F=2000, K=128, r=50, seed=77):
+    return other_config_c4_structured(dev, "lowrank", N, F, K, seed)
 
 
 def other_config_c4_lowrank_seeds(dev, seeds=(77, 78, 79)):
@@ -341,6 +393,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic tensor of the timed steps (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the other_configs legs to run (default: all)")
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default): --verts vertices in all, sharded over the ranks (config 4 is one fixed job); "
@@ -572,11 +625,16 @@ def main():
         cpu = not args.no_cpu_baseline
         oc = {}
         for tag, fn in (("c4_lowrank", lambda: other_config_c4_lowrank_seeds(dev)),
+                        ("c4_bumps", lambda: other_config_c4_structured(dev, "bumps", seed=5)),
+                        ("c4_slow_spectrum", lambda: other_config_c4_structured(dev, "slow_spectrum", seed=5)),
+                        ("c4_rank_deficient", lambda: other_config_c4_structured(dev, "rank_deficient", seed=5, residual_too=True)),
                         ("c4_other_seeds", lambda: other_config_c4_seeds(dev)),
                         ("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
                         ("c2_local", lambda: other_config_pos("config2 (local support)", "c2_bunny_pca_local", "local", "PCA", cpu)),
                         ("c3", lambda: other_config_pos("config3", "c3_armadillo_splocs", "local", "SPLOCS", cpu)),
                         ("c5", lambda: other_config_c5(dev, cpu))):
+            if args.legs and tag not in args.legs.split(","):
+                continue
             try:
                 oc[tag] = fn()
             except Exception as e:                        # the headline line must still be printed

@@ -224,6 +224,17 @@ int asb_deflate_guessed_panels(asb_ctx* ctx, int64_t* n);
  * candidates by energy do as well; the kernel decides that itself (one exchange) and otherwise leaves the plain selection.
  * *runs = replays in the last run, *reads = reads of X whose candidates came from one.  ASB_SKETCH=0 switches it off. */
 int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads);
+/* Leaving the projection mode in mid-run.  The panel algorithm proves its winners against bounds kept in the energy recurrence;
+ * where that cannot work -- K beyond the numerical rank of the data: the residual is rounding noise, nothing is provable and
+ * every panel ends in an exact refresh, ~5 reads of X per component -- the reference's own loop (posComponents.py:76-96: keep R,
+ * one read + one write per component) is the cheaper algorithm.  asb_project_switch_residual(ctx, k), k = components committed
+ * so far: R_k = X - sum_{j<k} w_j (x) c_j is written out once, the per-component scalars are converted, and the context is in
+ * residual mode from there on (asb_deflate_local_best / _pick / _apply / _results as if the run had begun in it).
+ * asb_deflate_run_global does this by itself (single rank) once the reads of X of the last >= 8 committed fewer than 3/4 of a
+ * component each (ASB_STALL_FALLBACK=0: never); several ranks: the driver applies the same rule (_panels.py).
+ * asb_deflate_switch_stats: the component at which the last run switched, -1 if it did not. */
+int asb_project_switch_residual(asb_ctx* ctx, int64_t k);
+int asb_deflate_switch_stats(asb_ctx* ctx, int64_t* k_switch);
 /* The same for the multi-rank driver (animsnapbases_amd/_panels.py).  asb_panel_guess_stats: this shard's energy along the
  * constant direction, its |X|^2 and whether the context could guess at all (0: both values are 0); the ranks sum all three
  * and guess only if every rank can and the share exceeds 1/4.  asb_panel_guess_begin (before the first panel's
@@ -304,6 +315,9 @@ int asb_st_upload(asb_ctx* ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, con
 int asb_st_residual_argmax(asb_ctx* ctx, int64_t* v_out, double* val_out);
 /* |R|_F^2 of the residual-mode deflation right now (the loop condition `while norm(R) > tol`, :179, :252) */
 int asb_deflate_residual_norm2(asb_ctx* ctx, double* out);
+/* residual mode: room for K_new >= K components in all; W / comps / scalars grow, what the run produced so far is kept (loops
+ * that end on a tolerance -- :179 `while norm(R) > tol` -- reserve a little and grow geometrically, as the reference's lists do) */
+int asb_deflate_reserve(asb_ctx* ctx, int64_t K_new);
 /* geom_block_form_utilizing_differential_operator(error_in_pos_space=True) (:652-672): residual of basis block k as
  * asb_deim_block_residual, mapped to position space by S^T ((|V|) x (3 p)); first arg-max of its squared row norms */
 int asb_deim_block_residual_st(asb_ctx* ctx, int64_t k, int p, const double* coef_host, double* maxabs_out, int64_t* v_out,
@@ -313,8 +327,15 @@ int asb_deim_block_residual_st(asb_ctx* ctx, int64_t k, int p, const double* coe
  * (K, n_loc, 3) buffer and a copy stream; every component row is copied as soon as it is final (projection mode: after each
  * read of X, while the next read runs; otherwise at the end).  asb_components_pinned waits for the copies and returns the
  * buffer: valid until the next asb_deflate_begin / destroy on this context (the caller copies what it wants to keep).
- * asb_components_stream(ctx, 0) switches it off and frees the buffer. */
+ * asb_components_stream(ctx, 0) switches it off and frees the buffer.
+ * asb_components_stream_into: the same into a pinned buffer the CALLER owns (`count` doubles >= K n_loc 3 of the runs that
+ * follow, or asb_deflate_begin fails; NULL: off) -- for callers that hand the buffer on (the Python engine's ndarray views):
+ * the context never frees it and stops writing to it with the next _into / asb_components_stream(ctx, 0) / asb_destroy.
+ * asb_host_alloc / asb_host_free: pinned host memory for such a buffer (hipHostMalloc / hipHostFree; no context). */
 int asb_components_stream(asb_ctx* ctx, int enable);
+int asb_components_stream_into(asb_ctx* ctx, double* pinned_host, int64_t count);
+int asb_host_alloc(int64_t count, double** out);
+int asb_host_free(double* p);
 int asb_components_pinned(asb_ctx* ctx, double** comps_pinned_out);
 /* installs a caller-assigned basis (host, K x n_loc x 3) as the device-resident one */
 int asb_components_upload(asb_ctx* ctx, const double* comps_host, int64_t K);
