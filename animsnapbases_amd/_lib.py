@@ -98,6 +98,10 @@ PROTOTYPES = {
     "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_sketch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_project_switch_residual": (c_int, [ctypes.c_void_p, c_i64]),
+    "asb_panel_read_run": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_int), ctypes.c_void_p,
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "asb_panel_read_commit": (c_int, [ctypes.c_void_p, c_dp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "asb_fetch_doubles": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_dp]),
     "asb_deflate_switch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_panel_guess_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(c_int)]),

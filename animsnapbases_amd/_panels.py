@@ -3,6 +3,22 @@ constraintsComponents 'pca_blocks' with p = 1 (constraint rows)."""
 import numpy as np
 
 
+def _residual_rest(eng, comm, k0, K):
+    """Components k0 .. K - 1 through the residual protocol (posComponents.py:76-96 as is: one all-gather of
+    [energy, idx, 3 x F slab] records per component) -- where a run ends up that left the projection mode."""
+    rec = recs = None
+    if comm.multi:
+        rec, recs = comm.new_records(eng.xchg_len(), eng.device_exchange)
+    for k in range(k0, K):
+        if comm.multi:
+            eng.local_best(k, rec.data_ptr())
+            comm.all_gather_records(rec, recs)
+            eng.pick(k, recs.data_ptr(), comm.world)
+        else:
+            eng.pick(k)
+        eng.apply(k)
+
+
 def deflate_panels_multirank(eng, comm, n_rows, K):
     """Projection-mode deflation over several ranks.  Per PANEL (up to 16 components):
       1. every rank thresholds its OWN energies (two local histogram steps, no collective) and exports its ~768 largest
@@ -24,7 +40,15 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     cap, rl = eng.panel_capacity(), eng.panel_row_len()
     m_target = eng.panel_target()
     _, e0 = eng.panel_scale()
-    eng.panel_scale(set_e0max=float(comm.allreduce_max(e0)[0]))
+    # ONE start-up exchange: the largest initial energy (histogram range and rounding margin must be the same everywhere) and
+    # what decides the guessed first panel travel together, as bit patterns in one all-gather of four words per rank
+    gs = (0.0, 0.0, True)
+    want_guess = hasattr(eng, "panel_guess_stats") and os.environ.get("ASB_FIRST_PANEL_MEAN", "1") != "0"
+    if want_guess:
+        gs = eng.panel_guess_stats()
+    start = np.array([e0, gs[0], gs[1], 0.0 if gs[2] else 1.0], dtype=np.float64)
+    allst = comm.all_gather_ints(start.view(np.int64)).view(np.float64).reshape(-1, 4)
+    eng.panel_scale(set_e0max=float(allst[:, 0].max()))
     # exchange buffers, kept on the engine between calls (49 MB: allocating and clearing them cost 1.3 ms per call).
     # Nothing reads the padding: the assembly takes counts[r] rows of rank r's piece.
     key = (cap, rl, comm.world, str(dev))
@@ -54,9 +78,8 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     # first panel guessed from the energies without the constant-in-time direction (asb.h: asb_panel_guess_*): a collective
     # decision -- every rank must be able to, and the share of that direction in |X|^2 over ALL shards must exceed 1/4
     guess_ok = False
-    if spec_budget and not global_all and hasattr(eng, "panel_guess_stats") and os.environ.get("ASB_FIRST_PANEL_MEAN", "1") != "0":
-        me, nx, possible = eng.panel_guess_stats()
-        tot = comm.allreduce_sum([me, nx, 0.0 if possible else 1.0])
+    if spec_budget and not global_all and want_guess:
+        tot = allst[:, 1:].sum(axis=0)
         guess_ok = bool(tot[2] == 0 and tot[1] > 0 and tot[0] > 0.25 * tot[1])
     guessing = False
     # several sub-panels per read (see the loop): only with the real engine, the co-resident kernel and device-side counts
@@ -65,11 +88,27 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
     sub_max = max(1, min(4, int(os.environ.get("ASB_SUB_PANELS", "4"))))
     sub_cur = min(sub_max, max(1, int(os.environ.get("ASB_SUB_FIRST", "4"))))
     sub_budget = [16] * 8
+    # the read in one launch + one exchange (round 4); ASB_SUB_CHAIN=0: one launch and one exchange per sub-panel / tile (round 2)
+    one_launch = bool(multi_sub and hasattr(eng, "panel_read_run") and os.environ.get("ASB_SUB_CHAIN", "1") != "0")
+    words = torch.zeros(10, dtype=torch.float64, device=dev) if one_launch else None
+    n_collectives = [0]
+    # the stall rule of the single-rank driver (asb.h: asb_project_switch_residual): reads of X that commit fewer than 3/4 of a
+    # component each (K beyond the numerical rank: every panel ends in a refresh) -- the run continues in the residual protocol
+    stall_rule = hasattr(eng, "project_switch_residual") and os.environ.get("ASB_STALL_FALLBACK", "1") != "0"
+    mark_reads = mark_k = reads = 0
     k, stalled, forced_next = 0, 0, -1
     while k < K:
         if guessing:
             eng.panel_guess_end()
             guessing = False
+        if stall_rule and reads - mark_reads >= 8:           # (every quantity below is the same on all ranks)
+            slow = (k - mark_k) * 4 < (reads - mark_reads) * 3
+            mark_reads, mark_k = reads, k
+            if slow:
+                eng.project_switch_residual(k)
+                _residual_rest(eng, comm, k, K)
+                return k
+        reads += 1
         forced = forced_next if stalled >= 2 else -1
         take_all = forced >= 0 or global_all
         if not take_all:
@@ -127,7 +166,39 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
             # identical everywhere -- except that the kernel can time out on one rank: the first exchange carries the
             # status, and on a failure all ranks switch the kernel off and repeat the panel the plain way.
             handled = multi_sub and spec_budget and not take_all and stalled == 0 and K - k > 16
-            if handled:
+            if handled and one_launch:
+                # ONE launch of the panel kernel for all sub-panels of the read (every rank holds the same candidates, so the
+                # runs and their nine-word summary are identical everywhere), this shard's pass and the checks of all its tiles
+                # enqueued behind it, ONE min-all-reduce of the per-tile counts (+ the kernel's status) for the whole read, one
+                # host read (asb.h: asb_panel_read_run / _commit).  Per read of X: two all-gathers (energies; rows + ids) and
+                # this all-reduce.
+                n_collectives[0] += 1
+                nt, ncs, provs = eng.panel_read_run(k, K, sub_cur, spec_budget, sub_budget, words.data_ptr())
+                comm.allreduce_min_tensor(words[:9])
+                w10 = eng.fetch_doubles(words.data_ptr(), 10) if same_stream else words.cpu().numpy()
+                if w10[8] < 0:                                # somewhere the exchange timed out: all ranks leave the kernel
+                    w10[:9] = 0.0
+                    eng.panel_read_commit(w10)                # (rolls back what this shard's local chain adopted; commits nothing)
+                    eng.panel_set_coop(False)
+                    coop_check = multi_sub = guess_ok = False     # (unproven steps, and with them the guess, need the kernel)
+                    continue                                  # the panel again, from the selection, the plain way
+                total, full, rejected = eng.panel_read_commit(w10)
+                if nt > 0:
+                    for ct in range(1, nt):
+                        if ct <= full:
+                            sub_budget[ct] = min(16, max(4, int(w10[ct]) + 2))
+                    if rejected:
+                        sub_cur = min(sub_max, full + 1)
+                    elif nt == sub_cur:
+                        sub_cur = min(sub_max, 2 * sub_cur)
+                    gain = total - provs[0]
+                    spec_budget = 16 if gain > 0 else max(2, spec_budget // 2)
+                if total > 0:
+                    stalled = 0
+                    k += total
+                    continue
+                done = 0                                      # nothing stood: the refresh below
+            if handled and not one_launch:
                 tiles, failed = [], False
                 for sp in range(sub_cur):
                     kb = k + 16 * sp
@@ -249,3 +320,4 @@ def deflate_panels_multirank(eng, comm, n_rows, K):
         k += done
     if guessing:
         eng.panel_guess_end()
+    return K

@@ -25,6 +25,7 @@ import sys
 import numpy as np
 
 from . import _lib
+from . import utils as _u
 from ._panels import deflate_panels_multirank
 from .distributed import Comm
 from .engine import HipEngine
@@ -217,14 +218,12 @@ class nonlinearSnapshots:
     def load_factorize_masses(self):
         """nonlinear_snapshots.py:178-265.  The mass FILE branch (:180-191: the simulator's auxiliary masses, ``<i n><i m>`` +
         n doubles, one per constraint row) and the factorisation (:244-262: massL = sqrt(mass), invMassL = 1 / massL with 0
-        where the mass is 0) are built; a per-row vector can also be handed over directly (``mass=``; ``.npy``).  Deriving
-        the masses from the MESH (:192-240) needs libigl's Voronoi / tet mass matrices, absent from this image: that branch
-        raises (parity unpinned)."""
+        where the mass is 0); a per-row vector can also be handed over directly (``mass=``; ``.npy``).  Without a file the
+        masses come from the MESH (:192-240, ``_masses_from_mesh``)."""
         m = self._preset_mass
+        if m is None and (not self.mass_file or not os.path.exists(self.mass_file)):
+            m = self._masses_from_mesh()
         if m is None:
-            if not self.mass_file or not os.path.exists(self.mass_file):
-                raise NotImplementedError("element masses from the mesh need libigl (absent here); give constProj_masses_file "
-                                          "(the recorder's .bin or a .npy) or pass mass=")
             if self.mass_file.lower().endswith(".npy"):
                 m = np.load(self.mass_file)
             else:
@@ -239,6 +238,48 @@ class nonlinearSnapshots:
         np.divide(1.0, massL, out=invMassL, where=massL != 0)
         assert np.allclose(invMassL * massL, np.ones_like(massL))             # (:258, as the reference: a zero mass fails here)
         self.massL, self.invMassL = massL, invMassL
+
+    def _masses_from_mesh(self):
+        """nonlinear_snapshots.py:192-240: per constraint row, the summed vertex masses of its element.  The element sums
+        (utils/support.py:12-76) and the tetrahedral lumping of the volumetric p = 1 branch (``compute_lumped_mass_matrix``,
+        :41-59) are the reference's own arithmetic, pinned by tests/golden/mesh_masses.npz; the VERTEX masses of the other
+        branches come from libigl in the reference (``igl.massmatrix``: mixed Voronoi areas on triangles, a quarter of the
+        volume per corner on tetrahedra) and are restated from their definitions here (no libigl in this image: "parity
+        unpinned", checked against closed forms)."""
+        p = self.param
+        size = int(self.constraintsSize)
+        tet_mesh, tri_mesh = getattr(p, "tet_mesh_file", None), getattr(p, "tri_mesh_file", None)
+        n_el = int(self.num_constained_elements)
+        if size == 1:
+            if getattr(p, "volumetric_mesh", False):
+                self.verts, self.tets, self.tris = _u.read_mesh_file(tet_mesh)
+                vm = _u.lumped_tet_vertex_masses(self.verts, self.tets)                       # (:210)
+            else:
+                self.verts, self.tris = _u.read_triangle_mesh(tri_mesh)
+                vm = _u.voronoi_vertex_masses(self.verts, self.tris)                          # (:213)
+            kind = getattr(p, "constProj_snapshots_type", "")
+            if kind == "verts_bending":
+                verts = np.load(p.constProj_input_snaps_constrained_elements)["indices"]
+                return vm[verts]
+            if kind == "edge_spring":
+                self.edges = _u.mesh_edges(self.tets if getattr(p, "volumetric_mesh", False) else self.tris)
+                if self.edges.shape[0] != n_el:
+                    raise ValueError("the mesh has %d edges, the snapshots %d constrained elements" % (self.edges.shape[0], n_el))
+                return _u.element_masses(vm, self.edges, size)
+            raise ValueError("masses from the mesh: unknown constProj_snapshots_type %r for p = 1" % (kind,))
+        if size == 2:
+            self.verts, self.tris = _u.read_triangle_mesh(tri_mesh)
+            vm = _u.voronoi_vertex_masses(self.verts, self.tris)
+            if self.tris.shape[0] != n_el:
+                raise ValueError("the mesh has %d triangles, the snapshots %d constrained elements" % (self.tris.shape[0], n_el))
+            return _u.element_masses(vm, self.tris, size)
+        if size == 3:
+            self.verts, self.tets, self.tris = _u.read_mesh_file(tet_mesh)
+            vm = _u.tet_barycentric_vertex_masses(self.verts, self.tets)
+            if self.tets.shape[0] != n_el:
+                raise ValueError("the mesh has %d tetrahedra, the snapshots %d constrained elements" % (self.tets.shape[0], n_el))
+            return _u.element_masses(vm, self.tets, size)
+        raise ValueError("masses from the mesh: constraint size %d" % size)
 
     def standarize(self, _fused=None):
         """nonlinear_snapshots.py:268-288 (``_fused``: sum(x), sum(x^2) when the upload sweep already removed the rest

@@ -3115,6 +3115,10 @@ extern "C" int asb_fetch_double(asb_ctx* ctx, const double* dev, double* out) {
     if (!ctx || !dev || !out) return ASB_ERR_ARG;
     return fetch_words(ctx, dev, 1, out);
 }
+extern "C" int asb_fetch_doubles(asb_ctx* ctx, const double* dev, int n, double* out) {
+    if (!ctx || !dev || !out || n < 1 || n > 16) return ASB_ERR_ARG;
+    return fetch_words(ctx, dev, n, out);
+}
 // multi-rank driver: switch the co-resident panel kernel on / off for this context (all ranks together); returns the old value
 extern "C" int asb_panel_set_coop(asb_ctx* ctx, int on) {
     if (!ctx) return ASB_ERR_ARG;
@@ -3696,6 +3700,161 @@ extern "C" int asb_panel_sub_commit(asb_ctx* ctx, int ct, int64_t kb, int nc, in
     if (kept > 0) ctx->k_done = kb + kept;
     ctx->n_spec_steps += nc;
     ctx->n_spec_kept += kept;
+    return ASB_OK;
+}
+
+// ---- round 4: the multi-rank read in THREE calls and ONE exchange, level with the single-rank chain.
+//   asb_panel_read_run     all sub-panels of the read in ONE launch of k_panel_multi on the ASSEMBLED candidates (identical on
+//                          every rank, so the nine-word summary is too), the read's pass over this shard enqueued behind it on
+//                          the expected column counts, the checks of all its tiles enqueued behind that with the LOCAL chain
+//                          (a tile counts on this shard only behind tiles that stood in full on this shard); leaves
+//                          words_dev[ct] = columns of tile ct that stand on this shard (nc[ct] for a tile not reached: neutral
+//                          under min) and words_dev[ASB_MAX_SUB] = status (0, or -1: the launch's exchange timed out here)
+//   -- the driver min-all-reduces words_dev (ASB_MAX_SUB + 1 doubles) over the ranks and reads it once --
+//   asb_panel_read_commit  the verdict for all ranks: tiles stand in full while min == nc, the first one below keeps min columns,
+//                          nothing behind it; where the local chain ran ahead of that (a tile stood here, not elsewhere) the
+//                          energies go back to their values at the start of the read and the verdict is applied column by column
+__global__ void k_read_words(const long long* __restrict__ res, int ntile, WideArgs wa, double status, double* __restrict__ words) {
+    const int t = threadIdx.x;
+    if (t < ASB_MAX_SUB) words[t] = t < ntile ? (res[t] < 0 ? (double)wa.nc[t] : (double)res[t]) : 0.0;
+    if (t == ASB_MAX_SUB) words[t] = status;
+    if (t == ASB_MAX_SUB + 1) {          // the local counts once more, packed (base 32), OUTSIDE the part the ranks reduce
+        double p = 0.0, b = 1.0;
+        for (int ct = 0; ct < ASB_MAX_SUB; ++ct, b *= 32.0) p += b * (ct < ntile ? (res[ct] < 0 ? (double)wa.nc[ct] : (double)res[ct]) : 0.0);
+        words[t] = p;
+    }
+}
+extern "C" int asb_panel_read_run(asb_ctx* ctx, int64_t k0, int64_t k1, int nsub_max, int spec_budget, const int* sub_budget,
+                                  double* words_dev, int* ntile_out, int* nc_out, int* proven_out) {
+    if (!ctx || !ctx->candR || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !words_dev || !ntile_out || !nc_out || !proven_out)
+        return ASB_ERR_ARG;
+    if (k0 < 0 || k1 > ctx->K || k0 >= k1 || nsub_max < 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_read_run: bad range");
+    if (!(ctx->panel_coop && ctx->spec_panels && ctx->Fp <= 2048 && ctx->pre_orth && ctx->correct_rows))
+        ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_read_run needs the co-resident panel kernel (and F <= 2048)");
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const int save_budget = ctx->spec_budget;
+    int save_sub[8];
+    for (int q = 0; q < 8; ++q) { save_sub[q] = ctx->sub_budget[q]; if (sub_budget) ctx->sub_budget[q] = sub_budget[q]; }
+    ctx->spec_budget = spec_budget;
+    int ntile = -1, nc[ASB_MAX_SUB] = {0}, proven[ASB_MAX_SUB] = {0}, spec_ntile = 0, spec_nc[ASB_MAX_SUB] = {0};
+    const int nlim = nsub_max > ASB_MAX_SUB ? ASB_MAX_SUB : nsub_max;
+    rc = multi_chain_run(ctx, k0, k1, nlim, &ntile, nc, proven, &spec_ntile, spec_nc, true);
+    ctx->spec_budget = save_budget;
+    for (int q = 0; q < 8; ++q) ctx->sub_budget[q] = save_sub[q];
+    if (rc) return rc;
+    WideArgs wa{};
+    double status = 0.0;
+    if (ntile < 0 || ctx->chain_timed_out) {          // the exchange timed out on THIS rank: every rank must leave the kernel together
+        status = -1.0;
+        if (ntile < 0) ntile = 0;
+        if (!ctx->chain_timed_out) {                   // (the launch could not be made at all)
+            ctx->n_coop_fallbacks++;
+        } else if (ctx->panel_coop) {
+            ctx->panel_coop = 0;
+            ctx->coop_test_stall = 0;
+            ctx->n_coop_fallbacks++;
+        }
+        ntile = 0;
+    }
+    long long kb[ASB_MAX_SUB];
+    PanelState* st[ASB_MAX_SUB];
+    for (int ct = 0; ct < ASB_MAX_SUB; ++ct) {
+        kb[ct] = k0 + (long long)ct * ASB_PANEL_COLS;
+        st[ct] = ctx->pstate2 + ct;
+        wa.kb[ct] = kb[ct];
+        wa.nc[ct] = ct < ntile ? nc[ct] : 0;
+    }
+    ctx->rd_k0 = k0;
+    ctx->rd_ntile = ntile;
+    for (int ct = 0; ct < 8; ++ct) { ctx->rd_nc[ct] = ct < ntile ? nc[ct] : 0; ctx->rd_proven[ct] = ct < ntile ? proven[ct] : 0; }
+    if (ntile > 0) {
+        bool covered = spec_ntile >= ntile;
+        for (int ct = 0; covered && ct < ntile; ++ct) covered = spec_nc[ct] >= nc[ct];
+        if (!covered) {
+            if ((rc = dbl_build_tiles(ctx, ntile, wa))) return rc;
+            if ((rc = launch_wide(ctx, ntile, wa))) return rc;
+        }
+        int rgrid = 0, cgrid = 0;
+        if ((rc = tiles_enqueue(ctx, ntile, kb, nc, st, &rgrid, &cgrid))) return rc;
+        ctx->rd_rgrid = rgrid;
+    }
+    hipLaunchKernelGGL(k_read_words, dim3(1), dim3(64), 0, ctx->stream, ctx->tile_res, ntile, wa, status, words_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    *ntile_out = ntile;
+    for (int ct = 0; ct < ASB_MAX_SUB; ++ct) { nc_out[ct] = ct < ntile ? nc[ct] : 0; proven_out[ct] = ct < ntile ? proven[ct] : 0; }
+    return ASB_OK;
+}
+// words (host, ASB_MAX_SUB + 2 doubles): [0, ASB_MAX_SUB] after the min over the ranks, [ASB_MAX_SUB + 1] this rank's own counts as
+// asb_panel_read_run packed them.  *total = components the read commits (the same number on every rank).
+extern "C" int asb_panel_read_commit(asb_ctx* ctx, const double* words, int64_t* total_out, int* full_out, int* rejected_out) {
+    if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT || !words || !total_out) return ASB_ERR_ARG;
+    const int ntile = ctx->rd_ntile;
+    const double* words_min = words;
+    double words_local[ASB_MAX_SUB];
+    {
+        long long p = (long long)words[ASB_MAX_SUB + 1];
+        for (int ct = 0; ct < ASB_MAX_SUB; ++ct, p /= 32) words_local[ct] = (double)(p % 32);
+    }
+    long long cw = (ctx->n_loc + 255) / 256;
+    const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    // the verdict
+    int keep[ASB_MAX_SUB] = {0}, nstand = 0;             // keep[ct]: columns of tile ct that are committed; nstand: tiles that take part
+    for (int ct = 0; ct < ntile; ++ct) {
+        const int g = (int)words_min[ct];
+        if (g < 0 || g > ctx->rd_nc[ct]) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_panel_read_commit: bad count %d for tile %d", g, ct);
+        keep[ct] = g;
+        nstand = ct + 1;
+        if (g < ctx->rd_nc[ct]) break;
+    }
+    // what the local chain did: it adopted the tentative energies of tiles 0 .. l_full - 1 (stood in full HERE, consecutively)
+    int l_full = 0;
+    while (l_full < ntile && (int)words_local[l_full] == ctx->rd_nc[l_full]) {
+        // (a tile "not reached" locally also reads nc: it lies behind a local failure, so the loop has stopped before it)
+        ++l_full;
+    }
+    int g_full = 0;
+    while (g_full < nstand && keep[g_full] == ctx->rd_nc[g_full]) ++g_full;
+    int64_t total = 0;
+    auto commit_cols = [&](int ct, int cols) {
+        hipLaunchKernelGGL(k_commit_energy, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
+                           (long long)ctx->n_loc, (int)(ctx->rd_k0 + 16 * ct), ctx->pstate2 + ct, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax,
+                           ctx->pidx, ctx->psum, ctx->colpart, cols);
+        ctx->nblk = cgrid;
+        hipLaunchKernelGGL(k_colsum, dim3(1), dim3(1024), 0, ctx->stream, ctx->colpart, ctx->nblk, cols, (long long)(ctx->rd_k0 + 16 * ct),
+                           ctx->scal, (PanelState*)nullptr);
+    };
+    if (l_full > g_full) {
+        // this shard ran ahead of the verdict: back to the energies at the start of the read, then the verdict column by column
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->energy, ctx->e_class, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        for (int ct = 0; ct < nstand; ++ct)
+            if (keep[ct] > 0) commit_cols(ct, keep[ct]);
+    } else {
+        // l_full == g_full (the minimum cannot stand where this shard did not): the full tiles are adopted, the partial one --
+        // its energies untouched -- keeps its head
+        ctx->nblk = ctx->rd_rgrid;
+        if (g_full < nstand && keep[g_full] > 0) commit_cols(g_full, keep[g_full]);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    bool rejected = false;
+    int full = 0;
+    for (int ct = 0; ct < nstand; ++ct) {
+        total += keep[ct];
+        ctx->n_spec_steps += ctx->rd_nc[ct] - ctx->rd_proven[ct];
+        ctx->n_spec_kept += keep[ct] > ctx->rd_proven[ct] ? keep[ct] - ctx->rd_proven[ct] : 0;
+        if (keep[ct] < ctx->rd_nc[ct]) rejected = true; else ++full;
+    }
+    if (total > 0) ctx->k_done = ctx->rd_k0 + total;
+    *total_out = total;
+    if (full_out) *full_out = full;
+    if (rejected_out) *rejected_out = rejected ? 1 : 0;
     return ASB_OK;
 }
 

@@ -52,14 +52,38 @@ class Comm(object):
         # the stream RCCL collectives are enqueued on (torch's current stream when the communicator was made): a consumer
         # may rely on stream order between a collective and an engine's kernels only if the engine runs on this very stream
         self.stream_handle = None
+        # STAGED collectives: a gloo group with the shards on GPUs (several processes on ONE GPU: the launch rehearsal of
+        # bench.py --gpus N on the one-GPU box, tests/test_gpu_launch.py).  Exchange tensors stay device tensors -- the engine
+        # writes and reads them with kernels --, every collective synchronises the device, runs on a host copy and copies back.
+        self._staged = False
         if self.multi:
             import torch
 
             self._torch = torch
             backend = self.dist.get_backend(group)
-            self._dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+            self._staged = bool(backend == "gloo" and torch.cuda.is_available() and os.environ.get("ASB_GLOO_STAGED", "1") != "0")
+            self._dev = torch.device("cuda", torch.cuda.current_device()) if (backend == "nccl" or self._staged) else torch.device("cpu")
             if backend == "nccl":
                 self.stream_handle = int(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------ the two primitives everything below is made of
+    def _all_reduce(self, t, op):
+        if self._staged and t.is_cuda:
+            self._torch.cuda.synchronize()
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+            return
+        self.dist.all_reduce(t, op=op, group=self.group)
+
+    def _all_gather(self, out, inp):
+        if self._staged and (out.is_cuda or inp.is_cuda):
+            self._torch.cuda.synchronize()
+            h = self._torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(h, inp.cpu(), group=self.group)
+            out.copy_(h)
+            return
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def on_engine_stream(self, eng):
         """True iff collectives issued now are stream-ordered against ``eng``'s kernels (same HIP stream)."""
@@ -96,7 +120,7 @@ class Comm(object):
             return a.copy()
         t = self._scratch("red", a.size, self._torch.float64)
         t.copy_(self._torch.from_numpy(np.ascontiguousarray(a).reshape(-1)), non_blocking=False)
-        self.dist.all_reduce(t, op=op, group=self.group)
+        self._all_reduce(t, op)
         return t.cpu().numpy().reshape(a.shape)
 
     def allreduce_sum(self, values):
@@ -115,7 +139,7 @@ class Comm(object):
         t = self._scratch("gi_in", n, self._torch.int64)
         out = self._scratch("gi_out", self.world * n, self._torch.int64)
         t.copy_(self._torch.from_numpy(np.ascontiguousarray(a)))
-        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        self._all_gather(out, t)
         return out.cpu().numpy().reshape(self.world, n)
 
     def _need_torch(self):
@@ -134,12 +158,12 @@ class Comm(object):
         if not self.multi:
             out.copy_(inp)
             return
-        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        self._all_gather(out, inp)
 
     def allreduce_min_tensor(self, t):
         """In-place MIN over ranks of a (device) tensor; the caller reads it."""
         if self.multi:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            self._all_reduce(t, self.dist.ReduceOp.MIN)
 
     def new_records(self, xlen, on_device):
         """(rec, recs): one exchange record and the gathered (world, xlen) buffer."""
@@ -152,10 +176,10 @@ class Comm(object):
     def all_gather_records(self, rec, recs):
         if rec.device.type != self._dev.type:      # e.g. CPU records with an nccl group (not used by the product)
             r, rs = rec.to(self._dev), recs.to(self._dev)
-            self.dist.all_gather_into_tensor(rs, r, group=self.group)
+            self._all_gather(rs, r)
             recs.copy_(rs)
             return
-        self.dist.all_gather_into_tensor(recs, rec, group=self.group)
+        self._all_gather(recs, rec)
 
     def new_gram_buffers(self, F, K, on_device):
         """Device buffers for the partial Gram matrices P (F x K) and M (K x K) of SPLOCS."""
@@ -169,7 +193,7 @@ class Comm(object):
 
     def allreduce_tensor(self, t):
         if self.multi:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(t, self.dist.ReduceOp.SUM)
 
     def global_argmax(self, idx, val):
         """Per entry k: the (val, idx) pair with the largest val over ranks, lowest idx on ties (NumPy's first-max rule
@@ -180,7 +204,7 @@ class Comm(object):
         loc = self._scratch("am_in", 2 * n, self._torch.float64)
         out = self._scratch("am_out", 2 * n * self.world, self._torch.float64)
         loc.copy_(self._torch.from_numpy(np.concatenate([np.asarray(val, dtype=np.float64), idx.astype(np.float64)])))
-        self.dist.all_gather_into_tensor(out, loc, group=self.group)
+        self._all_gather(out, loc)
         allv = out.view(self.world, 2, n)
         vals, ids = allv[:, 0, :], allv[:, 1, :]
         top = vals.max(dim=0).values
@@ -201,7 +225,7 @@ class Comm(object):
         piece = torch.zeros(nmax * per, dtype=torch.float64, device=self._dev)
         piece[:loc.shape[0] * per].copy_(torch.from_numpy(np.ascontiguousarray(loc, dtype=np.float64).reshape(-1)))
         out = torch.empty(self.world * nmax * per, dtype=torch.float64, device=self._dev)
-        self.dist.all_gather_into_tensor(out, piece, group=self.group)
+        self._all_gather(out, piece)
         full = out.cpu().numpy().reshape((self.world, nmax) + rest)
         parts = [full[r, :n] for r, (_, n) in enumerate(shards)]
         res = np.concatenate(parts, axis=0)

@@ -351,6 +351,28 @@ class HipEngine(object):
         self._ck(self.lib.asb_fetch_double(self.h, ctypes.c_void_p(dev_ptr), ctypes.byref(v)))
         return v.value
 
+    def fetch_doubles(self, dev_ptr, n):
+        out = np.empty(int(n))
+        self._ck(self.lib.asb_fetch_doubles(self.h, ctypes.c_void_p(dev_ptr), int(n), ptr(out)))
+        return out
+
+    def panel_read_run(self, k0, k1, nsub_max, spec_budget, sub_budget, words_dev_ptr):
+        """All sub-panels of a multi-rank read in one launch, pass and tile checks behind it (asb.h: asb_panel_read_run):
+        (ntile, [columns per tile], [provable head per tile]); the verdict words are left at words_dev_ptr (10 doubles)."""
+        nt = ctypes.c_int(0)
+        nc, pr = (ctypes.c_int * 8)(), (ctypes.c_int * 8)()
+        sb = (ctypes.c_int * 8)(*[int(x) for x in sub_budget])
+        self._ck(self.lib.asb_panel_read_run(self.h, int(k0), int(k1), int(nsub_max), int(spec_budget), sb,
+                                             ctypes.c_void_p(words_dev_ptr), ctypes.byref(nt), nc, pr))
+        return nt.value, list(nc)[:nt.value], list(pr)[:nt.value]
+
+    def panel_read_commit(self, words10):
+        words10 = np.ascontiguousarray(words10, dtype=np.float64)
+        assert words10.shape == (10,)
+        tot, full, rej = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(self.lib.asb_panel_read_commit(self.h, ptr(words10), ctypes.byref(tot), ctypes.byref(full), ctypes.byref(rej)))
+        return tot.value, full.value, bool(rej.value)
+
     def panel_set_coop(self, on):
         """Switches the co-resident panel kernel on / off; returns the previous setting."""
         return int(self.lib.asb_panel_set_coop(self.h, int(bool(on))))

@@ -204,9 +204,11 @@ class posSnapshots:
         if preset is not None:
             Mass_mat = np.asarray(preset, dtype=np.float64).copy()
         elif not self.massesFile or not os.path.exists(self.massesFile):
-            if mass_on_tet_mesh:
-                raise NotImplementedError("tet-mesh masses need libigl (out of scope, SURVEY.md section 2 #2)")
-            Mass_mat = _u.voronoi_vertex_masses(self.verts[0], self.tris)
+            if mass_on_tet_mesh:      # (:133-135: igl.massmatrix on the tetrahedral mesh -- barycentric lumping, restated)
+                _, self.tets, _ = _u.read_mesh_file(self.tet_mesh)
+                Mass_mat = _u.tet_barycentric_vertex_masses(self.verts[0], self.tets)
+            else:
+                Mass_mat = _u.voronoi_vertex_masses(self.verts[0], self.tris)
             Mass_mat = Mass_mat / Mass_mat.sum() * 2
         else:
             Mass_mat = np.zeros(N)

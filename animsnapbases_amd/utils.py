@@ -195,6 +195,95 @@ def voronoi_vertex_masses(verts, tris):
     return mass
 
 
+def read_mesh_file(path):
+    """Medit ``.mesh`` text file -> (vertices (n,3) float, tetrahedra (m,4) int, triangles (t,3) int), zero-based -- what
+    utils/utils.py:325-389 of the reference returns: sections ``Vertices`` / ``Tetrahedra`` / ``Triangles``, each followed by a
+    count line, every entry with a trailing reference number that is dropped; other sections are skipped."""
+    want = {"Vertices": (3, float), "Tetrahedra": (4, int), "Triangles": (3, int)}
+    got = {k: [] for k in want}
+    with open(path, "r") as fh:
+        tokens = iter(fh.read().split("\n"))
+        for line in tokens:
+            key = line.strip()
+            name = next((k for k in want if key.startswith(k)), None)
+            if name is None:
+                continue
+            count = int(next(tokens).strip())
+            ncol = want[name][0]
+            for _ in range(count):
+                parts = next(tokens).split()
+                if len(parts) >= ncol + 1 or (name != "Vertices" and len(parts) >= 4):
+                    got[name].append(parts[:ncol] if name == "Vertices" else parts[:-1])
+    V = np.array(got["Vertices"], dtype=float) if got["Vertices"] else np.array([], dtype=float)
+    T = np.array(got["Tetrahedra"], dtype=int) - 1 if got["Tetrahedra"] else np.array([], dtype=int)
+    F = np.array(got["Triangles"], dtype=int) - 1 if got["Triangles"] else np.array([], dtype=int)
+    return V, T, F
+
+
+def tet_volumes(V, T):
+    a, b, c, d = (V[T[:, i]] for i in range(4))
+    return np.abs(np.einsum("ij,ij->i", np.cross(b - a, c - a), d - a)) / 6.0
+
+
+def tet_barycentric_vertex_masses(V, T):
+    """A quarter of every tetrahedron's volume to each of its corners: the diagonal of libigl's mass matrix of a tetrahedral
+    mesh (``igl.massmatrix(V, T)``: barycentric lumping is the only kind libigl builds for tetrahedra), which
+    snapbases/posSnapshots.py:135 and nonlinear_snapshots.py:236 take.  libigl is not in this image: pinned by its definition
+    and by closed forms (the masses sum to the mesh volume; tests/test_host_logic_cpu.py), "parity unpinned" in DESIGN.md."""
+    V, T = np.asarray(V, dtype=np.float64), np.asarray(T, dtype=np.int64)
+    return np.bincount(T.ravel(), np.repeat(tet_volumes(V, T) / 4.0, 4), minlength=V.shape[0])
+
+
+def lumped_tet_vertex_masses(V, T, density=1.0):
+    """utils/support.py:41-59 of the reference (``compute_lumped_mass_matrix``): barycentric lumping, then normalised to a total
+    mass of one; returned as the vector of the diagonal."""
+    m = density * tet_barycentric_vertex_masses(V, T)
+    tot = m.sum()
+    return m / tot if tot > 0 else m
+
+
+def element_masses(vertex_masses, elements, aux_size):
+    """Per auxiliary row of every element (edge, triangle, tetrahedron): the sum of its corners' masses, repeated ``aux_size``
+    times -- utils/support.py:12-76 (``compute_edgeMasses`` / ``compute_triMasses`` / ``compute_tetMasses``) in one line."""
+    vm = np.asarray(vertex_masses, dtype=np.float64)
+    w = vm[np.asarray(elements, dtype=np.int64)].sum(axis=1)
+    return np.repeat(w, int(aux_size))
+
+
+def mesh_edges(simplices):
+    """Unique undirected edges (i < j) of a triangle or tetrahedron list, ordered by (j, i) -- the order libigl's ``igl.edges``
+    walks its adjacency matrix in (column by column, rows above the diagonal).  No libigl here: parity unpinned."""
+    S = np.asarray(simplices, dtype=np.int64)
+    k = S.shape[1]
+    e = np.concatenate([S[:, [a, b]] for a in range(k) for b in range(a + 1, k)])
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    return e[np.lexsort((e[:, 0], e[:, 1]))]
+
+
+def read_triangle_mesh(path):
+    """(vertices, triangles) of an ``.obj`` or ``.off`` file (what the reference reads with ``igl.read_triangle_mesh``)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".off":
+        from .process import load_off
+        v, f = load_off(path, no_colors=True)[:2]
+        return np.asarray(v, dtype=float), np.asarray(f, dtype=np.int64)
+    if ext == ".obj":
+        vs, fs = [], []
+        with open(path, "r") as fh:
+            for line in fh:
+                p = line.split()
+                if not p:
+                    continue
+                if p[0] == "v":
+                    vs.append([float(x) for x in p[1:4]])
+                elif p[0] == "f":
+                    idx = [int(q.split("/")[0]) - 1 for q in p[1:]]
+                    for t in range(1, len(idx) - 1):          # fan triangulation of polygons
+                        fs.append([idx[0], idx[t], idx[t + 1]])
+        return np.array(vs, dtype=float), np.array(fs, dtype=np.int64)
+    raise ValueError("read_triangle_mesh: unknown mesh file type " + path)
+
+
 # ------------------------------------------------------------------ animation files
 def read_animation(path):
     """``verts`` (F,N,3) and ``tris`` (M,3) from ``.h5`` (reference format,

@@ -322,6 +322,53 @@ def other_config_c4_seeds(dev, seeds=(1, 2, 3, 4, 5, 6), N=100000, F=2000, K=128
             "note": "mean over the seeds; the headline's tensor (seed 1234) needs 2 reads"}
 
 
+def other_config_c4_forced(dev, N=100000, F=2000, K=128, steps=10, seed=1234):
+    """The headline's workload through the MULTI-RANK protocol on one rank (Comm(force_collectives=True) over a single-rank RCCL
+    group): every collective of a multi-GPU run really issued -- the start-up exchange, per read of X the two all-gathers
+    (energies; candidate rows + ids) and the one min-all-reduce of the tile verdicts --, the candidates assembled from the gathered
+    buffer, the read through asb_panel_read_run / _commit.  What the protocol costs on top of the fused single-rank driver."""
+    import torch
+    import torch.distributed as dist
+    from animsnapbases_amd import Comm, posComponents, posSnapshots
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        comm = Comm(force_collectives=True)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(seed))
+        Xd = torch.rand((F, N, 3), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        torch.cuda.synchronize()
+        snaps = _quiet(lambda: posSnapshots.from_device(Xd.data_ptr(), F, N, rest_shape="first", standarize=True, comm=comm, keepalive=Xd))
+        comp = posComponents(_pos_param(K, "global"), snaps)
+        eng = snaps._engine
+
+        def sync():
+            torch.cuda.synchronize()
+            eng.sync()
+        for _ in range(2):
+            _timed(lambda: comp.extract_k_components(None), sync)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _quiet(lambda: comp.extract_k_components(None))
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        st = eng.deflate_stats()
+        assert len(set(comp.selected_vertices.tolist())) == K
+        out = {"workload": "config4 through the multi-rank protocol on ONE rank (single-rank RCCL group, every collective issued): "
+                           "%d verts x %d frames, PCA K=%d global" % (N, F, K),
+               "ms": ms, "snapshots_per_s": F / (ms * 1e-3), "steps": steps, "reads_of_X": st["panels"] + st.get("refreshes", 0),
+               "panel_kernel_fallbacks": st.get("coop_fallbacks", 0),
+               "note": "compare with the headline's ms_per_step (the fused single-rank driver on the same tensor)"}
+        del comp, snaps, Xd
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    return out
+
+
 def other_config_c5(dev, cpu=True, ep=50000, F=4000, K=256):
     """config 5: constraint-projection snapshots 50 000 x 3 rows x 4 000 frames, POD (pod_vectorized) K = 256 + DEIM."""
     import torch
@@ -413,8 +460,14 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Launch rehearsal on a ONE-GPU box (tests/test_gpu_launch.py): ASB_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # ASB_BENCH_BACKEND=gloo exchanges through the host (Comm's staged collectives) -- rank / seed / partition / barrier /
+    # teardown / the one-JSON-line contract under the real launcher; the numbers of such a run mean nothing.
+    one_device = os.environ.get("ASB_BENCH_ONE_DEVICE", "0") == "1"
+    backend = os.environ.get("ASB_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # ASB_FORCE_COLLECTIVES=1 (with --gpus 1): single-rank RCCL group, multi-rank protocol -- measures what the
     # per-panel collectives and their host synchronisation cost on top of the kernels
     forced = os.environ.get("ASB_FORCE_COLLECTIVES", "0") == "1"
@@ -422,7 +475,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from animsnapbases_amd import Comm, partition, posComponents, posSnapshots
 
@@ -472,7 +528,7 @@ def main():
     launches, kern_ms = eng.prof_get()
     eng.prof_reset(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -567,7 +623,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config4: synthetic U[-1,1) %d verts x %d frames, greedy-deflation PCA K=%d, "
                                    "global support, standardised, vertex rows sharded over %d GPU(s)" % (N, F, K, world),
-                       "n_verts": N, "n_frames": F, "K": K, "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "")},
+                       "n_verts": N, "n_frames": F, "K": K,
+                       "parallelism": "vertex-shard x%d" % world + (" (multi-rank protocol forced)" if forced else "") +
+                                      (" (LAUNCH REHEARSAL: all ranks on one device, %s collectives through the host -- not a measurement)" % backend
+                                       if (one_device or backend != "nccl") else "")},
             # The dominant kernel against BOTH of its ceilings, the binding one first.  One launch reads the shard once
             # (24 n F bytes) and does 2 * 3n * F flops per component column it projects on; at the peaks that is 0.60 ms
             # of HBM and 0.245 ms of f64 MFMA per 16 columns, so launches with 3 or 4 sub-panels (48 / 64 columns, the usual
@@ -629,6 +688,7 @@ def main():
                         ("c4_slow_spectrum", lambda: other_config_c4_structured(dev, "slow_spectrum", seed=5)),
                         ("c4_rank_deficient", lambda: other_config_c4_structured(dev, "rank_deficient", seed=5, residual_too=True)),
                         ("c4_other_seeds", lambda: other_config_c4_seeds(dev)),
+                        ("c4_forced_collectives", lambda: other_config_c4_forced(dev)),
                         ("c2", lambda: other_config_pos("config2", "c2_bunny_pca_global", "global", "PCA", cpu)),
                         ("c2_local", lambda: other_config_pos("config2 (local support)", "c2_bunny_pca_local", "local", "PCA", cpu)),
                         ("c3", lambda: other_config_pos("config3", "c3_armadillo_splocs", "local", "SPLOCS", cpu)),

@@ -234,6 +234,20 @@ int asb_deflate_sketch_stats(asb_ctx* ctx, int64_t* runs, int64_t* reads);
  * component each (ASB_STALL_FALLBACK=0: never); several ranks: the driver applies the same rule (_panels.py).
  * asb_deflate_switch_stats: the component at which the last run switched, -1 if it did not. */
 int asb_project_switch_residual(asb_ctx* ctx, int64_t k);
+/* The multi-rank read of X in two calls and ONE exchange (round 4; what asb_deflate_run_global does inside the library on one
+ * rank: posComponents.py:76-96 for up to 64 components per read).  Every rank holds the same assembled candidates
+ * (asb_panel_assemble*).  asb_panel_read_run: all (<= nsub_max) sub-panels of the read in ONE launch of the panel kernel --
+ * identical on every rank --, this shard's pass over X and the checks of all tiles behind it; words_dev (device, 10 doubles):
+ * [ct] = columns of tile ct that stand on this shard (the tile's length if it was not reached: neutral under min), [8] = status
+ * (0; -1: the kernel's exchange timed out here), [9] = the local counts again, packed, NOT to be reduced.  The driver
+ * min-all-reduces words_dev[0 .. 8] over the ranks, reads all 10 words once (asb_fetch_doubles) and hands them to
+ * asb_panel_read_commit: tiles stand in full while the minimum equals their length, the first one below keeps that many
+ * columns, nothing behind it; a shard whose local chain ran ahead of the verdict rolls its energies back first.  With status
+ * -1 the driver passes zeros (roll-back only), switches the kernel off on all ranks (asb_panel_set_coop) and repeats the panel. */
+int asb_panel_read_run(asb_ctx* ctx, int64_t k0, int64_t k1, int nsub_max, int spec_budget, const int* sub_budget8,
+                       double* words_dev, int* ntile_out, int* nc_out8, int* proven_out8);
+int asb_panel_read_commit(asb_ctx* ctx, const double* words10_host, int64_t* total_out, int* full_out, int* rejected_out);
+int asb_fetch_doubles(asb_ctx* ctx, const double* dev, int n, double* out);
 int asb_deflate_switch_stats(asb_ctx* ctx, int64_t* k_switch);
 /* The same for the multi-rank driver (animsnapbases_amd/_panels.py).  asb_panel_guess_stats: this shard's energy along the
  * constant direction, its |X|^2 and whether the context could guess at all (0: both values are 0); the ranks sum all three

@@ -498,6 +498,54 @@ def _ingest(work):
     print("wrote ingest_small")
 
 
+def _meshmass(work):
+    """Element masses derived from a mesh -- the reference's OWN arithmetic (utils/support.py:12-76: `compute_lumped_mass_matrix`,
+    `compute_tetMasses`, `compute_edgeMasses`, `compute_triMasses`) and its `.mesh` reader (utils/utils.py:325-389) run on a small
+    random tetrahedral mesh written to disk here.  (The vertex masses the reference takes from libigl -- `igl.massmatrix` -- are not
+    part of this fixture: no libigl in this image.)"""
+    from utils.support import compute_lumped_mass_matrix, compute_tetMasses, compute_edgeMasses, compute_triMasses
+    ref = import_reference.cache
+    rng = np.random.default_rng(31)
+    # a 3 x 3 x 2 grid of jittered cubes, five tetrahedra each
+    nx, ny, nz = 4, 4, 3
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    V = np.stack([gx, gy, gz], -1).reshape(-1, 3).astype(float) + 0.15 * rng.normal(size=(nx * ny * nz, 3))
+    vid = lambda i, j, k: (i * ny + j) * nz + k
+    T = []
+    for i in range(nx - 1):
+        for j in range(ny - 1):
+            for k in range(nz - 1):
+                c = [vid(i + a, j + b, k + d) for a in (0, 1) for b in (0, 1) for d in (0, 1)]     # c[4a + 2b + d]
+                T += [[c[0], c[4], c[2], c[1]], [c[6], c[2], c[4], c[7]], [c[5], c[4], c[1], c[7]], [c[3], c[1], c[2], c[7]],
+                      [c[4], c[2], c[1], c[7]]]
+    T = np.array(T, dtype=np.int64)
+    faces = np.sort(np.concatenate([T[:, [0, 1, 2]], T[:, [0, 1, 3]], T[:, [0, 2, 3]], T[:, [1, 2, 3]]]), axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    tris = uniq[counts == 1]                                   # boundary triangles
+    mesh_path = os.path.join(work, "cubes.mesh")
+    with open(mesh_path, "w") as fh:
+        fh.write("MeshVersionFormatted 1\nDimension 3\nVertices\n%d\n" % len(V))
+        for p in V:
+            fh.write("%.17g %.17g %.17g 0\n" % tuple(p))
+        fh.write("Tetrahedra\n%d\n" % len(T))
+        for t in T:
+            fh.write("%d %d %d %d 0\n" % tuple(t + 1))
+        fh.write("Triangles\n%d\n" % len(tris))
+        for t in tris:
+            fh.write("%d %d %d 0\n" % tuple(t + 1))
+        fh.write("End\n")
+    rV, rT, rTri = ref["utils"].read_mesh_file(mesh_path)
+    vm = np.asarray(compute_lumped_mass_matrix(rV, rT).todense()).diagonal().copy()
+    edges = np.unique(np.sort(np.concatenate([rT[:, [a, b]] for a in range(4) for b in range(a + 1, 4)]), axis=1), axis=0)
+    out = dict(mesh_text=np.frombuffer(open(mesh_path, "rb").read(), dtype=np.uint8), read_V=rV, read_T=rT, read_tris=rTri,
+               lumped_vertex_mass=vm, edges=edges,
+               tet_masses=compute_tetMasses(vm, rT, rT.shape[0], 3),
+               edge_masses=compute_edgeMasses(vm, edges, edges.shape[0], 1),
+               tri_masses=compute_triMasses(vm, rTri, rTri.shape[0], 2))
+    np.savez_compressed(os.path.join(OUT, "mesh_masses.npz"), **out)
+    print("wrote mesh_masses: %d vertices, %d tets, %d boundary triangles, %d edges" % (len(rV), len(rT), len(rTri), len(edges)))
+
+
 def main():
     """`python oracle/gen_golden.py` regenerates every fixture; `... ingest` / `... blocks` only that one.  The ingest
     functions of the reference (utils/process.py) call `ndarray.ptp` / `np.asfarray`, which NumPy 2 removed, so that
@@ -531,6 +579,8 @@ def main():
                                        if k != "vertPos_output_directory"},
                                     **res)
                 print("wrote", name, "idx", res["idx"].tolist())
+            if only is not None and "meshmass" in only:
+                return _meshmass(work)
             if only is not None and "blocksdeim" in only:
                 return _blocksdeim(work)
             if only is not None and "recon" in only:
@@ -561,6 +611,7 @@ def main():
             _recon(work)
             _podslices(work)
             _withst(work)
+            _meshmass(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

@@ -6,7 +6,9 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+import types
+
+from conftest import GOLDEN, load_golden, relerr
 from animsnapbases_amd import GeodesicDistanceComputation, partition
 from animsnapbases_amd import utils as U
 from animsnapbases_amd.posComponents import posComponents
@@ -145,3 +147,128 @@ def test_constraint_path_host_helpers(tmp_path):
     X = ns.read(".bin")
     assert np.array_equal(X, frames[0:6:2]) and np.array_equal(ns.test_snapTensor, frames[1:6:2])
     assert ns.num_constained_elements == 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# masses derived from a mesh (posSnapshots.py:130-139, nonlinear_snapshots.py:192-240)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_mesh_masses_against_the_reference_functions(tmp_path):
+    """The reference's own arithmetic (utils/support.py:12-76, utils/utils.py:325-389), recorded by oracle/gen_golden.py
+    meshmass: the .mesh reader, the normalised tetrahedral lumping, the per-element sums."""
+    from animsnapbases_amd import utils as u
+    g = np.load(os.path.join(GOLDEN, "mesh_masses.npz"))
+    path = tmp_path / "cubes.mesh"
+    path.write_bytes(g["mesh_text"].tobytes())
+    V, T, tris = u.read_mesh_file(str(path))
+    assert np.array_equal(V, g["read_V"]) and np.array_equal(T, g["read_T"]) and np.array_equal(tris, g["read_tris"])
+    vm = u.lumped_tet_vertex_masses(V, T)
+    assert np.allclose(vm, g["lumped_vertex_mass"], rtol=1e-13, atol=0) and abs(vm.sum() - 1.0) < 1e-14
+    assert np.allclose(u.element_masses(vm, T, 3), g["tet_masses"], rtol=1e-14, atol=0)
+    assert np.allclose(u.element_masses(vm, g["edges"], 1), g["edge_masses"], rtol=1e-14, atol=0)
+    assert np.allclose(u.element_masses(vm, tris, 2), g["tri_masses"], rtol=1e-14, atol=0)
+
+
+def test_vertex_masses_closed_forms():
+    """What the reference takes from libigl (absent here: "parity unpinned"), against closed forms of the definitions."""
+    from animsnapbases_amd import utils as u
+    # a unit cube cut into six tetrahedra around its main diagonal: the masses sum to the volume, corner shares are known
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]], dtype=float)
+    T = np.array([[0, 1, 3, 7], [0, 3, 2, 7], [0, 2, 6, 7], [0, 6, 4, 7], [0, 4, 5, 7], [0, 5, 1, 7]])
+    assert np.allclose(u.tet_volumes(V, T), 1.0 / 6.0)
+    m = u.tet_barycentric_vertex_masses(V, T)
+    assert abs(m.sum() - 1.0) < 1e-15
+    assert np.allclose(m[[0, 7]], 6 / 24.0) and np.allclose(m[1:7], 2 / 24.0)      # the diagonal's ends touch all six, the rest two
+    A = np.array([[2.0, 0.3, 0.1], [0.0, 1.5, 0.2], [0.1, 0.0, 0.7]])                # an affine map scales every volume by |det|
+    assert np.allclose(u.tet_barycentric_vertex_masses(V @ A.T, T), m * abs(np.linalg.det(A)))
+    # a regular grid of right triangles (non-obtuse): the mixed-Voronoi cells tile the plane
+    n = 6
+    gx, gy = np.meshgrid(np.arange(n, dtype=float), np.arange(n, dtype=float), indexing="ij")
+    P = np.stack([gx.ravel(), gy.ravel(), np.zeros(n * n)], 1)
+    vid = lambda i, j: i * n + j
+    tris = np.array([t for i in range(n - 1) for j in range(n - 1)
+                     for t in ([vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)], [vid(i, j), vid(i + 1, j + 1), vid(i, j + 1)])])
+    mv = u.voronoi_vertex_masses(P, tris)
+    assert abs(mv.sum() - (n - 1) ** 2) < 1e-12                                     # total area
+    assert np.allclose(mv.reshape(n, n)[1:-1, 1:-1], 1.0)                            # an interior vertex owns one unit cell
+    # an obtuse triangle: half of the area to the obtuse corner, a quarter to the others
+    Pt = np.array([[0, 0, 0], [4, 0, 0], [2, 0.5, 0]], dtype=float)
+    mo = u.voronoi_vertex_masses(Pt, np.array([[0, 1, 2]]))
+    assert np.allclose(mo, [0.25, 0.25, 0.5])
+    # edges of a tetrahedron, in libigl's order (by the larger end point, then the smaller)
+    assert u.mesh_edges(np.array([[0, 1, 2, 3]])).tolist() == [[0, 1], [0, 2], [1, 2], [0, 3], [1, 3], [2, 3]]
+
+
+def test_element_masses_from_the_mesh_feed_the_constraint_snapshots(tmp_path):
+    """nonlinear_snapshots.py:192-240 end to end on the host: no mass file -> masses from the mesh, one per constraint row."""
+    from animsnapbases_amd import utils as u
+    from animsnapbases_amd.constraints import nonlinearSnapshots
+    g = np.load(os.path.join(GOLDEN, "mesh_masses.npz"))
+    path = tmp_path / "cubes.mesh"
+    path.write_bytes(g["mesh_text"].tobytes())
+    ns = nonlinearSnapshots.__new__(nonlinearSnapshots)
+    ns.param = types.SimpleNamespace(tet_mesh_file=str(path), tri_mesh_file=None, volumetric_mesh=True,
+                                     constProj_snapshots_type="edge_spring")
+    ns._preset_mass, ns.mass_file = None, ""
+    T = g["read_T"]
+    # p = 3: tetrahedral strain, three rows per tetrahedron
+    ns.constraintsSize, ns.num_constained_elements = 3, T.shape[0]
+    ns.load_factorize_masses()
+    vm = u.tet_barycentric_vertex_masses(g["read_V"], T)
+    assert ns.mass.shape == (3 * T.shape[0],) and np.allclose(ns.mass[::3], vm[T].sum(1)) and np.allclose(ns.mass[1::3], ns.mass[::3])
+    assert np.allclose(ns.massL ** 2, ns.mass) and np.allclose(ns.massL * ns.invMassL, 1.0)
+    # p = 1 on the volumetric mesh: edge springs, the reference's normalised lumping
+    e = u.mesh_edges(T)
+    ns.constraintsSize, ns.num_constained_elements = 1, e.shape[0]
+    ns.load_factorize_masses()
+    assert np.allclose(ns.mass, g["lumped_vertex_mass"][e].sum(1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the recorder's binary files, written here with struct exactly as the reference READS them element by element
+# (nonlinear_snapshots.py:126-160, :180-191; utils/utils.py:289-311)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bin_readers_round_trip(tmp_path):
+    import struct
+    from animsnapbases_amd.constraints import nonlinearSnapshots, read_sparse_matrix
+    rng = np.random.default_rng(3)
+    F, ep, inc, jump = 5, 7, 2, 1
+    frames = rng.normal(size=(F * inc, ep, 3))
+    pattern = str(tmp_path / "snap_")
+    for i in range(F * inc):                                   # <i rows><i cols>, then column by column
+        with open(pattern + str(i) + ".bin", "wb") as fh:
+            fh.write(struct.pack("<i", ep) + struct.pack("<i", 3))
+            for c in range(3):
+                for r in range(ep):
+                    fh.write(struct.pack("<d", frames[i, r, c]))
+    mass = rng.uniform(0.5, 2.0, size=ep)
+    mass_file = str(tmp_path / "mass.bin")
+    with open(mass_file, "wb") as fh:                          # <i n><i m>, then n doubles
+        fh.write(struct.pack("<i", ep) + struct.pack("<i", 1))
+        for v in mass:
+            fh.write(struct.pack("<d", v))
+    ns = nonlinearSnapshots.__new__(nonlinearSnapshots)
+    ns.param = types.SimpleNamespace(constProj_frame_increment=inc, constProj_train_test_jump=jump)
+    ns._frames = ns._test_frames = None
+    ns.snapshots_file, ns.frs, ns.constraintsSize = pattern, F, 1
+    X = ns.read(".bin")
+    assert X.dtype == np.float64 and np.array_equal(X, frames[0:F * inc:inc])
+    assert np.array_equal(ns.test_snapTensor, frames[jump:F * inc:inc])
+    assert ns.num_constained_elements == ep
+    ns._preset_mass, ns.mass_file = None, mass_file
+    ns.load_factorize_masses()
+    assert np.array_equal(ns.mass, mass) and np.allclose(ns.massL, np.sqrt(mass)) and np.allclose(ns.invMassL * ns.massL, 1.0)
+    # sparse operator: <i rows><i cols><i nnz>, then nnz triplets <i row><i col><d value>; repeated entries add up (csr_matrix)
+    rows, cols = 6, ep
+    trip = [(int(rng.integers(rows)), int(rng.integers(cols)), float(rng.normal())) for _ in range(15)] + [(2, 3, 1.5), (2, 3, -0.25)]
+    st_file = str(tmp_path / "St.bin")
+    with open(st_file, "wb") as fh:
+        fh.write(struct.pack("<i", rows) + struct.pack("<i", cols) + struct.pack("<i", len(trip)))
+        for r, c, v in trip:
+            fh.write(struct.pack("<i", r) + struct.pack("<i", c) + struct.pack("<d", v))
+    dense = np.zeros((rows, cols))
+    for r, c, v in trip:
+        dense[r, c] += v
+    St = read_sparse_matrix(st_file, ".bin")
+    assert St.shape == (rows, cols) and np.allclose(St.toarray(), dense, rtol=0, atol=1e-15)
+    with pytest.raises(ValueError):
+        read_sparse_matrix(st_file, ".txt")
