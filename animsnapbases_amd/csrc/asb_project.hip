@@ -3563,6 +3563,23 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         want_replay = !ctx->last_by_score;                  // look at the other kind again, ever more rarely while the verdict stands
         ctx->probe_after = ctx->probe_after < 64 ? 2 * ctx->probe_after : 64;
     }
+    if (getenv("ASB_DEBUG_PANELS") && ctx->read_by_score && ctx->sk_pred) {
+        // how good was the replay that named this read's candidates?  its winners (local vertex ids) against the read's own
+        long long pr[64];
+        std::vector<double> sc4((size_t)(total + 1) * 4);
+        (void)hipMemcpy(pr, ctx->sk_pred, sizeof(pr), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sc4.data(), ctx->scal + k * 4, sc4.size() * sizeof(double), hipMemcpyDeviceToHost);
+        int agree = 0;
+        for (; agree < total && agree < 64; ++agree) {
+            long long g;
+            memcpy(&g, &sc4[(size_t)agree * 4 + 2], 8);
+            if (pr[agree] + ctx->v0 != g) break;
+        }
+        long long gq = -1;
+        if (total < 64) memcpy(&gq, &sc4[(size_t)total * 4 + 2], 8);
+        fprintf(stderr, "[asb]   the replay named the first %d of the %lld winners kept; at the step that fell it had vertex %lld, the panel took %lld\n",
+                agree, (long long)total, total < 64 ? pr[total] + ctx->v0 : -1LL, gq);
+    }
     if (getenv("ASB_DEBUG_PANELS"))
         fprintf(stderr, "[asb] read at k=%lld (%s candidates) kept %lld: components per ms plain %.1f, predicted %.1f -> %s next\n", k,
                 ctx->read_by_score ? "predicted" : "plain", (long long)total, ctx->rate_plain, ctx->rate_sketch,
@@ -3608,7 +3625,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     // columns of its rejected steps -- greedy steps on rows from ALL over the mesh -- are the sketch the read after it is
     // predicted from.  CPU replay (tools/sim_sketch2.py, N = 100 000, F = 256, K = 128, 50 localised bumps): 6 reads (1, 39, 9, 20,
     // 35, 24 components) against 9 with candidates by energy and replay alone; low rank and the slow spectrum unchanged (6, 8).
-    if (ctx->diverse && rejected && !ctx->sketch_valid && !ctx->sketch_run_off && total > 0 && k + total < k1) {
+    // (only where a predicted read is what the rating wants next and there is no sketch to predict it from -- too few rejected
+    // columns, or a probe of the other kind in between: on data where plain reads rate better, e.g. a slowly decaying spectrum, a
+    // diverse read would only be a dearer plain read: 27.5 against 17.5 ms when every rejection was answered by one)
+    if (ctx->diverse && want_replay && ctx->sketch && rejected && !ctx->sketch_valid && !ctx->sketch_run_off && total > 0 && k + total < k1) {
         ctx->diverse_next = true;
         ctx->sub_cur = nsub_lim;
         for (int sp = 0; sp < 8; ++sp) ctx->sub_budget[sp] = ASB_PANEL_COLS;

@@ -142,3 +142,35 @@ def test_rank_deficient_run_leaves_the_projection_mode(N, F, rank, K, monkeypatc
     print("without the rule: %d reads of X" % reads0)
     assert st0["residual_switch_at"] == -1 and reads0 > reads
     assert comp0.selected_vertices[:good].tolist() == d["idx"][:good].tolist()
+
+
+@pytest.mark.parametrize("rest_shape", ["first", "average"])
+def test_device_resident_constraint_frames_with_mass_weights(rest_shape):
+    """nonlinear_snapshots.py:74-96 with constProj_massWeight on frames that already sit in HBM (frames_device=): the same
+    prepared tensor, mean and scale as the host-array path and as the oracle."""
+    import torch
+    from animsnapbases_amd import nonlinearSnapshots
+    rng = np.random.default_rng(9)
+    F, ep = 24, 333
+    frames = 0.2 + rng.normal(size=(F, ep, 3)) * rng.uniform(0.2, 1.0, size=(1, ep, 1))
+    mass = rng.uniform(0.5, 2.0, size=ep)
+    param = types.SimpleNamespace(constProj_rest_shape=rest_shape, constProj_numFrames=F, constProj_p_size=1, constProj_massWeight=True,
+                                  constProj_standarize=True, constProj_orthogonal=False, constProj_output_directory=".", name="t",
+                                  constProj_name="v")
+    host = nonlinearSnapshots(param, frames=frames, mass=mass)
+    host.config()
+    host.snapshots_prepare()
+    Xd = torch.from_numpy(frames).to("cuda:0").contiguous()
+    torch.cuda.synchronize()
+    devs = nonlinearSnapshots(param, frames_device=(Xd.data_ptr(), F, ep), keepalive=Xd, mass=mass)
+    devs.config()
+    devs.snapshots_prepare()
+    assert np.allclose(devs.massL, np.sqrt(mass))
+    assert abs(devs.pre_scale_factor / host.pre_scale_factor - 1.0) < 1e-13
+    assert relerr(devs.mean, host.mean) < 1e-14
+    assert relerr(devs.snapTensor, host.snapTensor) < 1e-13
+    # and the reference's arithmetic: weight, remove the rest shape, scale by 1 / std
+    W = frames * np.sqrt(mass)[None, :, None]
+    mean = W[0] if rest_shape == "first" else W.mean(axis=0)
+    R = W - mean[None]
+    assert relerr(devs.snapTensor, R / R.std()) < 1e-12

@@ -22,6 +22,8 @@ CONST = int(os.environ.get("CONST", "0"))
 SPR = int(os.environ.get("SPR", "64"))
 SEED = int(os.environ.get("SEED", "77"))
 PERSIST = int(os.environ.get("PERSIST", "1"))      # 0: the sketch is the LAST read's rejected columns only (what round 3 ships)
+F32 = int(os.environ.get("F32", "0"))              # 1: the replay in float32 (what the device kernel holds its sketch in)
+E_SHARE = float(os.environ.get("E_SHARE", "0"))    # share of a predicted read's slots given to the largest energies (device: 1/3)
 ADAPT = int(os.environ.get("ADAPT", "0"))          # 1: SPR doubles (up to 64) after a read that kept everything, halves (down to 16) below a third
 rng = np.random.default_rng(SEED)
 
@@ -81,8 +83,8 @@ def cand_greedy(Rc, steps):
 
 
 def sketch_greedy(Z, E, steps):
-    Z = Z.copy()
-    E = E.copy()
+    Z = Z.astype(np.float32) if F32 else Z.copy()
+    E = E.astype(np.float32) if F32 else E.copy()
     tail = np.maximum(E - (Z * Z).sum(0).reshape(N, 3).sum(1), 0.0)
     score = np.zeros(N)
     pred = []
@@ -130,7 +132,11 @@ def cost_ms(sub, replay_steps=0):
 def pick_candidates(score, E, m, share=None):
     """m slots: (1 - share) by the score (or the energies), share by an energy-weighted sample of everyone else"""
     nd = int(round((DIVERSE if share is None else share) * m))
-    top = np.argpartition(-score, m - nd)[:m - nd]
+    ne = int(round(E_SHARE * m)) if score is not E else 0
+    top = np.argpartition(-score, m - nd - ne)[:m - nd - ne]
+    if ne:
+        Em = E.copy(); Em[top] = -1.0
+        top = np.concatenate([top, np.argpartition(-Em, ne)[:ne]])
     if nd == 0:
         return top
     p = E.copy()
