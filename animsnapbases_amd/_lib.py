@@ -98,6 +98,9 @@ PROTOTYPES = {
     "asb_deflate_guessed_panels": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64)]),
     "asb_deflate_sketch_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "asb_project_switch_residual": (c_int, [ctypes.c_void_p, c_i64]),
+    "asb_splocs_trace_begin": (c_int, [ctypes.c_void_p, c_i64]),
+    "asb_splocs_objective_dev": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64]),
+    "asb_splocs_trace": (c_int, [ctypes.c_void_p, c_i64, c_dp]),
     "asb_panel_read_run": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_int), ctypes.c_void_p,
                                    ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "asb_panel_read_commit": (c_int, [ctypes.c_void_p, c_dp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -326,8 +326,18 @@ struct asb_splocs {
     const double** field_ptr = nullptr;
     long long* cen_idx = nullptr;
     int* status = nullptr;
+    double* trace = nullptr;          // (its, 3): <W, P>, <G, M>, sum Lambda |C_v| of every outer iteration, read once at the end
+    int64_t trace_cap = 0;
+    bool defer_status = false;        // the ADMM's status word is looked at with the trace, not after every outer iteration
 };
 
+static int dot_to_dev(asb_ctx* ctx, asb_splocs* s, const double* a, const double* b, long long n, double* out_dev) {
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_dot_part, dim3(grid), dim3(256), 0, ctx->stream, a, b, n, s->red);
+    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(256), 0, ctx->stream, s->red, grid, out_dev);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
 static int dot_to_host(asb_ctx* ctx, asb_splocs* s, const double* a, const double* b, long long n, double* out) {
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_dot_part, dim3(grid), dim3(256), 0, ctx->stream, a, b, n, s->red);
@@ -344,6 +354,7 @@ extern "C" int asb_splocs_begin(asb_ctx* ctx) {
     asb_splocs* s = ctx->splocs;
     const int64_t K = ctx->K, n3 = 3 * ctx->n_loc, F = ctx->F;
     s->K = K;
+    s->defer_status = false;
     int rc;
     if ((rc = asb_alloc(ctx, &s->C, (size_t)K * n3))) return rc;
     if ((rc = asb_alloc(ctx, &s->Z, (size_t)K * n3))) return rc;
@@ -434,6 +445,15 @@ extern "C" int asb_splocs_admm(asb_ctx* ctx, const double* Lambda, double rho, i
 }
 
 // Lambda[k][i] = lambda * (clip(phi_k[v0 + i], dmin, dmax) - dmin) / (dmax - dmin)   (:162-165, utils/support.py:61-64)
+struct FieldPtrs { const double* p[64]; };
+__global__ __launch_bounds__(256) void k_lambda_fields_arg(FieldPtrs fp, long long v0, long long n_loc, double lambda, double dmin,
+                                                           double dmax, double* __restrict__ L) {
+    const double* phi = fp.p[blockIdx.y] + v0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_loc; i += (long long)gridDim.x * 256) {
+        const double p = fmin(fmax(phi[i], dmin), dmax);
+        L[(long long)blockIdx.y * n_loc + i] = lambda * ((p - dmin) / (dmax - dmin));
+    }
+}
 __global__ __launch_bounds__(256) void k_lambda_fields(const double* const* __restrict__ field, long long v0, long long n_loc,
                                                        double lambda, double dmin, double dmax, double* __restrict__ L) {
     const double* phi = field[blockIdx.y] + v0;
@@ -459,12 +479,19 @@ extern "C" int asb_splocs_admm_fields(asb_ctx* ctx, const int64_t* slots, double
                                        (long long)ctx->N_glob);
     }
     int rc;
-    if ((rc = asb_alloc(ctx, &s->field_ptr, (size_t)K))) return rc;
-    ASB_HIP(ctx, hipMemcpyAsync(s->field_ptr, ptrs.data(), (size_t)K * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
-    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // ptrs is a local
     const int gx = (int)((ctx->n_loc + 255) / 256 < 64 ? (ctx->n_loc + 255) / 256 : 64);
-    hipLaunchKernelGGL(k_lambda_fields, dim3(gx, (unsigned)K), dim3(256), 0, ctx->stream, s->field_ptr, (long long)ctx->v0,
-                       (long long)ctx->n_loc, lambda, dmin, dmax, s->Lambda);
+    if (K <= 64) {              // the K field addresses travel as a kernel argument: no upload, no synchronisation
+        FieldPtrs fp{};
+        for (int64_t k = 0; k < K; ++k) fp.p[k] = ptrs[(size_t)k];
+        hipLaunchKernelGGL(k_lambda_fields_arg, dim3(gx, (unsigned)K), dim3(256), 0, ctx->stream, fp, (long long)ctx->v0,
+                           (long long)ctx->n_loc, lambda, dmin, dmax, s->Lambda);
+    } else {
+        if ((rc = asb_alloc(ctx, &s->field_ptr, (size_t)K))) return rc;
+        ASB_HIP(ctx, hipMemcpyAsync(s->field_ptr, ptrs.data(), (size_t)K * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // ptrs is a local
+        hipLaunchKernelGGL(k_lambda_fields, dim3(gx, (unsigned)K), dim3(256), 0, ctx->stream, s->field_ptr, (long long)ctx->v0,
+                           (long long)ctx->n_loc, lambda, dmin, dmax, s->Lambda);
+    }
     ASB_CHECK_LAUNCH(ctx);
     return splocs_admm_run(ctx, rho, n_iter);
 }
@@ -478,7 +505,7 @@ static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
         int rc = asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3, nullptr);
         if (rc) return rc;
     }
-    ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
+    if (!s->defer_status) ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
     {                   // blocked Gauss-Jordan on the matrix padded to a multiple of 16 (asb_dense.hip: one in-LDS pivot block up to K = 256)
         const int np = (int)((K + 15) / 16 * 16);
         int rc2;
@@ -507,6 +534,7 @@ static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
     }
     ASB_HIP(ctx, hipMemcpyAsync(s->C, s->Z, (size_t)K * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // C = Z
     ASB_CHECK_LAUNCH(ctx);
+    if (s->defer_status) return ASB_OK;          // (asb_splocs_trace looks at it, once, with the objective trace)
     int st[4];
     ASB_HIP(ctx, hipMemcpyAsync(st, s->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -535,6 +563,51 @@ extern "C" int asb_splocs_objective(asb_ctx* ctx, const double* P_dev, const dou
         ASB_HIP(ctx, hipMemcpyAsync(sparsity_local, s->red + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return ASB_OK;
+}
+
+// The same three numbers of outer iteration `it` left ON THE DEVICE (no synchronisation): the trace of a whole run -- the lines
+// the reference prints at :186-189 -- is read once, by asb_splocs_trace, when the loop is over.  asb_splocs_trace_begin(n_its)
+// sizes the trace and defers the ADMM's status check (W^T W + rho I not positive definite) to that read as well.
+extern "C" int asb_splocs_trace_begin(asb_ctx* ctx, int64_t n_its) {
+    if (!ctx || !ctx->splocs || n_its < 1) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    int rc;
+    if ((rc = asb_alloc(ctx, &s->trace, (size_t)n_its * 3))) return rc;
+    s->trace_cap = n_its;
+    s->defer_status = true;
+    ASB_HIP(ctx, hipMemsetAsync(s->trace, 0, (size_t)n_its * 3 * sizeof(double), ctx->stream));
+    ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
+    return ASB_OK;
+}
+extern "C" int asb_splocs_objective_dev(asb_ctx* ctx, const double* P_dev, const double* M_dev, int64_t it) {
+    if (!ctx || !ctx->splocs) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    if (!s->trace || it < 0 || it >= s->trace_cap) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_splocs_objective_dev: iteration %lld outside the trace", (long long)it);
+    const int64_t K = s->K;
+    if (P_dev) ASB_HIP(ctx, hipMemcpyAsync(s->P, P_dev, (size_t)ctx->F * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (M_dev) ASB_HIP(ctx, hipMemcpyAsync(s->M, M_dev, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    int rc;
+    double* t = s->trace + it * 3;
+    if ((rc = dot_to_dev(ctx, s, s->Wfk, s->P, (long long)ctx->F * K, t))) return rc;
+    if ((rc = dot_to_dev(ctx, s, s->G, s->M, (long long)K * K, t + 1))) return rc;
+    const long long kn = K * ctx->n_loc;
+    const int grid = (int)((kn + 255) / 256 < 1024 ? (kn + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_sparsity_part, dim3(grid), dim3(256), 0, ctx->stream, s->C, s->Lambda, kn, s->red);
+    hipLaunchKernelGGL(k_sum1, dim3(1), dim3(256), 0, ctx->stream, s->red, grid, t + 2);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+extern "C" int asb_splocs_trace(asb_ctx* ctx, int64_t n_its, double* out) {
+    if (!ctx || !ctx->splocs || !out) return ASB_ERR_ARG;
+    asb_splocs* s = ctx->splocs;
+    if (!s->trace || n_its < 1 || n_its > s->trace_cap) return ASB_ERR_ARG;
+    int st[4];
+    ASB_HIP(ctx, hipMemcpyAsync(out, s->trace, (size_t)n_its * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(st, s->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->defer_status = false;
+    if (st[0]) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "SPLOCS: W^T W + rho I is not positive definite");
     return ASB_OK;
 }
 

@@ -432,6 +432,18 @@ class HipEngine(object):
                                              ctypes.c_void_p(M_dev_ptr) if M_dev_ptr else None, ptr(idx), ptr(val)))
         return idx, val
 
+    def splocs_trace_begin(self, n_its):
+        self._ck(self.lib.asb_splocs_trace_begin(self.h, int(n_its)))
+
+    def splocs_objective_dev(self, it, P_dev_ptr=None, M_dev_ptr=None):
+        self._ck(self.lib.asb_splocs_objective_dev(self.h, ctypes.c_void_p(P_dev_ptr) if P_dev_ptr else None,
+                                                   ctypes.c_void_p(M_dev_ptr) if M_dev_ptr else None, int(it)))
+
+    def splocs_trace(self, n_its):
+        out = np.empty((int(n_its), 3))
+        self._ck(self.lib.asb_splocs_trace(self.h, int(n_its), ptr(out)))
+        return out
+
     def splocs_admm(self, Lambda_loc, rho, n_iter):
         Lambda_loc = np.ascontiguousarray(Lambda_loc, dtype=np.float64)
         assert Lambda_loc.shape == (self.K, self.n_loc)

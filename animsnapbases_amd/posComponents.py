@@ -234,6 +234,11 @@ class posComponents:  # Components == bases
         if fields_on_device:
             eng.geodesic_cache_clear()
         trace, centres = [], []
+        # the objective of every iteration stays on the device and is read once after the loop (nothing in the loop depends
+        # on the printed numbers): with the distance fields on the device an outer iteration synchronises once, for its centres
+        deferred = fields_on_device and hasattr(eng, "splocs_trace_begin") and num_iters_max > 0
+        if deferred:
+            eng.splocs_trace_begin(num_iters_max)
         for it in range(num_iters_max):
             cidx, cval = eng.splocs_weights(*ptrs())                          # :144-156, :161
             if comm.multi:
@@ -264,15 +269,28 @@ class posComponents:  # Components == bases
                     Lambda[k] = lam * smap[v0:v0 + n_loc]
                 eng.splocs_admm(Lambda, rho, num_admm_iterations)             # :167-181
             gram()
+            centres.append(cidx.copy())
+            if deferred:
+                eng.splocs_objective_dev(it, *ptrs())
+                continue
             wp, gm, sp = eng.splocs_objective(*ptrs())
             sparsity = comm.allreduce_sum(sp)[0]
             r2 = max(normX2 - 2.0 * wp + gm, 0.0)                             # |X - W C|^2
             E_rms = np.sqrt(r2) / sqrt(3 * N * F)
             energy = r2 + sparsity
             trace.append([energy, E_rms])
-            centres.append(cidx.copy())
             if comm.rank == 0:
                 print("itr %03d, Energy =%f, Error =%f" % (it, energy, E_rms))
+        if deferred:
+            tr = eng.splocs_trace(num_iters_max)                              # (its, 3): <W,P>, <G,M>, local sum Lambda |C_v|
+            spars = comm.allreduce_sum(tr[:, 2].copy())
+            for it in range(num_iters_max):
+                r2 = max(normX2 - 2.0 * tr[it, 0] + tr[it, 1], 0.0)
+                E_rms = np.sqrt(r2) / sqrt(3 * N * F)
+                energy = r2 + spars[it]
+                trace.append([energy, E_rms])
+                if comm.rank == 0:
+                    print("itr %03d, Energy =%f, Error =%f" % (it, energy, E_rms))
         C_loc, W_new = eng.splocs_results()
         self.splocs_comps = comm.all_gather_rows(C_loc, N, axis=1)
         self.splocs_weigs = W_new

@@ -244,6 +244,12 @@ int asb_project_switch_residual(asb_ctx* ctx, int64_t k);
  * asb_panel_read_commit: tiles stand in full while the minimum equals their length, the first one below keeps that many
  * columns, nothing behind it; a shard whose local chain ran ahead of the verdict rolls its energies back first.  With status
  * -1 the driver passes zeros (roll-back only), switches the kernel off on all ranks (asb_panel_set_coop) and repeats the panel. */
+/* SPLOCS without a host read per outer iteration (posComponents.py:183-189 prints one line per iteration; nothing in the loop
+ * depends on the printed numbers): asb_splocs_trace_begin sizes a device trace and defers the ADMM's status check,
+ * asb_splocs_objective_dev leaves iteration it's <W,P>, <G,M>, sum Lambda |C_v| there, asb_splocs_trace reads all (n_its, 3) once. */
+int asb_splocs_trace_begin(asb_ctx* ctx, int64_t n_its);
+int asb_splocs_objective_dev(asb_ctx* ctx, const double* P_dev, const double* M_dev, int64_t it);
+int asb_splocs_trace(asb_ctx* ctx, int64_t n_its, double* out_n_its_by_3);
 int asb_panel_read_run(asb_ctx* ctx, int64_t k0, int64_t k1, int nsub_max, int spec_budget, const int* sub_budget8,
                        double* words_dev, int* ntile_out, int* nc_out8, int* proven_out8);
 int asb_panel_read_commit(asb_ctx* ctx, const double* words10_host, int64_t* total_out, int* full_out, int* rejected_out);

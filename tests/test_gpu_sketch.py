@@ -181,3 +181,21 @@ def test_two_contexts_replay_at_once():
         assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
     print("replays: %d / %d, panel-kernel fallbacks: %d / %d" % (outs[0][3]["sketch_runs"], outs[1][3]["sketch_runs"],
                                                                outs[0][3]["coop_fallbacks"], outs[1][3]["coop_fallbacks"]))
+
+
+@pytest.mark.parametrize("diverse", ["1", "0"])
+def test_localised_bumps_same_basis_with_and_without_the_diversity_family(diverse, monkeypatch):
+    """50 localised modes (Gaussian bumps, what SPLOCS is made for) at N = 40 000: the candidates of a read are half an
+    energy-weighted random sample of all vertices behind a rejection (asb_project.hip: in_div) -- they only NAME candidates, so
+    the selected sequence and the basis are the oracle's with the family on and off; with it the reads of X should be fewer."""
+    rng = np.random.default_rng(29)
+    F, N, K = 200, 40000, 80
+    verts = orc.synth_snapshots(rng.uniform(size=(N, 3)), F, rank=40, noise=1e-4, decay=0.9, seed=29, kind="bumps")
+    d = orc.extract_k_components(orc.prepare_snapshots(verts, "first", True)["snapTensor"], K)
+    monkeypatch.setenv("ASB_DIVERSE", diverse)
+    comp, st = _run(verts, K)
+    assert comp.selected_vertices.tolist() == d["idx"].tolist()
+    comps, weigs = align_signs(comp.comps, comp.weigs, d["comps"])
+    assert relerr(comps, d["comps"]) < 1e-8 and relerr(weigs, d["weigs"]) < 1e-8
+    print("ASB_DIVERSE=%s: %d reads of X (%d replays, %d refreshes)" % (diverse, st["panels"] + st["refreshes"], st["sketch_runs"],
+                                                                     st["refreshes"]))

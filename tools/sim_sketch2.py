@@ -24,6 +24,8 @@ SEED = int(os.environ.get("SEED", "77"))
 PERSIST = int(os.environ.get("PERSIST", "1"))      # 0: the sketch is the LAST read's rejected columns only (what round 3 ships)
 F32 = int(os.environ.get("F32", "0"))              # 1: the replay in float32 (what the device kernel holds its sketch in)
 E_SHARE = float(os.environ.get("E_SHARE", "0"))    # share of a predicted read's slots given to the largest energies (device: 1/3)
+POW = float(os.environ.get("POW", "1"))            # the weighted sample draws vertex v with probability ~ E_v^POW
+FIRST_DIV = int(os.environ.get("FIRST_DIV", "-1"))   # >= 0: the first read takes M_CAND by energy + FIRST_DIV weighted-random vertices (the device's guessed read)
 ADAPT = int(os.environ.get("ADAPT", "0"))          # 1: SPR doubles (up to 64) after a read that kept everything, halves (down to 16) below a third
 rng = np.random.default_rng(SEED)
 
@@ -139,9 +141,8 @@ def pick_candidates(score, E, m, share=None):
         top = np.concatenate([top, np.argpartition(-Em, ne)[:ne]])
     if nd == 0:
         return top
-    p = E.copy()
+    p = np.maximum(E, 0.0) ** POW
     p[top] = 0.0
-    p = np.maximum(p, 0.0)
     p /= p.sum()
     extra = rng.choice(N, size=nd, replace=False, p=p)
     return np.concatenate([top, extra])
@@ -163,6 +164,10 @@ def run(steps_per_read):
             cand = pick_candidates(score, E, M_CAND, DIVERSE_PRED)
             ms += cost_ms(sub, steps)
             how.append("s%d" % D.shape[0])
+        elif k == 0 and FIRST_DIV >= 0:
+            cand = pick_candidates(E, E, M_CAND + FIRST_DIV, FIRST_DIV / float(M_CAND + FIRST_DIV))
+            ms += cost_ms(sub)
+            how.append("g")
         else:
             cand = pick_candidates(E, E, M_CAND)
             ms += cost_ms(sub)
@@ -214,5 +219,5 @@ def run(steps_per_read):
 
 t0 = time.time()
 reads, log, ms, how = run(SPR)
-print("%s seed %d PERSIST=%d ADAPT=%d DIVERSE=%.2f/%.2f CONST=%d SPR=%d M=%d: reads %d, modelled %.1f ms, kept %s how %s (%.0f s)" %
-      (kind, SEED, PERSIST, ADAPT, DIVERSE, DIVERSE_PRED, CONST, SPR, M_CAND, reads, ms, log, how, time.time() - t0), flush=True)
+print("%s POW=%.2f FIRST_DIV=%d E_SHARE=%.2f seed %d PERSIST=%d ADAPT=%d DIVERSE=%.2f/%.2f CONST=%d SPR=%d M=%d: reads %d, modelled %.1f ms, kept %s how %s (%.0f s)" %
+      (kind, POW, FIRST_DIV, E_SHARE, SEED, PERSIST, ADAPT, DIVERSE, DIVERSE_PRED, CONST, SPR, M_CAND, reads, ms, log, how, time.time() - t0), flush=True)
