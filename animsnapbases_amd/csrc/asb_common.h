@@ -203,9 +203,15 @@ struct asb_ctx {
     bool read_by_score = false, last_by_score = false;      // the read in progress / the one before took predicted candidates
     double rate_plain = -1.0, rate_sketch = -1.0;           // components per modelled ms of the two kinds of read (exponential means)
     int mode_streak = 0, probe_after = 2;
+    // measured cost (ms) of a read with 1 .. 4 sub-panels and of a 64-step replay on this context and shape (-1: not seen yet)
+    double cost_nt[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, cost_replay = -1.0;
+    int cost_cnt[5] = {0, 0, 0, 0, 0}, cost_replay_cnt = 0;
+    int64_t cost_n = 0, cost_Fp = 0;
     bool sketch_run_off = false;           // this run's data are noise-like (a sketch held too little of the residual): no more replays
     unsigned long long* sk_words = nullptr;
     unsigned* sk_flags = nullptr;          // [-, abort, ran to the end, -]
+    int* sk_map = nullptr;                 // replay subset (shards above one co-resident launch): slot -> vertex, increasing
+    int* sk_cnt = nullptr;
     double* sk_score = nullptr;            // (n_loc)
     long long* sk_pred = nullptr;          // (64) the replay's winners
     unsigned* sk_counts = nullptr;         // [replays run, launches that found the sketch too thin and left score = energy]

@@ -57,8 +57,12 @@ __device__ __forceinline__ bool in_guess(double e, double ev, const double* __re
 // predicted from (asb_sketch.hip).  For the second job the largest energies are the wrong rows on localised data: they all lie
 // in the one or two strongest modes, the steps behind those modes run on noise, and the sketch misses every other mode.  An
 // energy-WEIGHTED RANDOM SAMPLE of all vertices spans the dominant frame subspace of the whole residual (row sampling with
-// probability ~ squared row norm): vertex i belongs to it when e_i / Exp_i > tau_div, Exp_i = -log(u_i) a unit exponential from
-// a hash of (i, seed) -- the m largest keys are an exact weighted sample without replacement (Efraimidis-Spirakis).  Computed on
+// probability ~ a power of the squared row norm): vertex i belongs to it when e_i^(1/4) / Exp_i > tau_div, Exp_i = -log(u_i) a unit
+// exponential from a hash of (i, seed) -- the m largest keys are an exact weighted sample without replacement (Efraimidis-
+// Spirakis).  The weight is e^(1/4), not e: with weights ~ e the sample crowds into the strongest modes again and the WEAK modes,
+// whose directions the replay needs once the strong ones are gone, get one or two rows -- CPU replay (tools/sim_sketch2.py, 50
+// bumps, 190 sampled rows beside the first read's candidates): the read predicted from that sketch keeps 18 / 24 components (two
+// data sets) with weights e, 19 / 35 with e^(1/2), 37 with e^(1/4).  Computed on
 // the fly from the energy at the start of the read and the vertex's index, by the compaction and by the pass's check alike;
 // off while sc[SC_TAU_DIV] is "infinite".  Like every other family it only names candidates: nothing rests on it.
 #define ASB_DIV_Q (ASB_NG + 1)              // its slot among the thresholds of a multi-score selection
@@ -67,7 +71,7 @@ __device__ __forceinline__ double div_key(double e, long long i, double seed_bit
     unsigned long long x = ((unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull ^ (unsigned long long)__double_as_longlong(seed_bits);
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;      // splitmix64
     const double u = ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-    return e / -log(u);
+    return sqrt(sqrt(fmax(e, 0.0))) / -log(u);
 }
 __device__ __forceinline__ bool in_div(double e, long long i, const double* __restrict__ sc) {
     const double t = sc[SC_TAU_DIV];
@@ -2204,6 +2208,21 @@ static int hist_grid(const asb_ctx* ctx) {
 }
 
 // level 1: exponent histogram (range-free); level 2: linear bins inside the crossing binade
+// threshold with ~m_target (at most m_cap) of the n values of E above it into sc[SC_TAU] (the sketch replay's subset, asb_sketch.hip);
+// uses the panel selection's histogram and range scalars, which are free between two reads
+int asb_sketch_subset_tau(asb_ctx* ctx, const double* E, long long n, long long m_target, long long m_cap) {
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
+    long long want = (n + 255) / 256;
+    const int grid = (int)(want < 4LL * ctx->n_cu ? want : 4LL * ctx->n_cu);
+    for (int level = 1; level <= 2; ++level) {
+        hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, ctx->stream, E, n, ctx->scalar_dev, ctx->hist, level == 1 ? 1 : 0);
+        hipLaunchKernelGGL(k_tau, dim3(1), dim3(256), 0, ctx->stream, ctx->hist, ctx->scalar_dev, level, m_target, m_cap);
+    }
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 extern "C" int asb_panel_hist(asb_ctx* ctx, int level, int* hist_dev) {
     if (!ctx || !ctx->energy || ctx->mode != ASB_DEFLATE_PROJECT) return ASB_ERR_ARG;
     int* h = hist_dev ? hist_dev : ctx->hist;
@@ -3417,6 +3436,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
+    const auto t_read0 = std::chrono::steady_clock::now();
     if ((rc = panel_candidates(ctx, k, 0))) return rc;
     // who is a candidate is decided by the energies NOW; the later tiles' checks run after the earlier tiles' updates
     ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -3526,6 +3546,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         if (kept < nc[ct]) { rejected = true; break; }      // what follows was built on a rejected step
         ++full;
     }
+    // (chained tiles: the host has just read the tile results, the read's GPU work is done)
+    const double read_ms = chained ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_read0).count() : -1.0;
     // how many sub-panels the next read of X gets: twice as many after a read whose sub-panels all stood, what stood
     // (+1) after a rejection -- a rejected sub-panel costs its panel steps and its share of the MFMA work
     if (rejected) ctx->sub_cur = full + 1 < nsub_lim ? full + 1 : nsub_lim;
@@ -3549,8 +3571,29 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
             const int need = (int)((total + ASB_PANEL_COLS) / ASB_PANEL_COLS);
             nt = need < 1 ? 1 : (need < nt ? need : nt);
         }
+        // What a read costs is MEASURED: the fastest of the first four reads of each size on this context and shape (host clock
+        // from its selection to its tile results -- the host waits for the GPU there anyway; the first ones may pay for
+        // allocations) and likewise of the first replays fix cost_nt[] / cost_replay, which stay frozen afterwards (the same
+        // tensor takes the same decisions on every later call).  Until a size has been seen, the figures of the 100 000 x 2000
+        // tensor on an MI355X scaled by the shard's size stand in for it.
+        if (ctx->cost_n != ctx->n_loc || ctx->cost_Fp != ctx->Fp) {
+            for (int q = 0; q < 5; ++q) { ctx->cost_nt[q] = -1.0; ctx->cost_cnt[q] = 0; }
+            ctx->cost_replay = -1.0;
+            ctx->cost_replay_cnt = 0;
+            ctx->cost_n = ctx->n_loc;
+            ctx->cost_Fp = ctx->Fp;
+        }
+        {
+            const int nm = ntile < 1 ? 1 : (ntile > 4 ? 4 : ntile);
+            if (ctx->cost_cnt[nm] < 4 && read_ms > 0.0 && !getenv("ASB_DEBUG_PANELS")) {
+                ctx->cost_nt[nm] = (ctx->cost_nt[nm] < 0.0 || read_ms < ctx->cost_nt[nm]) ? read_ms : ctx->cost_nt[nm];
+                ctx->cost_cnt[nm]++;
+            }
+        }
         const double scale = (double)ctx->n_loc * (double)ctx->Fp / (100000.0 * 2000.0);
-        const double cost = (0.45 + 0.23 * nt + pass_ms[nt]) * (scale > 0.05 ? scale : 0.05) + (ctx->read_by_score ? 0.7 : 0.0);
+        const double modelled = (0.45 + 0.23 * nt + pass_ms[nt]) * (scale > 0.05 ? scale : 0.05);
+        const double replay_cost = ctx->cost_replay >= 0.0 ? ctx->cost_replay : 0.7 * (scale > 0.05 ? scale : 0.05);
+        const double cost = (ctx->cost_nt[nt] >= 0.0 ? ctx->cost_nt[nt] : modelled) + (ctx->read_by_score ? replay_cost : 0.0);
         const double rate = (double)total / cost;
         double& ema = ctx->read_by_score ? ctx->rate_sketch : ctx->rate_plain;
         ema = ema < 0.0 ? rate : 0.5 * (ema + rate);
@@ -3588,9 +3631,10 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         long long ncols = 0;
         for (int ct = 0; ct < ntile; ++ct) ncols += nc[ct];
         const long long left = ncols - total;
-        if (left >= 8 && ctx->n_loc <= asb_sketch_capacity(ctx) && ctx->n_loc > ctx->m_cap) {
+        if (left >= 8 && ctx->n_loc > ctx->m_cap) {        // (above one co-resident launch the replay runs on the largest energies)
             const long long ks = k + total, todo = k1 - ks;
             const int r = (int)(left < 64 ? left : 64), steps = (int)(todo < 64 ? todo : 64);
+            const auto t_rep0 = std::chrono::steady_clock::now();
             if ((rc = asb_sketch_predict(ctx, ctx->comps + (size_t)ks * 3 * ctx->n_loc, (long long)(3 * ctx->n_loc), ctx->scal + ks * 4 + 1, 4,
                                          ctx->energy, (long long)ctx->n_loc, r, steps)))
                 return rc;
@@ -3601,6 +3645,11 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
             unsigned fl[4] = {0, 0, 0, 0};
             if ((rc = fetch_words(ctx, ctx->sk_flags, 2, fl))) return rc;
             const bool replayed = fl[2] != 0 && fl[1] == 0;
+            if (replayed && ctx->cost_replay_cnt < 4 && steps == 64 && !getenv("ASB_DEBUG_PANELS")) {
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rep0).count();
+                ctx->cost_replay = (ctx->cost_replay < 0.0 || ms < ctx->cost_replay) ? ms : ctx->cost_replay;
+                ctx->cost_replay_cnt++;
+            }
             if (replayed) {
                 ctx->sketch_valid = true;
                 ctx->sub_cur = nsub_lim;

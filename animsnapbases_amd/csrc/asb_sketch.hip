@@ -100,7 +100,9 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
                                                            const double* __restrict__ E, long long n, int r, int steps,
                                                            double* __restrict__ score_out, long long* __restrict__ pred_out,
                                                            unsigned long long* words, unsigned* flags, int test_stall, float min_share,
-                                                           unsigned* counts) {
+                                                           unsigned* counts, const int* __restrict__ map = nullptr) {
+    // map (optional): the replay runs on a SUBSET of the vertices -- slot s of the launch holds vertex map[s], n = subset size, in
+    // increasing vertex order (so "lowest slot" is "lowest vertex"); cols / E / score_out stay indexed by the vertex
     __shared__ __attribute__((aligned(16))) float q_sh[SK_R];
     __shared__ double lam_sh;
     __shared__ float zs[4][64];
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
     __shared__ unsigned long long sh_k[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = gridDim.x;
-    const long long v = (long long)blockIdx.x * SK_T + tid;
-    const bool have = v < n;
+    const long long slot = (long long)blockIdx.x * SK_T + tid;
+    const bool have = slot < n;
+    const long long v = have ? (map ? (long long)map[slot] : slot) : 0;
     unsigned long long* rec = words;
     unsigned long long* qbuf = words + (size_t)3 * G;
     const double e_in = have ? E[v] : 0.0;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
     const bool tl = blockIdx.x == 0 && tid == 0;
     // a record is ONE word: (bits of the energy, an f32 >= 0: ordered like the value) << 32 | (2^32 - 1 - vertex): the largest
     // key is the largest energy and among equals the lowest vertex (NumPy's first max); all ones (a NaN) never occurs
-    const unsigned vkey = 0xFFFFFFFFu - (unsigned)v;
+    const unsigned vkey = 0xFFFFFFFFu - (unsigned)slot;
     for (int t = 0; t < steps; ++t) {
         const int ring = t % 3, ring_prev = (t + 2) % 3;
         if (tl) tlog[t * 6 + 0] = wall_clock64();
@@ -294,7 +297,10 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
         const bool mine = have && (unsigned)(bk & 0xffffffffull) == vkey;      // (this thread is the winner)
         const int gb = (int)((0xFFFFFFFFu - (unsigned)(bk & 0xffffffffull)) / SK_T);
         if (have) score = fmaxf(score, e / be);
-        if (tl && pred_out) pred_out[t] = (long long)(0xFFFFFFFFu - (unsigned)(bk & 0xffffffffull));
+        if (tl && pred_out) {
+            const long long ws = (long long)(0xFFFFFFFFu - (unsigned)(bk & 0xffffffffull));
+            pred_out[t] = map ? (long long)map[ws] : ws;
+        }
         // ---- 3. the winner's q: its block publishes it, the others spin on it
         unsigned long long* qb = qbuf + (size_t)ring * SK_QW;
         dead = 0;
@@ -380,17 +386,88 @@ long long asb_sketch_capacity(asb_ctx* ctx) {
     return cap < 256LL * SK_T ? cap : 256LL * SK_T;          // (the gate's exchange holds 256 blocks)
 }
 
+// ---- the replay on a SUBSET (shards above one co-resident launch: 256 blocks x 512 vertices).  A vertex's energy never grows, so
+// who can win within the next 64 steps lies among the largest energies NOW: the launch takes the ~118 000 largest (threshold by
+// the panel's two-level histogram, ordered compaction so that slot order is vertex order) and everyone else keeps score 0.
+__global__ __launch_bounds__(256) void k_subset_count(const double* __restrict__ E, long long n, const double* __restrict__ tau_p,
+                                                      int* __restrict__ cnt) {
+    __shared__ int sh[4];
+    const double tau = *tau_p;
+    const long long seg = (n + gridDim.x - 1) / gridDim.x, a = blockIdx.x * seg, b = (a + seg < n) ? a + seg : n;
+    int c = 0;
+    for (long long i = a + threadIdx.x; i < b; i += 256) c += E[i] > tau;
+    c = wave_isum_dpp(c);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_subset_fill(const double* __restrict__ E, long long n, const double* __restrict__ tau_p,
+                                                     const int* __restrict__ cnt, long long cap, int* __restrict__ map,
+                                                     int* __restrict__ total_out) {
+    __shared__ int wsum[4];
+    __shared__ long long base_sh;
+    const double tau = *tau_p;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {
+        long long off = 0;
+        for (int q = lane; q < (int)blockIdx.x; q += 64) off += cnt[q];
+        off = (long long)wave_isum_dpp((int)off);
+        if (lane == 0) base_sh = off;
+    }
+    __syncthreads();
+    long long base = base_sh;
+    const long long seg = (n + gridDim.x - 1) / gridDim.x, a = blockIdx.x * seg, b = (a + seg < n) ? a + seg : n;
+    for (long long i0 = a; i0 < b; i0 += 256) {
+        const long long i = i0 + threadIdx.x;
+        const bool on = i < b && E[i] > tau;
+        const unsigned long long m = __ballot(on);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < wv; ++q) woff += wsum[q];
+        const long long pos = base + woff + before;
+        if (on && pos < cap) map[pos] = (int)i;
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (int)(base < cap ? base : cap);
+}
+
 // scores of the n vertices whose sketch columns are cols[i * stride + 3 v + d] (i < r <= 64), exact energies E, into
 // ctx->sk_score (n doubles); the replay's predicted winners into ctx->sk_pred (<= 64).  Enqueued on the context's stream.
 int asb_sketch_predict(asb_ctx* ctx, const double* cols, long long stride, const double* wn2, int wn2_stride, const double* E,
                        long long n, int r, int steps) {
     if (!ctx || !cols || !wn2 || !E || n < 1 || r < 1 || r > SK_R || steps < 1) return ASB_ERR_ARG;
     if (steps > 64) steps = 64;
-    if (n > asb_sketch_capacity(ctx)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: %lld vertices exceed one co-resident launch", n);
-    const int G = (int)((n + SK_T - 1) / SK_T);
+    const long long cap = asb_sketch_capacity(ctx);
+    if (cap < SK_T) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: the replay kernel does not fit this device");
+    if (n >= (1LL << 31)) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: more than 2^31 vertices per shard");
+    int rc;
+    const int* map = nullptr;
+    long long n_run = n;
+    if (n > cap) {
+        // the ~0.9 cap largest energies take part (asb.h: energies never grow); threshold from the panel machinery's two-level
+        // histogram (its scalars are free between two reads), ordered compaction, the subset's size read back
+        extern int asb_sketch_subset_tau(asb_ctx * ctx, const double* E, long long n, long long m_target, long long m_cap);
+        if ((rc = asb_sketch_subset_tau(ctx, E, n, cap - cap / 10, cap))) return rc;
+        const int nb = 1024;
+        if ((rc = asb_alloc(ctx, &ctx->sk_map, (size_t)cap))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->sk_cnt, (size_t)nb + 1))) return rc;
+        hipLaunchKernelGGL(k_subset_count, dim3(nb), dim3(256), 0, ctx->stream, E, n, ctx->scalar_dev + 6 /* SC_TAU */, ctx->sk_cnt);
+        hipLaunchKernelGGL(k_subset_fill, dim3(nb), dim3(256), 0, ctx->stream, E, n, ctx->scalar_dev + 6, ctx->sk_cnt, cap, ctx->sk_map,
+                           ctx->sk_cnt + nb);
+        ASB_CHECK_LAUNCH(ctx);
+        int tot = 0;
+        ASB_HIP(ctx, hipMemcpyAsync(&tot, ctx->sk_cnt + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (tot < 1) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "asb_sketch_predict: empty replay subset");
+        n_run = tot;
+        map = ctx->sk_map;
+    }
+    const int G = (int)((n_run + SK_T - 1) / SK_T);
     if (G > 256) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sketch_predict: more than 256 blocks");
     const size_t n_words = (size_t)3 * G + (size_t)3 * SK_QW + (size_t)2 * G;
-    int rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_words, n_words))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_flags, (size_t)4 + 2 * 64 * 6))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->sk_score, (size_t)n))) return rc;
@@ -403,8 +480,9 @@ int asb_sketch_predict(asb_ctx* ctx, const double* cols, long long stride, const
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_words, 0xFF, n_words * sizeof(unsigned long long), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_flags, 0, 4 * sizeof(unsigned), ctx->stream));
     ASB_HIP(ctx, hipMemsetAsync(ctx->sk_pred, 0xFF, 64 * sizeof(long long), ctx->stream));
-    hipLaunchKernelGGL(k_sketch_greedy, dim3(G), dim3(SK_T), 0, ctx->stream, cols, stride, wn2, wn2_stride, E, n, r, steps,
-                       ctx->sk_score, ctx->sk_pred, ctx->sk_words, ctx->sk_flags, ctx->sk_test_stall, min_share, ctx->sk_counts);
+    if (map) ASB_HIP(ctx, hipMemsetAsync(ctx->sk_score, 0, (size_t)n * sizeof(double), ctx->stream));      // everyone outside the subset
+    hipLaunchKernelGGL(k_sketch_greedy, dim3(G), dim3(SK_T), 0, ctx->stream, cols, stride, wn2, wn2_stride, E, n_run, r, steps,
+                       ctx->sk_score, ctx->sk_pred, ctx->sk_words, ctx->sk_flags, ctx->sk_test_stall, min_share, ctx->sk_counts, map);
     ASB_CHECK_LAUNCH(ctx);
     ctx->sk_test_stall = 0;
     ctx->n_sketch_runs++;

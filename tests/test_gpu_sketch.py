@@ -44,6 +44,41 @@ def replay_model(Z, E, steps):
     return score, pred
 
 
+def replay_model_f32(Z, E, steps):
+    """The same replay in the KERNEL's arithmetic: the sketch, its Gram sums, the deflation and the re-summed energies in
+    float32 (the kernel holds the sketch as packed f32 and re-sums a vertex's energy from it every step), the tail E - |Z|^2 from
+    the f64 energy once, the winner's 3 x 3 eigen-pair in f64 from f32 Gram sums.  NumPy has no fused multiply-add, so single
+    products differ from the kernel's by an ulp: scores agree to ~1e-5 instead of bit for bit."""
+    f32 = np.float32
+    n = E.shape[0]
+    Z = Z.astype(f32).reshape(Z.shape[0], n, 3).copy()          # (r, n, 3)
+    own = (Z * Z).sum(axis=(0, 2), dtype=f32)
+    tail = np.maximum(E - own.astype(np.float64), 0.0).astype(f32)
+    e = own + tail
+    score = np.zeros(n, dtype=f32)
+    pred = []
+    for _ in range(steps):
+        v = int(np.argmax(e))
+        if not e[v] > 0:
+            break
+        score = np.maximum(score, e / e[v])
+        pred.append(v)
+        A = Z[:, v, :].copy()                                    # (r, 3) f32
+        G = (A[:, :, None] * A[:, None, :]).sum(axis=0, dtype=np.float64).astype(f32).astype(np.float64)
+        lam, U = np.linalg.eigh(G + (np.float64(tail[v]) / 3.0) * np.eye(3))
+        u, lam = U[:, -1], lam[-1]
+        u = u * (1.0 if u[np.argmax(np.abs(u))] > 0 else -1.0)
+        uf = u.astype(f32)
+        q = (A * uf[None, :]).sum(axis=1, dtype=f32)             # (r,)
+        il = f32(1.0 / lam)
+        a = np.einsum("i,ind->nd", q, Z).astype(f32) * il        # (n, 3)
+        a[v] = uf
+        Z -= q[:, None, None] * a[None, :, :]
+        tail[v] *= f32(2.0 / 3.0)
+        e = (Z * Z).sum(axis=(0, 2), dtype=f32) + tail
+    return score.astype(np.float64), pred
+
+
 def _predict(eng, cols, wn2, E, steps):
     r, n3 = cols.shape
     n = n3 // 3
@@ -58,7 +93,7 @@ def _predict(eng, cols, wn2, E, steps):
     return scores, [int(p) for p in pred], status.value
 
 
-@pytest.mark.parametrize("n,r,steps,tail_rel,tol", [(5000, 40, 30, 1e-6, 5e-3), (70001, 64, 64, 1e-3, 5e-3), (1300, 7, 12, 0.5, 1e-3)])
+@pytest.mark.parametrize("n,r,steps,tail_rel,tol", [(5000, 40, 30, 1e-6, 5e-4), (70001, 64, 64, 1e-3, 5e-4), (1300, 7, 12, 0.5, 5e-4)])
 def test_replay_kernel_against_its_numpy_model(n, r, steps, tail_rel, tol):
     from animsnapbases_amd import HipEngine
     rng = np.random.default_rng(n)
@@ -71,13 +106,46 @@ def test_replay_kernel_against_its_numpy_model(n, r, steps, tail_rel, tol):
     eng = HipEngine(0)
     scores, pred, status = _predict(eng, cols, wn2, E, steps)
     assert status == 1
-    ms, mp = replay_model(Z, E, steps)
-    # f32 sketch against f64; the tail E - |Z|^2 is a difference of f32 sums (1e-7 of the energy: a tenth of a 1e-6 tail),
-    # which shows once the energies have fallen to it
-    print("largest score difference %.2e, winners agree for %d of %d steps" %
-          (np.abs(scores - ms).max(), next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp)), len(mp)))
-    assert pred[:len(mp) // 2] == mp[:len(mp) // 2]
+    # against the model in the kernel's own arithmetic (f32 sketch, f32 re-summed energies): the bound that says something about
+    # the KERNEL; the f64 model beside it shows what the f32 sketch itself costs (round 3 compared with that one at 5e-3)
+    ms, mp = replay_model_f32(Z, E, steps)
+    ms64, mp64 = replay_model(Z, E, steps)
+    agree = next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp))
+    print("f32 model: largest score difference %.2e, winners agree for %d of %d steps; f64 model: %.2e, %d of %d" %
+          (np.abs(scores - ms).max(), agree, len(mp), np.abs(scores - ms64).max(),
+           next((t for t in range(len(mp64)) if pred[t] != mp64[t]), len(mp64)), len(mp64)))
+    # winners: every step up to the first NEAR-TIE of the model (two leading energies closer than 1e-5 relative: there an ulp
+    # in a product decides), and at least three quarters of the steps
+    assert agree >= (3 * len(mp)) // 4, (agree, len(mp))
     assert np.abs(scores - ms).max() < tol
+    eng.close()
+
+
+def test_replay_on_the_largest_energies_above_one_launch():
+    """A shard above the co-resident capacity (256 blocks x 512 vertices): the replay runs on the ~118 000 largest energies --
+    a vertex's energy never grows, so who can win soon is among them -- and everyone else keeps score 0; the subset is an upper
+    set of the energies, and on it the kernel agrees with the model run on the subset alone."""
+    from animsnapbases_amd import HipEngine
+    rng = np.random.default_rng(8)
+    n, r, steps = 300000, 24, 32
+    Z = rng.normal(size=(r, 3 * n)) * (0.85 ** np.arange(r))[:, None] * rng.uniform(0.2, 1.0, size=(1, n)).repeat(3, axis=1)
+    own = (Z * Z).sum(0).reshape(n, 3).sum(1)
+    E = own * (1.0 + 1e-3 * rng.uniform(0.5, 1.5, size=n))
+    eng = HipEngine(0)
+    scores, pred, status = _predict(eng, Z, np.ones(r), E, steps)
+    assert status == 1
+    sub = np.flatnonzero(scores > 0)
+    print("replay subset: %d of %d vertices" % (sub.size, n))
+    assert 90000 <= sub.size <= 131072
+    outside = np.ones(n, bool)
+    outside[sub] = False
+    assert E[sub].min() >= E[outside].max()                      # the largest energies, all of them
+    cols = (3 * sub[:, None] + np.arange(3)[None]).ravel()
+    ms, mp = replay_model_f32(Z[:, cols], E[sub], steps)
+    mp = [int(sub[p]) for p in mp]
+    agree = next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp))
+    print("largest score difference %.2e, winners agree for %d of %d steps" % (np.abs(scores[sub] - ms).max(), agree, len(mp)))
+    assert agree >= (3 * len(mp)) // 4 and np.abs(scores[sub] - ms).max() < 5e-4
     eng.close()
 
 
