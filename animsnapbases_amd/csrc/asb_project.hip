@@ -2213,6 +2213,8 @@ static int hist_grid(const asb_ctx* ctx) {
 int asb_sketch_subset_tau(asb_ctx* ctx, const double* E, long long n, long long m_target, long long m_cap) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->hist, (size_t)ASB_NBINS))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->scalar_dev, (size_t)48))) return rc;      // (a context that never uploaded snapshots: the test entry)
+    ASB_HIP(ctx, hipMemsetAsync(ctx->hist, 0, ASB_NBINS * sizeof(int), ctx->stream));      // (between two reads the bins are zero anyway)
     long long want = (n + 255) / 256;
     const int grid = (int)(want < 4LL * ctx->n_cu ? want : 4LL * ctx->n_cu);
     for (int level = 1; level <= 2; ++level) {

@@ -159,8 +159,16 @@ __global__ __launch_bounds__(SK_T, 2) void k_sketch_greedy(const double* __restr
         }
     };
     gram();
-    // the part of the exact energy the sketch does not hold (f32 sum: good to 1e-7 of the energy, and the tail is a model anyway)
-    float tail = (float)fmax(e_in - (double)((g[0] + g[3]) + g[5]), 0.0);
+    // the part of the exact energy the sketch does not hold.  |Z_v|^2 is summed in f64 HERE, once (round 4): as an f32 sum it is
+    // good to 1e-7 of the energy, which is 10 % of a tail of 1e-6 -- and on structured data (a sketch that holds 0.999 of the
+    // residual) the tails are what ranks the vertices once the sketched energies have fallen to them
+    double own64 = 0.0;
+#pragma unroll
+    for (int i = 0; i < SK_R; ++i) {
+        const double a = (double)z[0][i / 2][i & 1], b = (double)z[1][i / 2][i & 1], c = (double)z[2][i / 2][i & 1];
+        own64 += a * a + b * b + c * c;
+    }
+    float tail = (float)fmax(e_in - own64, 0.0);
     float e = (g[0] + g[3]) + g[5] + tail;
     float score = 0.0f;
     const long long spin_max = test_stall ? (1LL << 10) : (1LL << 20);

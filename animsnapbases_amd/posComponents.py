@@ -236,7 +236,8 @@ class posComponents:  # Components == bases
         trace, centres = [], []
         # the objective of every iteration stays on the device and is read once after the loop (nothing in the loop depends
         # on the printed numbers): with the distance fields on the device an outer iteration synchronises once, for its centres
-        deferred = fields_on_device and hasattr(eng, "splocs_trace_begin") and num_iters_max > 0
+        deferred = fields_on_device and hasattr(eng, "splocs_trace_begin") and num_iters_max > 0 and \
+            os.environ.get("ASB_SPLOCS_DEFER", "1") != "0"
         if deferred:
             eng.splocs_trace_begin(num_iters_max)
         for it in range(num_iters_max):

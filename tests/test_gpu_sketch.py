@@ -53,7 +53,7 @@ def replay_model_f32(Z, E, steps):
     n = E.shape[0]
     Z = Z.astype(f32).reshape(Z.shape[0], n, 3).copy()          # (r, n, 3)
     own = (Z * Z).sum(axis=(0, 2), dtype=f32)
-    tail = np.maximum(E - own.astype(np.float64), 0.0).astype(f32)
+    tail = np.maximum(E - (Z.astype(np.float64) ** 2).sum(axis=(0, 2)), 0.0).astype(f32)      # (the kernel sums |Z_v|^2 in f64 for this)
     e = own + tail
     score = np.zeros(n, dtype=f32)
     pred = []
@@ -106,17 +106,17 @@ def test_replay_kernel_against_its_numpy_model(n, r, steps, tail_rel, tol):
     eng = HipEngine(0)
     scores, pred, status = _predict(eng, cols, wn2, E, steps)
     assert status == 1
-    # against the model in the kernel's own arithmetic (f32 sketch, f32 re-summed energies): the bound that says something about
-    # the KERNEL; the f64 model beside it shows what the f32 sketch itself costs (round 3 compared with that one at 5e-3)
-    ms, mp = replay_model_f32(Z, E, steps)
-    ms64, mp64 = replay_model(Z, E, steps)
+    # Round 3 held the kernel to the f64 model at 5e-3 and to the first HALF of its winners: the tail E - |Z|^2 was a difference
+    # of f32 sums, 10 % wrong for a tail of 1e-6.  With |Z_v|^2 summed in f64 for the tail (round 4) the kernel follows the f64
+    # model to 5e-4 and names (nearly) all its winners.  A NumPy model in f32 is printed beside it: it is the LESS faithful one --
+    # NumPy's f32 sums (pairwise, unfused) are not the kernel's (sequential packed FMAs) -- which is why it is not the bound.
+    ms, mp = replay_model(Z, E, steps)
+    ms32, mp32 = replay_model_f32(Z, E, steps)
     agree = next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp))
-    print("f32 model: largest score difference %.2e, winners agree for %d of %d steps; f64 model: %.2e, %d of %d" %
-          (np.abs(scores - ms).max(), agree, len(mp), np.abs(scores - ms64).max(),
-           next((t for t in range(len(mp64)) if pred[t] != mp64[t]), len(mp64)), len(mp64)))
-    # winners: every step up to the first NEAR-TIE of the model (two leading energies closer than 1e-5 relative: there an ulp
-    # in a product decides), and at least three quarters of the steps
-    assert agree >= (3 * len(mp)) // 4, (agree, len(mp))
+    print("f64 model: largest score difference %.2e, winners agree for %d of %d steps; NumPy f32 model: %.2e, %d of %d" %
+          (np.abs(scores - ms).max(), agree, len(mp), np.abs(scores - ms32).max(),
+           next((t for t in range(len(mp32)) if pred[t] != mp32[t]), len(mp32)), len(mp32)))
+    assert agree >= (7 * len(mp)) // 8, (agree, len(mp))
     assert np.abs(scores - ms).max() < tol
     eng.close()
 
@@ -141,7 +141,7 @@ def test_replay_on_the_largest_energies_above_one_launch():
     outside[sub] = False
     assert E[sub].min() >= E[outside].max()                      # the largest energies, all of them
     cols = (3 * sub[:, None] + np.arange(3)[None]).ravel()
-    ms, mp = replay_model_f32(Z[:, cols], E[sub], steps)
+    ms, mp = replay_model(Z[:, cols], E[sub], steps)
     mp = [int(sub[p]) for p in mp]
     agree = next((t for t in range(len(mp)) if pred[t] != mp[t]), len(mp))
     print("largest score difference %.2e, winners agree for %d of %d steps" % (np.abs(scores[sub] - ms).max(), agree, len(mp)))
