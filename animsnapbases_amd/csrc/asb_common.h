@@ -240,6 +240,7 @@ struct asb_ctx {
     double* la_vtmp = nullptr;
     double* kk_tmp = nullptr;     // K x K transposed factor (asb_combine_rows)
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
+    double* pod_vn = nullptr;     // (F x K) right Ritz vectors / sigma of the power step
     int* la_status = nullptr;
     double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix

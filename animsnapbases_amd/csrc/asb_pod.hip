@@ -316,6 +316,40 @@ extern "C" int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host) {
     return ASB_OK;
 }
 
+// One step of subspace iteration on A A^T from the Rayleigh-Ritz result (round 4): the rows of the rotated B are sigma_i v_i^T
+// (v_i = A^T u_i / sigma_i, the right Ritz vectors -- exact images of the basis under A^T), so basis <- A V Sigma^-1 is A A^T
+// applied to every basis vector and scaled back to unit length.  What it buys: the Gram route leaves each weak vector with an
+// error ~ eps (sigma_0 / sigma_k)^2 that points OUT of the K + 32-dimensional Ritz subspace -- Rayleigh-Ritz on A cannot see it
+// -- spread over all the directions the subspace lacks; this step multiplies the part along direction j by (sigma_j / sigma_k)^2,
+// and most of those directions have singular values far below sigma_k.  The caller re-orthogonalises (CholeskyQR2: the new
+// vectors are the old ones plus small corrections) and repeats project + rotate.  B_dev: the buffer asb_pod_rotate worked on.
+__global__ __launch_bounds__(256) void k_power_v(const double* __restrict__ B, int F, int K, const int* __restrict__ where,
+                                                 const double* __restrict__ sig, double* __restrict__ Vn) {
+    // Vn (F x K) row-major: column r = row where[r] of B / sigma_r^2
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)F * K; e += (long long)gridDim.x * 256) {
+        const int f = (int)(e / K), r = (int)(e % K);
+        const double s = sig[r];
+        Vn[e] = s > 0.0 ? B[(long long)where[r] * F + f] / (s * s) : 0.0;
+    }
+}
+extern "C" int asb_pod_power(asb_ctx* ctx, const double* B_dev) {
+    if (!ctx || !ctx->X || !ctx->comps || !ctx->jac_where || !ctx->olam) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, F = ctx->F, n3 = 3 * ctx->n_loc;
+    const double* B = B_dev ? B_dev : ctx->pod_v;
+    if (!B) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_power: no rotated B (asb_pod_rotate first)");
+    if ((K | F | n3) & 1) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_pod_power: odd dimension (K = %lld, F = %lld, rows = %lld)", (long long)K,
+                                   (long long)F, (long long)n3);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_vn, (size_t)F * K))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * n3))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->pod_s, (size_t)K))) return rc;
+    hipLaunchKernelGGL(k_power_v, dim3(1024), dim3(256), 0, ctx->stream, B, (int)F, (int)K, ctx->jac_where, ctx->olam, ctx->pod_vn);
+    ASB_CHECK_LAUNCH(ctx);
+    // (3n x F)(F x K) on the tiled MFMA GEMM, then the transposition back to component-major rows (scale 1)
+    if ((rc = asb_gemm_nn(ctx, ctx->X, ctx->Fp, ctx->pod_vn, K, ctx->comps2, K, (int)n3, (int)K, (int)F, 1.0, 0.0))) return rc;
+    return asb_transpose(ctx, ctx->comps2, n3, K, ctx->comps);
+}
+
 // --------------------------------------------------------------------------------------
 // DEIM, device half (:820-836): r[e,i] = sum_{j<k} coef[i][j] V[e,j,i] - V[e,k,i],  idx = argmax_e sum_i r^2.
 // V[e,j,i] = comps[j][3e+i].  The k x k interpolation solves stay on the host (numpy lstsq, the

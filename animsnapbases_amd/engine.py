@@ -596,6 +596,9 @@ class HipEngine(object):
         self._ck(self.lib.asb_pod_rotate(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, ptr(S)))
         return S
 
+    def pod_power(self, B_dev_ptr=None):
+        self._ck(self.lib.asb_pod_power(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None))
+
     def qr_apply_joint(self, G_dev_ptr=None):
         self._ck(self.lib.asb_qr_apply_joint(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
 

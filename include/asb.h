@@ -440,6 +440,11 @@ int asb_pod_basis_dev(asb_ctx* ctx, int64_t K);
  * K x F matrix B = Q^T A (B_dev, or the context's from asb_pod_project; overwritten) by one-sided Jacobi on its rows;
  * basis <- Q U_B.  Replaces the small host SVD between asb_pod_project and asb_components_transform. */
 int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host);
+/* One step of subspace iteration from the Rayleigh-Ritz result: basis <- A V Sigma^-1 with the right Ritz vectors asb_pod_rotate
+ * left in B (even K, F and row count).  Followed by CholeskyQR2 + asb_pod_project + asb_pod_rotate again it removes most of what the
+ * Gram route's eps (sigma_0 / sigma_k)^2 leaves OUTSIDE the Ritz subspace of the weak vectors (constraintsComponents.py:307: the
+ * reference's gesdd has no such loss). */
+int asb_pod_power(asb_ctx* ctx, const double* B_dev);
 /* constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, :274-294): one SVD per (constraint row, coordinate)
  * slice of the snapshots -- e x F matrices -- by Gram matrix + device eigen-solver; the K leading left vectors of every
  * slice become the device-resident basis (K, e p, 3).  The reference does this in float32 with torch on the CPU. */

@@ -155,15 +155,17 @@ def test_config5_full_size_vs_reference(tmp_path):
     comps = cc.comps.copy()
     P = comps.reshape(K, -1) @ Gp
     sign = np.sign(np.einsum("kp,kp->k", P, g["comps_proj"]))
-    # accuracy of the Gram route + Rayleigh-Ritz: eps (sigma_0 / sigma_k)^2 leaks into directions beyond the K + 32 Ritz
-    # vectors, i.e. ~1e-6 on the LAST vectors here (sigma_256 = 3e-6 sigma_0) and rounding level on the strong ones; the
-    # bar is north_star's 1e-5 relative Frobenius error on the basis
+    # accuracy: the Gram route + Rayleigh-Ritz alone leaves eps (sigma_0 / sigma_k)^2 OUTSIDE the K + 32 Ritz vectors -- 1e-6 to
+    # 5e-6 on the last vectors here (sigma_256 = 3e-6 sigma_0; round 3's figure, ASB_POD_POWER=0) --; with the step of subspace
+    # iteration of round 4 (asb_pod_power) every one of the 256 vectors is held to 1e-7, the strong ones to 1e-8
     per = np.sqrt((((P * sign[:, None]) - g["comps_proj"]) ** 2).sum(1) / (g["comps_proj"] ** 2).sum(1))
-    print("config 5: per-vector error of the 32 projections: head", per[:4], "k=128", per[126:130], "tail", per[-4:])
+    print("config 5: per-vector error of the 32 projections: head", per[:4], "k=128", per[126:130], "tail", per[-4:],
+          "largest %.2e at k = %d; power steps: %s" % (per.max(), int(per.argmax()), getattr(cc, "pod_power_steps", 0)))
     strong = g["S"][:K] > 1e-4 * g["S"][0]
     assert strong.sum() >= 128 and per[strong].max() < 1e-8
-    assert relerr(P * sign[:, None], g["comps_proj"]) < 1e-5
-    assert relerr(comps[:, sv, :] * sign[:, None, None], g["comps_sample"]) < 1e-5
+    assert per.max() < 1e-7
+    assert relerr(P * sign[:, None], g["comps_proj"]) < 1e-7
+    assert relerr(comps[:, sv, :] * sign[:, None, None], g["comps_sample"]) < 1e-7
     assert np.abs(comps.reshape(K, -1) @ comps.reshape(K, -1).T - np.eye(K)).max() < 1e-10
     # install the reference's signs (LAPACK's are arbitrary and "+ mean" is not symmetric), post-process, DEIM
     cc.comps = comps * sign[:, None, None]
