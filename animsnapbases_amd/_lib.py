@@ -88,6 +88,8 @@ PROTOTYPES = {
     "asb_pod_basis_dev": (c_int, [ctypes.c_void_p, c_i64]),
     "asb_pod_rotate": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_dp]),
     "asb_pod_power": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "asb_pod_deflate_begin": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64]),
+    "asb_pod_deflate_end": (c_int, [ctypes.c_void_p, c_i64]),
     "asb_qr_apply_joint": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "asb_test_tridiag_eig": (c_int, [ctypes.c_void_p, c_dp, c_dp, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),
     "asb_test_jacobi_rows": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_dp, c_dp, ctypes.POINTER(c_i64)]),

@@ -565,11 +565,69 @@ class constraintsComponents:  # Components == bases
 
     @log_time(constProj_output_directory)
     def compute_pod_for_vectorized_nonlinear_snapshots_tensor(self, writer=None):
-        """constraintsComponents.py:298-320: svd(A), A = R.reshape(F,-1).T (3ep x F), through the Gram matrix."""
+        """constraintsComponents.py:298-320: svd(A), A = R.reshape(F,-1).T (3ep x F): ``comps = U[:K]`` and ALL F singular values
+        (the CSV).  Here: Gram matrix -> F x F eigen-problem on the device -> Rayleigh-Ritz on A itself (+ steps of subspace
+        iteration for weak vectors) -- and, where K reaches below what the Gram matrix of A resolves (~1e-8 sigma_0; the
+        reference's gesdd returns vectors there too), the same again on the DEFLATED snapshots A - U_1 U_1^T A, level by level
+        (round 4; round 3 raised ArithmeticError)."""
         ns = self.nonlinearSnapshots
         eng, comm = ns._engine, ns._comm
         F = ns.frs
         K = min(int(self.param.deim_desired_num_components), F)
+        on_dev = os.environ.get("ASB_POD_EIG", getattr(self, "pod_eig", "device")) == "device"
+        levels_ok = hasattr(eng, "pod_deflate_begin") and not (F & 1) and not any((3 * n) & 1 for _, n in ns._shards) \
+            and os.environ.get("ASB_POD_LEVELS", "1") != "0"
+        S_kept = []                     # singular values of the vectors kept by finished levels
+        remaining, level = K, 0
+        self.pod_power_steps = 0
+        while True:
+            S_lvl, Sb, Kx, Bbuf, keep = self._pod_level(remaining, on_dev)
+            resolved = int(np.sum(S_lvl > 3e-8 * S_lvl[0])) if S_lvl[0] > 0 else 0
+            if Kx >= remaining:         # this level delivers everything that is still wanted
+                break
+            # K reaches below what this level's Gram matrix resolves: keep what it resolved WELL (above 1e-5 of the level's
+            # largest: Gram error below 1e-6, which the subspace-iteration steps remove), deflate, go on
+            if not levels_ok or keep < 2 or level >= 8:
+                raise ArithmeticError("POD: singular value %d of the %d requested is %.3e of the largest -- below what the "
+                                      "Gram-matrix route resolves (1e-8), and the deflated levels cannot take over here (%s)"
+                                      % (K, K, S_lvl[remaining - 1] / S_lvl[0] if S_lvl[0] > 0 else 0.0,
+                                         "odd F or row count" if not levels_ok else "nothing left to resolve: the snapshot "
+                                         "matrix has numerical rank %d" % (K - remaining + resolved)))
+            eng.pod_deflate_begin(keep, Bbuf.data_ptr() if Bbuf is not None else None)
+            S_kept.extend(Sb[:keep].tolist())
+            remaining -= keep
+            level += 1
+        if level:
+            eng.pod_deflate_end(remaining, K)
+            # the levels' vectors are orthogonal to one another to ~eps |A| / |A_level|: one CholeskyQR2 over all K rows
+            for _ in range(2):
+                Gq = comm.new_buffer(3 * K * K, eng.device_exchange) if comm.multi else None
+                eng.orth_gram(Gq.data_ptr() if Gq is not None else None)
+                if Gq is not None:
+                    comm.allreduce_tensor(Gq)
+                eng.qr_apply_joint(Gq.data_ptr() if Gq is not None else None)
+        elif Kx > K:                                    # drop the oversampling vectors again
+            eng.components_truncate(K)
+        S = np.concatenate([np.asarray(S_kept), S_lvl])[:F] if S_kept else S_lvl
+        if Sb is not None:
+            S = S.copy()
+            nb = min(len(Sb), S.shape[0] - len(S_kept))
+            S[len(S_kept):len(S_kept) + nb] = Sb[:nb]
+        self.singular_values = S
+        self.pod_levels = level + 1
+        if writer is not None:
+            for ai, bi in zip(range(1, S.shape[0] + 1), S):
+                writer.writerow([ai, bi])
+        self._comps, self._comps_on_device = None, True
+        self.numComp = K
+
+    def _pod_level(self, K, on_dev):
+        """One level of the POD on the context's CURRENT snapshots (the original ones, or a deflated copy): all F singular
+        values the Gram matrix gives, and a device basis of Kx rows -- the K wanted ones (+ oversampling while more follow) when
+        the level resolves them, else as many as it does resolve.  Returns (S_level (F), refined values Sb (Kx) or None, Kx, B)."""
+        ns = self.nonlinearSnapshots
+        eng, comm = ns._engine, ns._comm
+        F = ns.frs
         # eigenvectors computed: K + the refinement's oversampling -- all F of them when that is not much more: a noise
         # floor is one big cluster of singular values, and a Rayleigh-Ritz subspace that cuts through the cluster leaves
         # the requested vectors inside it 1e-4 off (seed 41014 of tools/fuzz_sweep_more.py: F = 69, K = 22, rank 5 + noise)
@@ -579,7 +637,6 @@ class constraintsComponents:  # Components == bases
             Gbuf = comm.new_buffer(F * F, eng.device_exchange)
             eng.pod_gram(Gbuf.data_ptr(), to_host=False)
             comm.allreduce_tensor(Gbuf)                      # partial Gram matrices: RCCL all-reduce
-        on_dev = os.environ.get("ASB_POD_EIG", getattr(self, "pod_eig", "device")) == "device"
         dev_vectors = False
         if on_dev and F >= 3 and (Gbuf is None or Gbuf.is_cuda):
             # F x F eigen-problem entirely on the device: Householder tridiagonalisation (asb_eig.hip), bisection + inverse
@@ -597,70 +654,72 @@ class constraintsComponents:  # Components == bases
             lam, V = np.linalg.eigh(G)                       # ascending
             lam, V = lam[::-1], V[:, ::-1]
         S = np.sqrt(np.maximum(lam, 0.0))
-        self.singular_values = S
         # The Gram route resolves singular values down to ~sqrt(eps) sigma_max (vector k carries an error eps (sigma_0 /
-        # sigma_k)^2).  Below that a left vector A v / sigma is noise divided by noise: refuse instead of returning it.
-        if not S[K - 1] > 3e-8 * S[0]:
-            raise ArithmeticError("POD: singular value %d of the %d requested is %.3e of the largest -- below what the "
-                                  "Gram-matrix route resolves (1e-8); ask for fewer components (the snapshot matrix has "
-                                  "numerical rank %d)" % (K, K, S[K - 1] / S[0] if S[0] > 0 else 0.0,
-                                                          int(np.sum(S > 3e-8 * S[0]))))
+        # sigma_k)^2).  Below that a left vector A v / sigma is noise divided by noise: this level stops there.
+        resolved = int(np.sum(S > 3e-8 * S[0])) if S[0] > 0 else 0
+        if resolved < K:
+            Kx = min(Kv, resolved)
+            if Kx < 1:
+                return S, None, 0, None, 0
+        else:
+            Kx = None
         # Gram-route accuracy of left vector k is eps (sigma_0 / sigma_k)^2, and the device's inverse iteration gives the
         # vectors of close eigenvalues only as a span.  Rayleigh-Ritz on A itself repairs both: K + p Gram vectors ->
         # orthonormal Q (CholeskyQR2 with the joint Gram matrix over all 3 ep entries, blocked Cholesky on the device) ->
         # B = Q^T A (one more pass over A) -> left vectors / singular values of the small B by one-sided Jacobi on the
         # device -> basis = Q U_B.  Always on with the device eigen-solver; with host LAPACK vectors only when the
         # weakest requested component makes the Gram route worse than ~1e-9.
-        refine = (dev_vectors or S[0] > 3e3 * S[K - 1]) and getattr(self, "pod_refine", True)
-        if refine:
-            Kx = int(min(Kv, np.sum(S > 3e-8 * S[0])))
+        refine = (dev_vectors or Kx is not None or S[0] > 3e3 * S[K - 1]) and getattr(self, "pod_refine", True)
+        if not refine:
             if dev_vectors:
-                eng.pod_basis_dev(Kx)
+                eng.pod_basis_dev(K)
             else:
-                eng.pod_basis(np.ascontiguousarray(V[:, :Kx]), S[:Kx])
-            def ritz():
-                for _ in range(2):
-                    Gq = comm.new_buffer(3 * Kx * Kx, eng.device_exchange) if comm.multi else None
-                    eng.orth_gram(Gq.data_ptr() if Gq is not None else None)
-                    if Gq is not None:
-                        comm.allreduce_tensor(Gq)
-                    eng.qr_apply_joint(Gq.data_ptr() if Gq is not None else None)       # one factor for all three slices
-                Bbuf = comm.new_buffer(Kx * F, eng.device_exchange) if comm.multi else None
-                eng.pod_project(Bbuf.data_ptr() if Bbuf is not None else None, to_host=False)
-                if Bbuf is not None:
-                    comm.allreduce_tensor(Bbuf)
-                return eng.pod_rotate(Bbuf.data_ptr() if Bbuf is not None else None), Bbuf
-            Sb, Bbuf = ritz()
-            # Tail accuracy (round 4).  Rayleigh-Ritz repairs what lies INSIDE span(Q); the Gram route also leaves every weak
-            # vector eps (sigma_0 / sigma_k)^2 OUTSIDE it.  One step of subspace iteration -- basis <- A V Sigma^-1 from the
-            # right Ritz vectors, then Rayleigh-Ritz again -- shrinks the part along a missing direction j by (sigma_j /
-            # sigma_k)^2.  Taken where it is needed (the weakest requested vector below 1e-4 sigma_0: Gram error above 1e-8)
-            # AND can work (the spectrum still falls across the oversampling vectors; inside a flat noise floor every missing
-            # direction is as strong as the vector itself and the step would change nothing).  ASB_POD_POWER=0 / .pod_power.
-            want_power = getattr(self, "pod_power", os.environ.get("ASB_POD_POWER", "1") != "0")
-            # (a second step below 1e-5 sigma_0 -- Gram error above 1e-6; measured on config 5's fixture, sigma_256 = 3e-6
-            # sigma_0: largest per-vector error 5e-6 without, 2.7e-7 with one step, below 1e-7 with two)
-            self.pod_power_steps = 0
-            while want_power and hasattr(eng, "pod_power") and Kx > K and Sb[Kx - 1] < 0.6 * Sb[K - 1] \
-                    and not ((Kx | F) & 1) and not any((3 * n) & 1 for _, n in ns._shards) \
-                    and self.pod_power_steps < (2 if Sb[K - 1] < 1e-5 * Sb[0] else (1 if Sb[K - 1] < 1e-4 * Sb[0] else 0)):
-                eng.pod_power(Bbuf.data_ptr() if Bbuf is not None else None)
-                Sb, Bbuf = ritz()
-                self.pod_power_steps += 1
-            S = S.copy()
-            S[:Kx] = Sb
-            self.singular_values = S
-            if Kx > K:                                  # drop the oversampling vectors again
-                eng.components_truncate(K)
-        elif dev_vectors:
-            eng.pod_basis_dev(K)
+                eng.pod_basis(np.ascontiguousarray(V[:, :K]), S[:K])
+            return S, None, K, None, K
+        if Kx is None:
+            Kx = int(min(Kv, resolved))
+        if dev_vectors:
+            eng.pod_basis_dev(Kx)
         else:
-            eng.pod_basis(np.ascontiguousarray(V[:, :K]), S[:K])
-        if writer is not None:
-            for ai, bi in zip(range(1, S.shape[0] + 1), S):
-                writer.writerow([ai, bi])
-        self._comps, self._comps_on_device = None, True
-        self.numComp = K
+            eng.pod_basis(np.ascontiguousarray(V[:, :Kx]), S[:Kx])
+
+        def ritz():
+            for _ in range(2):
+                Gq = comm.new_buffer(3 * Kx * Kx, eng.device_exchange) if comm.multi else None
+                eng.orth_gram(Gq.data_ptr() if Gq is not None else None)
+                if Gq is not None:
+                    comm.allreduce_tensor(Gq)
+                eng.qr_apply_joint(Gq.data_ptr() if Gq is not None else None)       # one factor for all three slices
+            Bbuf = comm.new_buffer(Kx * F, eng.device_exchange) if comm.multi else None
+            eng.pod_project(Bbuf.data_ptr() if Bbuf is not None else None, to_host=False)
+            if Bbuf is not None:
+                comm.allreduce_tensor(Bbuf)
+            return eng.pod_rotate(Bbuf.data_ptr() if Bbuf is not None else None), Bbuf
+        Sb, Bbuf = ritz()
+        # Tail accuracy (round 4).  Rayleigh-Ritz repairs what lies INSIDE span(Q); the Gram route also leaves every weak
+        # vector eps (sigma_0 / sigma_k)^2 OUTSIDE it.  One step of subspace iteration -- basis <- A V Sigma^-1 from the
+        # right Ritz vectors, then Rayleigh-Ritz again -- shrinks the part along a missing direction j by (sigma_j /
+        # sigma_k)^2.  Taken where it is needed (the weakest wanted vector below 1e-4 sigma_0: Gram error above 1e-8; a second
+        # step below 1e-5 -- config 5's fixture, sigma_256 = 3e-6 sigma_0: largest per-vector error 5e-6 without, 2.7e-7 with
+        # one step, 1e-8 with two) AND can work (the spectrum still falls across the oversampling vectors; inside a flat noise
+        # floor every missing direction is as strong as the vector itself and the step would change nothing).
+        want_power = getattr(self, "pod_power", os.environ.get("ASB_POD_POWER", "1") != "0")
+        # what this level hands on: the K wanted vectors, or -- when it cannot resolve them all -- the ones above 1e-5 of its
+        # largest singular value (an even number: the device GEMMs' alignment)
+        target = K
+        if Kx < K:
+            target = int(np.sum(Sb > 1e-5 * Sb[0]))
+            target -= target & 1
+        kq = max(target, 1) - 1
+        steps = 0
+        while want_power and hasattr(eng, "pod_power") and target >= 1 and Kx > target and Sb[Kx - 1] < 0.6 * Sb[kq] \
+                and not ((Kx | F) & 1) and not any((3 * n) & 1 for _, n in ns._shards) \
+                and steps < (2 if Sb[kq] < 1e-5 * Sb[0] else (1 if Sb[kq] < 1e-4 * Sb[0] else 0)):
+            eng.pod_power(Bbuf.data_ptr() if Bbuf is not None else None)
+            Sb, Bbuf = ritz()
+            steps += 1
+        self.pod_power_steps += steps
+        return S, Sb, Kx, Bbuf, target
 
     @log_time(constProj_output_directory)
     def post_process_components(self):
@@ -707,6 +766,8 @@ class constraintsComponents:  # Components == bases
             # single rank: the whole loop on the device (bordered inverse of the k x k systems carried there, verified
             # per step); one host synchronisation.  A failed verification falls through to the lstsq loop below.
             Pt_d, maxabs, bad = eng.deim_run()
+            if bad and os.environ.get("ASB_DEBUG_DEIM"):
+                print("[asb] DEIM: the device loop's verification failed at a step: host loop", file=sys.stderr)
             if not bad:
                 for k in range(K):
                     if k > 0 and maxabs[k] <= 1e-8:             # np.allclose(r, 0) of :837

@@ -241,6 +241,10 @@ struct asb_ctx {
     double* kk_tmp = nullptr;     // K x K transposed factor (asb_combine_rows)
     double *pod_g = nullptr, *pod_v = nullptr, *pod_s = nullptr, *pod_coef = nullptr;   // asb_pod.hip
     double* pod_vn = nullptr;     // (F x K) right Ritz vectors / sigma of the power step
+    // the POD in levels (asb_pod_deflate_begin / _end): bases kept by finished levels, the deflated copy of the snapshots
+    double* pod_u1 = nullptr;
+    int64_t pod_u1_rows = 0;
+    double *X_deflated = nullptr, *X_original = nullptr;
     int* la_status = nullptr;
     double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix

@@ -350,6 +350,84 @@ extern "C" int asb_pod_power(asb_ctx* ctx, const double* B_dev) {
     return asb_transpose(ctx, ctx->comps2, n3, K, ctx->comps);
 }
 
+// ---- the POD in LEVELS (round 4): what the Gram matrix of A cannot resolve -- singular values below ~1e-8 sigma_0, where its
+// entries are rounding noise of the strong directions -- is resolved by the Gram matrix of the DEFLATED snapshots A_2 = A - U_1
+// (U_1^T A), whose largest singular value is the first one level 1 left out.  asb_pod_deflate_begin keeps the level's basis U_1
+// (the first `keep` rows of the context's basis; appended to what earlier levels kept) and replaces the context's snapshot
+// tensor by A_2 (a second buffer: the original is restored by asb_pod_deflate_end); every POD entry point then works on A_2 as
+// it did on A.  asb_pod_deflate_end restores the snapshots and installs [kept bases of all levels ; first `last` rows of the
+// current basis] as the context's basis.  B_dev: the (all-reduced) buffer asb_pod_rotate worked on (rows sigma_i v_i^T, unsorted).
+__global__ __launch_bounds__(256) void k_gather_b(const double* __restrict__ B, int F, int K, const int* __restrict__ where,
+                                                  double* __restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)K * F; e += (long long)gridDim.x * 256)
+        out[e] = B[(long long)where[e / F] * F + e % F];
+}
+extern "C" int asb_pod_deflate_begin(asb_ctx* ctx, const double* B_dev, int64_t keep) {
+    if (!ctx || !ctx->X || !ctx->comps || !ctx->jac_where) return ASB_ERR_ARG;
+    const int64_t K = ctx->K, F = ctx->F, n3 = 3 * ctx->n_loc;
+    const double* B = B_dev ? B_dev : ctx->pod_v;
+    if (!B || keep < 1 || keep > K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_deflate_begin: keep = %lld of %lld", (long long)keep, (long long)K);
+    if ((keep | F | n3 | ctx->Fp) & 1) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_pod_deflate_begin: odd dimension");
+    int rc;
+    // the kept rows join the earlier levels' (pod_u1 grows: old content first)
+    const size_t have = (size_t)ctx->pod_u1_rows * n3, add = (size_t)keep * n3;
+    double* u1 = nullptr;
+    ASB_HIP(ctx, hipMalloc((void**)&u1, (have + add) * sizeof(double)));
+    if (have) ASB_HIP(ctx, hipMemcpyAsync(u1, ctx->pod_u1, have * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipMemcpyAsync(u1 + have, ctx->comps, add * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pod_u1) (void)hipFree(ctx->pod_u1);
+    ctx->pod_u1 = u1;
+    ctx->pod_u1_rows += keep;
+    // B_1 = U_1^T A in sorted order = the gathered rows of the rotated B; oct_1 = U_1^T (3n x keep)
+    if ((rc = asb_alloc(ctx, &ctx->pod_vn, (size_t)F * K))) return rc;
+    hipLaunchKernelGGL(k_gather_b, dim3(1024), dim3(256), 0, ctx->stream, B, (int)F, (int)keep, ctx->jac_where, ctx->pod_vn);
+    ASB_CHECK_LAUNCH(ctx);
+    if ((rc = asb_alloc(ctx, &ctx->comps2, (size_t)K * n3))) return rc;
+    if ((rc = asb_transpose(ctx, ctx->comps, keep, n3, ctx->comps2))) return rc;          // (3n x keep)
+    // A_2 = A - oct_1 B_1 into the second snapshot buffer
+    const size_t nx = (size_t)n3 * ctx->Fp;
+    if (!ctx->X_deflated) {
+        ASB_HIP(ctx, hipMalloc((void**)&ctx->X_deflated, nx * sizeof(double)));
+        ASB_HIP(ctx, hipMemcpyAsync(ctx->X_deflated, ctx->X, nx * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->X_original = ctx->X;
+        ctx->X = ctx->X_deflated;
+    }
+    if ((rc = asb_gemm_nn(ctx, ctx->comps2, keep, ctx->pod_vn, F, ctx->X, ctx->Fp, (int)n3, (int)F, (int)keep, -1.0, 1.0))) return rc;
+    ctx->e0_valid = false;
+    ctx->ev_valid = false;
+    return ASB_OK;
+}
+extern "C" int asb_pod_deflate_end(asb_ctx* ctx, int64_t last) {
+    if (!ctx || !ctx->X) return ASB_ERR_ARG;
+    if (!ctx->X_original) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_deflate_end without asb_pod_deflate_begin");
+    const int64_t n3 = 3 * ctx->n_loc;
+    if (last < 0 || last > ctx->K) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_pod_deflate_end: last = %lld of %lld", (long long)last, (long long)ctx->K);
+    const int64_t Kt = ctx->pod_u1_rows + last;
+    double* nb = nullptr;
+    ASB_HIP(ctx, hipMalloc((void**)&nb, (size_t)Kt * n3 * sizeof(double)));
+    ASB_HIP(ctx, hipMemcpyAsync(nb, ctx->pod_u1, (size_t)ctx->pod_u1_rows * n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (last)
+        ASB_HIP(ctx, hipMemcpyAsync(nb + (size_t)ctx->pod_u1_rows * n3, ctx->comps, (size_t)last * n3 * sizeof(double),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the context's basis buffer is replaced (asb_alloc's bookkeeping follows the pointer variable)
+    if (ctx->comps) (void)hipFree(ctx->comps);
+    ctx->comps = nb;
+    ctx->alloc_bytes[(void*)&ctx->comps] = (size_t)Kt * n3 * sizeof(double);
+    ctx->K = Kt;
+    ctx->X = ctx->X_original;
+    ctx->X_original = nullptr;
+    (void)hipFree(ctx->X_deflated);
+    ctx->X_deflated = nullptr;
+    (void)hipFree(ctx->pod_u1);
+    ctx->pod_u1 = nullptr;
+    ctx->pod_u1_rows = 0;
+    ctx->e0_valid = false;
+    ctx->ev_valid = false;
+    return ASB_OK;
+}
+
 // --------------------------------------------------------------------------------------
 // DEIM, device half (:820-836): r[e,i] = sum_{j<k} coef[i][j] V[e,j,i] - V[e,k,i],  idx = argmax_e sum_i r^2.
 // V[e,j,i] = comps[j][3e+i].  The k x k interpolation solves stay on the host (numpy lstsq, the

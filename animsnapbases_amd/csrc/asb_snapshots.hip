@@ -316,6 +316,12 @@ extern "C" void asb_destroy(asb_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->X_original) {                    // a POD in levels that did not reach its end: the original snapshots own the slot
+        ctx->X = ctx->X_original;
+        ctx->X_original = nullptr;
+    }
+    if (ctx->X_deflated) (void)hipFree(ctx->X_deflated);
+    if (ctx->pod_u1) (void)hipFree(ctx->pod_u1);
     for (auto& kv : ctx->alloc_bytes) {       // every context-owned buffer was registered by asb_alloc
         void** slot = (void**)kv.first;
         if (*slot) (void)hipFree(*slot);

@@ -596,6 +596,13 @@ class HipEngine(object):
         self._ck(self.lib.asb_pod_rotate(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, ptr(S)))
         return S
 
+    def pod_deflate_begin(self, keep, B_dev_ptr=None):
+        self._ck(self.lib.asb_pod_deflate_begin(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None, int(keep)))
+
+    def pod_deflate_end(self, last, K_total):
+        self._ck(self.lib.asb_pod_deflate_end(self.h, int(last)))
+        self.K = int(K_total)
+
     def pod_power(self, B_dev_ptr=None):
         self._ck(self.lib.asb_pod_power(self.h, ctypes.c_void_p(B_dev_ptr) if B_dev_ptr else None))
 

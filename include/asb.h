@@ -445,6 +445,14 @@ int asb_pod_rotate(asb_ctx* ctx, double* B_dev, double* S_host);
  * Gram route's eps (sigma_0 / sigma_k)^2 leaves OUTSIDE the Ritz subspace of the weak vectors (constraintsComponents.py:307: the
  * reference's gesdd has no such loss). */
 int asb_pod_power(asb_ctx* ctx, const double* B_dev);
+/* The POD in LEVELS: singular values below ~1e-8 sigma_0 are invisible in the Gram matrix of A (where the reference's gesdd on A
+ * itself still returns vectors, constraintsComponents.py:307-316) but not in the Gram matrix of A_2 = A - U_1 (U_1^T A).
+ * asb_pod_deflate_begin(ctx, B_dev, keep): the first `keep` rows of the basis are kept (behind what earlier levels kept) and the
+ * context's snapshots become A_2 (a second buffer; even `keep`, F and row count); the POD entry points then work on A_2.
+ * asb_pod_deflate_end(ctx, last): the snapshots are the original ones again, the basis is [kept rows of all levels ; the first
+ * `last` rows of the current basis]. */
+int asb_pod_deflate_begin(asb_ctx* ctx, const double* B_dev, int64_t keep);
+int asb_pod_deflate_end(asb_ctx* ctx, int64_t last);
 /* constProj_basis_type 'pod' (compute_pod_for_nonlinear_snapshots_tensor, :274-294): one SVD per (constraint row, coordinate)
  * slice of the snapshots -- e x F matrices -- by Gram matrix + device eigen-solver; the K leading left vectors of every
  * slice become the device-resident basis (K, e p, 3).  The reference does this in float32 with torch on the CPU. */

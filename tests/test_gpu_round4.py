@@ -174,3 +174,64 @@ def test_device_resident_constraint_frames_with_mass_weights(rest_shape):
     mean = W[0] if rest_shape == "first" else W.mean(axis=0)
     R = W - mean[None]
     assert relerr(devs.snapTensor, R / R.std()) < 1e-12
+
+
+def _cparam(K, tmp):
+    return types.SimpleNamespace(constProj_rest_shape="first", constProj_numFrames=0, constProj_p_size=1, constProj_massWeight=False,
+                                 constProj_standarize=True, constProj_orthogonal=False, constProj_basis_type="pod_vectorized",
+                                 deim_desired_num_components=K, constProj_store_sing_val=False, constProj_output_directory=str(tmp),
+                                 name="t", constProj_name="v")
+
+
+@pytest.mark.parametrize("ep,F,r,K,floor", [(400, 120, 20, 44, 1e-9), (1200, 260, 30, 100, 1e-10), (300, 64, 6, 30, 1e-12)])
+def test_pod_reaches_into_the_noise_floor_like_svd(ep, F, r, K, floor, tmp_path):
+    """constraintsComponents.py:307-316 returns K left vectors whatever the spectrum.  K cuts deep into a noise floor 1e-9 and
+    less below the signal -- invisible in the Gram matrix of A (round 3 raised ArithmeticError): the POD goes on level by level
+    on the deflated snapshots (asb_pod_deflate_begin).  Against SciPy's svd of A (the oracle): all singular values, the signal
+    vectors one by one, the floor vectors one by one where the floor's own gaps determine them and as a subspace always."""
+    from animsnapbases_amd import constraintsComponents, nonlinearSnapshots
+    rng = np.random.default_rng(ep + F)
+    coef = rng.normal(size=(F, r)) * np.logspace(0, -3, r)[None]
+    frames = 0.3 + np.tensordot(coef, rng.normal(size=(r, ep, 3)), (1, 0)) + floor * rng.normal(size=(F, ep, 3))
+    pre = orc.prepare_nonlinear_snapshots(frames, "first", True)
+    pod = orc.pod_vectorized(pre["snapTensor"], K)
+    S_ref = pod["S"]
+    n_sig = int(np.sum(S_ref > 1e-6 * S_ref[0]))
+    assert n_sig < K - 8 and S_ref[K - 1] < 3e-8 * S_ref[0]           # K is far inside the floor, below the Gram route's reach
+    param = _cparam(K, tmp_path)
+    ns = nonlinearSnapshots(param, frames=frames)
+    ns.config()
+    ns.snapshots_prepare()
+    cc = constraintsComponents(param, ns)
+    cc.config()
+    cc.compute_components_store_singvalues()
+    assert cc.pod_levels >= 2
+    S = cc.singular_values
+    assert S.shape == S_ref.shape
+    assert relerr(S[:n_sig], S_ref[:n_sig]) < 1e-9
+    nz = S_ref > 1e-3 * S_ref[n_sig]                                    # (rest shape "first": one exact zero at the end)
+    assert relerr(S[nz], S_ref[nz]) < 1e-6, relerr(S[nz], S_ref[nz])
+    got, want = cc.comps.reshape(K, -1), pod["comps"].reshape(K, -1)
+    assert np.abs(got @ got.T - np.eye(K)).max() < 1e-10
+    sg = np.sign(np.sum(got * want, axis=1))
+    per = np.linalg.norm(got * sg[:, None] - want, axis=1)
+    print("levels %d; per-vector error: signal max %.2e, floor max %.2e (median %.2e)" %
+          (cc.pod_levels, per[:n_sig].max(), per[n_sig:].max(), np.median(per[n_sig:])))
+    assert per[:n_sig].max() < 1e-7
+    # the floor: the span of the first K vectors is determined by the gap between sigma_K and sigma_K+1 alone -- and only as
+    # well as a backward-stable SVD determines it: a perturbation eps |A| moves it by eps sigma_0 / (sigma_K - sigma_K+1), which
+    # is what two correct algorithms (LAPACK's on A, this one) may differ by (here ~1e-6: sigma_K ~ 3e-8 sigma_0, gap ~ 3e-3)
+    gap = (S_ref[K - 1] - S_ref[K]) / S_ref[K - 1]
+    cond = 2.2e-16 * S_ref[0] / (S_ref[K - 1] * gap)
+    Pg, Pw = got.T @ got, want.T @ want
+    print("relative gap at the cut %.2e, conditioning eps sigma_0 / (sigma_K gap) = %.2e, |P - P_ref| = %.2e" %
+          (gap, cond, np.linalg.norm(Pg - Pw)))
+    if 100.0 * cond < 1e-2:          # (a floor at 1e-12 sigma_0 leaves the cut undetermined for LAPACK as well: cond > 1)
+        assert np.linalg.norm(Pg - Pw) < max(1e-7, 100.0 * cond)
+    # and every returned floor vector is a singular vector of A to the floor's own accuracy: |A^T u| = its singular value
+    A = pre["snapTensor"].reshape(F, -1).T
+    rq = np.linalg.norm(A.T @ got.T, axis=0)
+    if cond < 1e-2:
+        assert relerr(rq[n_sig:], S_ref[n_sig:K]) < 1e-4
+    else:                            # floor at rounding level of A: the values are floor-sized, no more can be said
+        assert np.all(rq[n_sig:] < 4.0 * S_ref[n_sig]) and np.all(rq[n_sig:] > 0.25 * S_ref[K - 1])
