@@ -329,6 +329,8 @@ struct asb_splocs {
     double* trace = nullptr;          // (its, 3): <W, P>, <G, M>, sum Lambda |C_v| of every outer iteration, read once at the end
     int64_t trace_cap = 0;
     bool defer_status = false;        // the ADMM's status word is looked at with the trace, not after every outer iteration
+    double* pin = nullptr;            // 4096 doubles of pinned host memory for the centres' read-back
+    ~asb_splocs() { if (pin) (void)hipHostFree(pin); }
 };
 
 static int dot_to_dev(asb_ctx* ctx, asb_splocs* s, const double* a, const double* b, long long n, double* out_dev) {
@@ -391,7 +393,13 @@ extern "C" int asb_splocs_gram(asb_ctx* ctx, double* P_dev, double* M_dev, doubl
     double* Mout = M_dev ? M_dev : s->M;
     int rc;
     if ((rc = asb_transpose(ctx, s->C, K, n3, s->Ct))) return rc;
-    if ((rc = asb_gemm_tn(ctx, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout))) return rc;
+    // P = X^T C^T is the one pass over X of an outer iteration: on the 128 x 128-tile MFMA kernel of the POD's Gram matrix (two
+    // operands, split over row slabs) where the shapes allow -- the one-wave-per-16 x 16-tile kernel takes ~0.4 ms for config 3's
+    // 44 379 x 1000 by 44 379 x 64 (it re-reads X once per 16 columns of C)
+    static const int big = getenv("ASB_SPLOCS_GRAM_BIG") ? atoi(getenv("ASB_SPLOCS_GRAM_BIG")) : 1;
+    if (big && K >= 32 && !(K & 1)) rc = asb_gemm_tn_big(ctx, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout);
+    else rc = asb_gemm_tn(ctx, ctx->X, ctx->Fp, s->Ct, K, n3, (int)ctx->F, (int)K, Pout);
+    if (rc) return rc;
     if ((rc = asb_gemm_tn(ctx, s->Ct, K, s->Ct, K, n3, (int)K, (int)K, Mout))) return rc;
     if (normX2_local) return dot_to_host(ctx, s, ctx->X, ctx->X, (long long)n3 * ctx->Fp, normX2_local);
     return ASB_OK;
@@ -428,6 +436,18 @@ extern "C" int asb_splocs_weights(asb_ctx* ctx, const double* P_dev, const doubl
     hipLaunchKernelGGL(k_centres, dim3(K), dim3(256), 0, ctx->stream, s->C, (long long)ctx->n_loc, (long long)ctx->v0,
                        s->cen_idx, s->cen_val);
     ASB_CHECK_LAUNCH(ctx);
+    // the centres come back through PINNED memory: a device-to-host copy into pageable memory is a blocking staged copy (~100 us
+    // of idle GPU each, twice per outer iteration); into pinned memory it is one small asynchronous copy
+    if (!s->pin) ASB_HIP(ctx, hipHostMalloc((void**)&s->pin, 4096 * sizeof(double), hipHostMallocDefault));
+    const bool fits = (size_t)K <= 2048;
+    if (fits && (centre_idx || centre_val)) {
+        ASB_HIP(ctx, hipMemcpyAsync(s->pin, s->cen_idx, K * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(s->pin + 2048, s->cen_val, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (centre_idx) memcpy(centre_idx, s->pin, K * sizeof(long long));
+        if (centre_val) memcpy(centre_val, s->pin + 2048, K * sizeof(double));
+        return ASB_OK;
+    }
     if (centre_idx) ASB_HIP(ctx, hipMemcpyAsync(centre_idx, s->cen_idx, K * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     if (centre_val) ASB_HIP(ctx, hipMemcpyAsync(centre_val, s->cen_val, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));

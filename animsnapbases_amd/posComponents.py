@@ -194,6 +194,10 @@ class posComponents:  # Components == bases
 
     @log_time("")
     def splocs_glob_optimization(self, num_iters_max, num_admm_iterations, R, compute_geodesic_distance):
+        with _u.no_gc():          # (a garbage collection inside the loop is 2 - 3 ms of idle GPU: utils.no_gc)
+            return self._splocs_glob_optimization(num_iters_max, num_admm_iterations, R, compute_geodesic_distance)
+
+    def _splocs_glob_optimization(self, num_iters_max, num_admm_iterations, R, compute_geodesic_distance):
         """posComponents.py:131-189 on the GPU (csrc/asb_splocs.hip).
 
         Like the reference, this leaves ``comps`` / ``weigs`` untouched (the reference works on

@@ -18,6 +18,24 @@ from numpy.linalg import matrix_rank
 _has_written = False
 
 
+class no_gc(object):
+    """The host loops that feed the GPU launch by launch (SPLOCS' outer iterations, the per-component residual loop) leave the
+    device idle for as long as the interpreter pauses: a generation-2 garbage collection in the middle of one costs 2 - 3 ms
+    (measured on config 3: two such holes in 20 outer iterations).  Collection is deferred to the end of the loop."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def log_time(filePath):
     """Decorator: prints and logs ``Function '<name>' executed in X.XXXX seconds.`` to
     ``<filePath>function_timings.txt`` (first call of the process truncates, later calls
