@@ -235,3 +235,53 @@ def test_pod_reaches_into_the_noise_floor_like_svd(ep, F, r, K, floor, tmp_path)
         assert relerr(rq[n_sig:], S_ref[n_sig:K]) < 1e-4
     else:                            # floor at rounding level of A: the values are floor-sized, no more can be said
         assert np.all(rq[n_sig:] < 4.0 * S_ref[n_sig]) and np.all(rq[n_sig:] > 0.25 * S_ref[K - 1])
+
+
+@pytest.mark.parametrize("world,kind", [(3, "lowrank"), (2, "bumps"), (3, "rankdef")])
+def test_multirank_read_in_one_exchange_on_structured_data(world, kind):
+    """The multi-rank read of round 4 (asb_panel_read_run / _commit: one launch of the panel kernel, one min-all-reduce per read)
+    where the shards DISAGREE: on structured data a tile stands on one shard and falls on another, so the local chain of a
+    shard runs ahead of the verdict and is rolled back; on rank-deficient data the stall rule fires over the ranks and the run
+    continues in the residual protocol.  `world` shards with their own contexts on one GPU (emulated collectives)."""
+    import contextlib
+    import io
+    from animsnapbases_amd import HipEngine, posComponents, posSnapshots
+    from thread_comm import run_ranks
+    rng = np.random.default_rng(world * 7 + len(kind))
+    N, F = 12001, 96
+    if kind == "lowrank":
+        verts, K = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=20, noise=1e-4, decay=0.9, seed=3), 40
+    elif kind == "bumps":
+        verts, K = orc.synth_snapshots(rng.uniform(size=(N, 3)), F, rank=24, noise=1e-4, decay=0.9, seed=4, kind="bumps"), 40
+    else:
+        verts, K = orc.synth_snapshots(rng.normal(size=(N, 3)), F, rank=6, noise=1e-13, decay=0.8, seed=5), 30
+    param = _param(K)
+
+    def rank_fn(rank, comm):
+        with contextlib.redirect_stdout(io.StringIO()):
+            snaps = posSnapshots.from_arrays(verts, None, "first", standarize=True, massWeight=False,
+                                             engine=HipEngine(0, stream=0), comm=comm)
+            comp = posComponents(param, snaps)
+            comp.deflate_mode = "project"
+            comp.compute_components_store_singvalues()
+        return (comp.selected_vertices.copy(), comp.comps.copy(), comp.weigs.copy(), comp.measures_at_largeDeforVerts.copy(),
+                snaps._engine.deflate_stats())
+
+    outs = run_ranks(world, rank_fn)
+    pre = orc.prepare_snapshots(verts, "first", True)
+    ref = orc.extract_k_components(pre["snapTensor"], K)
+    sig = ref["measures"][:, 1]
+    good = int(np.argmax(sig < 1e-7 * sig[0])) if np.any(sig < 1e-7 * sig[0]) else K
+    print(kind, "world", world, "determined components", good, "of", K, "| residual switch at", [o[4]["residual_switch_at"] for o in outs],
+          "| reads", [o[4]["panels"] + o[4]["refreshes"] for o in outs])
+    for idx, comps, weigs, meas, st in outs:
+        assert idx[:good].tolist() == ref["idx"][:good].tolist()
+        c, w = align_signs(comps[:good], weigs[:, :good], ref["comps"][:good])
+        assert relerr(c, ref["comps"][:good]) < 1e-7 and relerr(w, ref["weigs"][:, :good]) < 1e-7
+        assert relerr(meas[:good, 1], sig[:good]) < 1e-7
+        rec = np.tensordot(weigs, comps, axes=([1], [0]))
+        if kind == "rankdef":
+            assert st["residual_switch_at"] >= good - 1
+            assert relerr(rec, pre["snapTensor"]) < 1e-9
+    for o in outs[1:]:           # every rank ends with the same replicated results
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1], outs[0][1])

@@ -2,7 +2,7 @@
 """Where the GPU sits idle between kernels: from a rocprofv3 --kernel-trace SQLite result (*_results.db), the dispatch timeline of
 the busiest window, idle time grouped by the pair (kernel before the gap, kernel after it).
 
-    python tools/rocpd_gaps.py gpurun_out/<tag>/prof/stats_results.db [first_kernel_substring] [min_gap_us]
+    python tools/rocpd_gaps.py gpurun_out/<tag>/prof/stats_results.db [first_kernel_substring] [min_gap_us] [end_kernel_substring]
 The window starts at the LAST dispatch of `first_kernel_substring` minus nothing (default: the whole trace)."""
 import sqlite3
 import sys
@@ -20,10 +20,17 @@ for kid, name in con.execute("select id, display_name from rocpd_info_kernel_sym
 disp = [(ks.get(k, str(k)), s, e) for k, s, e in rows]
 sub = sys.argv[2] if len(sys.argv) > 2 else None
 min_gap = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
+end_sub = sys.argv[4] if len(sys.argv) > 4 else None
 if sub:
     idx = [i for i, d in enumerate(disp) if sub in d[0]]
     if idx:
-        disp = disp[idx[0]:]
+        # with an END substring: the LAST window [last `sub` .. first `end_sub` behind it] (one timed step of a bench run)
+        start = idx[-1] if end_sub else idx[0]
+        disp = disp[start:]
+        if end_sub:
+            e = [i for i, d in enumerate(disp) if end_sub in d[0]]
+            if e:
+                disp = disp[:e[0] + 1]
 t0, t1 = disp[0][1], max(d[2] for d in disp)
 busy = 0
 gaps = defaultdict(lambda: [0, 0.0])
