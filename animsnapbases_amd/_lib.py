@@ -133,6 +133,7 @@ PROTOTYPES = {
     "asb_geodesic_setup": (c_int, [ctypes.c_void_p, c_int, c_int] + [c_dp] * 14),
     "asb_geodesic_solve": (c_int, [ctypes.c_void_p, c_dp, c_int, c_dbl, c_dp, c_dp]),
     "asb_geodesic_dense_setup": (c_int, [ctypes.c_void_p]),
+    "asb_geodesic_bt_setup": (c_int, [ctypes.c_void_p, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "asb_deflate_apply_geodesic": (c_int, [ctypes.c_void_p, c_i64, c_dbl, c_dbl]),
     "asb_align_frames": (c_int, [ctypes.c_void_p, c_dp, c_i64, c_i64, c_int, c_dp]),
     "asb_pod_gram": (c_int, [ctypes.c_void_p, c_dp, c_dp]),

@@ -9,7 +9,21 @@
 // right-hand side and the constant is fixed afterwards by phi -= min(phi), exactly as the reference does (:206).
 #include "asb_kernels.h"
 
+#include <vector>
+
 #define GB 64     // right-hand sides per batch = lanes of a wave
+
+// One factorised block-tridiagonal SPD matrix (the "slab" mode, round 4): A = L D L^T with dense blocks --
+// Dinv[k] = D_k^-1 (sp_k x sp_k), E[k] = A_{k,k-1} D_{k-1}^-1 (sp_k x sp_{k-1}) and its transpose Et[k]
+struct asb_bt {
+    std::vector<double*> Dinv, E, Et;
+    void release() {
+        for (auto* p : Dinv) if (p) (void)hipFree(p);
+        for (auto* p : E) if (p) (void)hipFree(p);
+        for (auto* p : Et) if (p) (void)hipFree(p);
+        Dinv.clear(); E.clear(); Et.clear();
+    }
+};
 
 struct asb_csr {
     int rows = 0, cols = 0;
@@ -40,6 +54,15 @@ struct asb_geo {
     // distance fields kept for SPLOCS (asb_geodesic_cache_add): slot q lives in slab[q / 64] at row q % 64
     double* slab[ASB_GEO_CACHE_SLABS] = {};
     long long cached = 0;
+    // slab mode (asb_geodesic_bt_setup): both systems factorised DIRECTLY as block-tridiagonal matrices over breadth-first
+    // slabs of the mesh; bt_off / bt_sz: padded offset / size of every slab, pos: vertex -> padded position
+    bool bt = false;
+    std::vector<int> bt_off, bt_sz;
+    int bt_npad = 0;
+    int* bt_pos = nullptr;
+    asb_bt Hbt, Pbt;
+    double *bt_z = nullptr, *bt_w = nullptr;       // (npad x 64) right-hand sides / solutions in slab order
+    ~asb_geo() { Hbt.release(); Pbt.release(); }
 };
 
 // Y = A X  (+ optional per-column partial sums of X .* Y for CG's p^T A p)
@@ -291,6 +314,7 @@ extern "C" int asb_geodesic_setup(asb_ctx* ctx, int n, int m3, const int* heat_r
     G->n = n; G->m3 = m3;
     G->dense = false;                  // a new mesh: explicit inverses and cached fields of the old one are void
     G->coarse = false;
+    G->bt = false;
     G->cached = 0;
     int rc;
     if ((rc = upload_csr(ctx, G->heat, n, n, heat_rp, heat_ci, heat_v))) return rc;
@@ -537,6 +561,198 @@ extern "C" int asb_geodesic_dense_setup(asb_ctx* ctx) {
     return ASB_OK;
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// Slab mode (round 4): a DIRECT sparse solver out of dense building blocks.  Breadth-first level sets of the mesh graph,
+// grouped into slabs of ~1500 vertices (geodesic.py: bfs_slabs), make both matrices block tridiagonal: a vertex's
+// neighbours lie in its own or an adjacent level.  Block LDL^T: D_0 = A_00, E_k = A_{k,k-1} D_{k-1}^-1, D_k = A_kk - E_k
+// A_{k-1,k}, each D_k^-1 by the symmetric blocked Gauss-Jordan of asb_dense.hip, the products on the tiled f64-MFMA GEMM.
+// A solve is a forward sweep z_k -= E_k z_{k-1}, w_k = D_k^-1 z_k, and a backward sweep w_k -= E_{k+1}^T w_{k+1} -- 3 small
+// GEMMs per slab for 64 right-hand sides.  What it buys over the Jacobi-sweep / PCG sparse mode: no convergence question
+// at all -- the heat system's solution spans 14 orders of magnitude and must be right in every component (utils/support.py:
+// 181-190 needs the DIRECTION of grad u everywhere); for an M-matrix every term of these sweeps has the same sign, as in
+// SuperLU's factorisation, whatever the element sizes (slivers, graded meshes) -- and no size limit but memory: ~3 ns s^2
+// doubles per matrix (100 000 vertices, 50 slabs of 2000: 4.8 GB).
+// The Laplacian is singular (constants): ONE vertex is grounded (gamma on its diagonal); for the consistent right-hand side
+// div X the grounded solution is an exact solution of the singular system, and phi -= min(phi) removes the constant.
+// --------------------------------------------------------------------------------------------------------------------
+// out (nr_pad x ld) <- block [r0, r0 + nr) x [c0, c0 + nc) of a CSR matrix; pad_diag: 1 on the diagonal of the padding rows
+__global__ __launch_bounds__(256) void k_csr_block_dense(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                                         const double* __restrict__ vals, int r0, int nr, int c0, int nc,
+                                                         double* __restrict__ out, int ld, int nr_pad, int pad_diag) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wid; r < nr_pad; r += gridDim.x * 4) {
+        double* row = out + (long long)r * ld;
+        if (r >= nr) {
+            if (pad_diag && lane == 0 && r < ld) row[r] = 1.0;
+            continue;
+        }
+        for (int j = rowptr[r0 + r] + lane; j < rowptr[r0 + r + 1]; j += 64) {
+            const int c = colidx[j] - c0;
+            if (c >= 0 && c < nc) row[c] = vals[j];
+        }
+    }
+}
+// z[pos[v]] = b[v] (64 columns) / x[v] = w[pos[v]]
+__global__ __launch_bounds__(256) void k_bt_permute(const double* __restrict__ in, const int* __restrict__ pos, int n,
+                                                    double* __restrict__ out, int gather) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int v = blockIdx.x * 4 + wid; v < n; v += gridDim.x * 4) {
+        if (gather) out[(long long)pos[v] * GB + lane] = in[(long long)v * GB + lane];
+        else out[(long long)v * GB + lane] = in[(long long)pos[v] * GB + lane];
+    }
+}
+__global__ void k_add_one(double* __restrict__ p, double v) { *p += v; }
+
+static int bt_factor(asb_ctx* ctx, asb_geo* G, asb_bt& bt, const int* rp, const int* ci, const double* va, const std::vector<int>& ptr,
+                     int ground_row, double ground_val) {
+    const int ns = (int)G->bt_sz.size();
+    bt.release();
+    bt.Dinv.assign(ns, nullptr);
+    bt.E.assign(ns, nullptr);
+    bt.Et.assign(ns, nullptr);
+    int rc;
+    double* Ct = nullptr;                      // A_{k-1,k} (sp_{k-1} x sp_k): scratch, sized for the largest pair
+    size_t ct_cap = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int sp = G->bt_sz[k], s = ptr[k + 1] - ptr[k];
+        ASB_HIP(ctx, hipMalloc((void**)&bt.Dinv[k], (size_t)sp * sp * sizeof(double)));
+        ASB_HIP(ctx, hipMemsetAsync(bt.Dinv[k], 0, (size_t)sp * sp * sizeof(double), ctx->stream));
+        const int grid = (sp + 3) / 4 < 2048 ? (sp + 3) / 4 : 2048;
+        hipLaunchKernelGGL(k_csr_block_dense, dim3(grid), dim3(256), 0, ctx->stream, rp, ci, va, ptr[k], s, ptr[k], s, bt.Dinv[k], sp, sp, 1);
+        if (ground_row >= ptr[k] && ground_row < ptr[k + 1]) {
+            const int q = ground_row - ptr[k];
+            hipLaunchKernelGGL(k_add_one, dim3(1), dim3(1), 0, ctx->stream, bt.Dinv[k] + (size_t)q * sp + q, ground_val);
+        }
+        if (k > 0) {
+            const int spm = G->bt_sz[k - 1], sm = ptr[k] - ptr[k - 1];
+            ASB_HIP(ctx, hipMalloc((void**)&bt.E[k], (size_t)sp * spm * sizeof(double)));
+            ASB_HIP(ctx, hipMalloc((void**)&bt.Et[k], (size_t)sp * spm * sizeof(double)));
+            const size_t need = (size_t)sp * spm;
+            if (need > ct_cap) {
+                if (Ct) (void)hipFree(Ct);
+                ASB_HIP(ctx, hipMalloc((void**)&Ct, 2 * need * sizeof(double)));
+                ct_cap = need;
+            }
+            double* C = Ct + ct_cap;           // A_{k,k-1} (sp x sp_{k-1})
+            ASB_HIP(ctx, hipMemsetAsync(Ct, 0, 2 * ct_cap * sizeof(double), ctx->stream));
+            hipLaunchKernelGGL(k_csr_block_dense, dim3(grid), dim3(256), 0, ctx->stream, rp, ci, va, ptr[k], s, ptr[k - 1], sm, C, spm, sp, 0);
+            const int gridm = (spm + 3) / 4 < 2048 ? (spm + 3) / 4 : 2048;
+            hipLaunchKernelGGL(k_csr_block_dense, dim3(gridm), dim3(256), 0, ctx->stream, rp, ci, va, ptr[k - 1], sm, ptr[k], s, Ct, sp, spm, 0);
+            ASB_CHECK_LAUNCH(ctx);
+            // E_k = A_{k,k-1} D_{k-1}^-1 ; D_k -= E_k A_{k-1,k}
+            if ((rc = asb_gemm_nn(ctx, C, spm, bt.Dinv[k - 1], spm, bt.E[k], spm, sp, spm, spm, 1.0, 0.0))) return rc;
+            if ((rc = asb_gemm_nn(ctx, bt.E[k], spm, Ct, sp, bt.Dinv[k], sp, sp, sp, spm, -1.0, 1.0))) return rc;
+            if ((rc = asb_transpose(ctx, bt.E[k], sp, spm, bt.Et[k]))) return rc;
+        }
+        ASB_CHECK_LAUNCH(ctx);
+        if ((rc = asb_dense_spd_inverse(ctx, bt.Dinv[k], sp))) return rc;
+    }
+    ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (Ct) (void)hipFree(Ct);
+    return ASB_OK;
+}
+
+// slab_ptr (nslab + 1): slab boundaries in the PERMUTED numbering; perm_of_vertex (n): vertex -> permuted index; the two CSR
+// matrices in the permuted numbering (A - tL and -L)
+extern "C" int asb_geodesic_bt_setup(asb_ctx* ctx, int nslab, const int* slab_ptr, const int* perm_of_vertex, const int* heat_rp,
+                                     const int* heat_ci, const double* heat_v, const int* lap_rp, const int* lap_ci,
+                                     const double* lap_v) {
+    if (!ctx || !ctx->geo || nslab < 1 || !slab_ptr || !perm_of_vertex || !heat_rp || !lap_rp) return ASB_ERR_ARG;
+    asb_geo* G = ctx->geo;
+    const int n = G->n;
+    if (slab_ptr[0] != 0 || slab_ptr[nslab] != n) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_geodesic_bt_setup: the slabs do not cover the %d vertices", n);
+    std::vector<int> ptr(slab_ptr, slab_ptr + nslab + 1);
+    G->bt = false;
+    G->bt_off.assign(nslab, 0);
+    G->bt_sz.assign(nslab, 0);
+    int off = 0;
+    for (int k = 0; k < nslab; ++k) {
+        const int s = ptr[k + 1] - ptr[k];
+        if (s < 1) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_geodesic_bt_setup: empty slab %d", k);
+        G->bt_off[k] = off;
+        G->bt_sz[k] = (s + 15) / 16 * 16;
+        off += G->bt_sz[k];
+    }
+    G->bt_npad = off;
+    // vertex -> padded position
+    std::vector<int> slab_of(n), pos(n);
+    for (int k = 0; k < nslab; ++k)
+        for (int q = ptr[k]; q < ptr[k + 1]; ++q) slab_of[q] = k;
+    for (int v = 0; v < n; ++v) {
+        const int q = perm_of_vertex[v];
+        if (q < 0 || q >= n) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_geodesic_bt_setup: bad permutation");
+        pos[v] = G->bt_off[slab_of[q]] + (q - ptr[slab_of[q]]);
+    }
+    int rc;
+    if ((rc = asb_alloc(ctx, &G->bt_pos, (size_t)n))) return rc;
+    if ((rc = asb_alloc(ctx, &G->bt_z, (size_t)G->bt_npad * GB))) return rc;
+    if ((rc = asb_alloc(ctx, &G->bt_w, (size_t)G->bt_npad * GB))) return rc;
+    ASB_HIP(ctx, hipMemcpyAsync(G->bt_pos, pos.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    // the permuted matrices go to the device for the block extraction only
+    auto up = [&](const int* rp, const int* ci, const double* va, int*& drp, int*& dci, double*& dva) -> int {
+        const long long nnz = rp[n];
+        ASB_HIP(ctx, hipMalloc((void**)&drp, (size_t)(n + 1) * sizeof(int)));
+        ASB_HIP(ctx, hipMalloc((void**)&dci, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int)));
+        ASB_HIP(ctx, hipMalloc((void**)&dva, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double)));
+        ASB_HIP(ctx, hipMemcpyAsync(drp, rp, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(dci, ci, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        ASB_HIP(ctx, hipMemcpyAsync(dva, va, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        return ASB_OK;
+    };
+    int *hrp = nullptr, *hci = nullptr, *lrp = nullptr, *lci = nullptr;
+    double *hva = nullptr, *lva = nullptr;
+    auto body = [&]() -> int {
+        int r;
+        if ((r = up(heat_rp, heat_ci, heat_v, hrp, hci, hva))) return r;
+        if ((r = up(lap_rp, lap_ci, lap_v, lrp, lci, lva))) return r;
+        if ((r = bt_factor(ctx, G, G->Hbt, hrp, hci, hva, ptr, -1, 0.0))) return r;
+        // ground the LAST vertex of the permuted numbering with the mean diagonal of -L (keeps the conditioning)
+        double gamma = 0.0;
+        for (int q = 0; q < n; ++q)
+            for (int j = lap_rp[q]; j < lap_rp[q + 1]; ++j)
+                if (lap_ci[j] == q) gamma += lap_v[j];
+        gamma /= n;
+        if (!(gamma > 0.0)) ASB_FAIL(ctx, ASB_ERR_NUMERIC, "slab geodesics: the Laplacian has a non-positive mean diagonal");
+        return bt_factor(ctx, G, G->Pbt, lrp, lci, lva, ptr, n - 1, gamma);
+    };
+    rc = body();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : {(void*)hrp, (void*)hci, (void*)hva, (void*)lrp, (void*)lci, (void*)lva})
+        if (p) (void)hipFree(p);
+    if (rc) return rc;
+    G->bt = true;
+    G->dense = false;
+    G->coarse = false;
+    return ASB_OK;
+}
+
+// x (n x 64, vertex order) <- A^-1 b for a factorised matrix
+static int bt_solve(asb_ctx* ctx, asb_geo* G, const asb_bt& bt, const double* b, double* x) {
+    const int ns = (int)G->bt_sz.size(), n = G->n;
+    int rc;
+    const int grid = (n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048;
+    ASB_HIP(ctx, hipMemsetAsync(G->bt_z, 0, (size_t)G->bt_npad * GB * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_bt_permute, dim3(grid), dim3(256), 0, ctx->stream, b, G->bt_pos, n, G->bt_z, 1);
+    ASB_CHECK_LAUNCH(ctx);
+    for (int k = 0; k < ns; ++k) {             // forward: z_k -= E_k z_{k-1};  w_k = D_k^-1 z_k
+        const int sp = G->bt_sz[k];
+        double* zk = G->bt_z + (size_t)G->bt_off[k] * GB;
+        if (k > 0) {
+            const int spm = G->bt_sz[k - 1];
+            if ((rc = asb_gemm_nn(ctx, bt.E[k], spm, G->bt_z + (size_t)G->bt_off[k - 1] * GB, GB, zk, GB, sp, GB, spm, -1.0, 1.0))) return rc;
+        }
+        if ((rc = asb_gemm_nn(ctx, bt.Dinv[k], sp, zk, GB, G->bt_w + (size_t)G->bt_off[k] * GB, GB, sp, GB, sp, 1.0, 0.0))) return rc;
+    }
+    for (int k = ns - 2; k >= 0; --k) {        // backward: w_k -= E_{k+1}^T w_{k+1}
+        const int sp = G->bt_sz[k], spn = G->bt_sz[k + 1];
+        if ((rc = asb_gemm_nn(ctx, bt.Et[k + 1], spn, G->bt_w + (size_t)G->bt_off[k + 1] * GB, GB, G->bt_w + (size_t)G->bt_off[k] * GB, GB, sp, GB,
+                              spn, -1.0, 1.0))) return rc;
+    }
+    hipLaunchKernelGGL(k_bt_permute, dim3(grid), dim3(256), 0, ctx->stream, G->bt_w, G->bt_pos, n, x, 0);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 // distances of nsrc (<= 64) sources whose vertex ids are on the device; result (nsrc, n), min-shifted, in ctx->geo_out
 static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, double tol, int* it1_out, int* it2_out) {
     asb_geo* G = ctx->geo;
@@ -547,6 +763,10 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     int it1 = 0, it2 = 0;
     if (G->dense) {
         hipLaunchKernelGGL(k_gather_sources, dim3(1024), dim3(256), 0, ctx->stream, G->Hinv, G->np, src_dev, nsrc, G->x);
+    } else if (G->bt) {
+        ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
+        if ((rc = bt_solve(ctx, G, G->Hbt, G->b, G->x))) return rc;
     } else {
         ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
@@ -565,6 +785,10 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
     if (G->dense) {        // y = (-L + gamma/n 1 1^T)^-1 div : one (np x np) by (np x 64) product
         if ((rc = asb_gemm_nn(ctx, G->Pinv, G->np, G->b, GB, G->x, GB, G->np, GB, G->np, 1.0, 0.0))) return rc;
+    } else if (G->bt) {    // the grounded Laplacian, factorised: an exact solution of the singular system for the consistent div X
+        if ((rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
+        ASB_HIP(ctx, hipMemcpyAsync(G->z, G->b, (size_t)n * GB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = bt_solve(ctx, G, G->Pbt, G->z, G->x))) return rc;
     } else {
         hipLaunchKernelGGL(k_remove_mean, dim3(GB), dim3(256), 0, ctx->stream, G->b, n);
         if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2, G->coarse ? G->AcP : nullptr))) return rc;
@@ -773,14 +997,16 @@ __global__ __launch_bounds__(256) void k_support_weights(const double* __restric
 
 extern "C" int asb_deflate_apply_geodesic(asb_ctx* ctx, int64_t k, double dmin, double dmax) {
     if (!ctx || !ctx->geo || !ctx->scal) return ASB_ERR_ARG;
-    if (!ctx->geo->dense) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply_geodesic needs the dense geodesic backend");
+    if (!ctx->geo->dense && !ctx->geo->bt) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply_geodesic needs the dense or the slab geodesic backend");
     if (ctx->geo->n != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deflate_apply_geodesic: the mesh has %d vertices, the snapshots %lld",
                                             ctx->geo->n, (long long)ctx->N_glob);
     if (k < 0 || k >= ctx->K) return ASB_ERR_ARG;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->geo_src, (size_t)GB))) return rc;
     hipLaunchKernelGGL(k_src_from_pick, dim3(1), dim3(1), 0, ctx->stream, ctx->scal, (long long)k, ctx->geo_src);
-    if ((rc = geodesic_solve1_dense(ctx, ctx->geo_src))) return rc;
+    if (ctx->geo->dense) rc = geodesic_solve1_dense(ctx, ctx->geo_src);
+    else rc = geodesic_solve_dev(ctx, ctx->geo_src, 1, 1e-13, nullptr, nullptr);      // (slab mode: the batch solver with one source)
+    if (rc) return rc;
     const int grid = (int)((ctx->n_loc + 255) / 256 < 1024 ? (ctx->n_loc + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_support_weights, dim3(grid), dim3(256), 0, ctx->stream, ctx->geo_out, (long long)ctx->v0, (long long)ctx->n_loc,
                        dmin, dmax, ctx->s_dev);

@@ -470,7 +470,7 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ post-processing
     # ------------------------------------------------------------------ device geodesics
-    def geodesic_setup(self, heat, lap, grad, div, dense=False, coarse=None):
+    def geodesic_setup(self, heat, lap, grad, div, dense=False, coarse=None, slabs=None):
         """heat, lap, grad, div: scipy CSR matrices (float64).  dense: invert the two SPD systems explicitly on the
         device (asb_geodesic_dense_setup) instead of solving them by PCG per batch.  coarse = (agg, heat_c, lap_c): the
         aggregates and dense coarse operators of the PCG mode's two-level preconditioner."""
@@ -490,8 +490,19 @@ class HipEngine(object):
         args = csr(heat) + csr(lap) + csr(grad) + csr(div) + [dh.ctypes.data, dl.ctypes.data]
         self._ck(self.lib.asb_geodesic_setup(self.h, int(n), int(m3), *args))
         self._geo_n = n
-        self.geodesic_dense = bool(dense)
-        if dense:
+        self.geodesic_dense = bool(dense) or slabs is not None      # (the whole local step can stay on the device)
+        if slabs is not None:
+            # slab mode: order (permuted index -> vertex), ptr (slab boundaries); both matrices go over in the permuted numbering
+            order, ptr_ = slabs
+            order = np.ascontiguousarray(order, dtype=np.int64)
+            inv = np.empty(n, dtype=np.int32)
+            inv[order] = np.arange(n, dtype=np.int32)
+            hp = heat.tocsr()[order][:, order]
+            lp = lap.tocsr()[order][:, order]
+            ptr32 = np.ascontiguousarray(ptr_, dtype=np.int32)
+            self._ck(self.lib.asb_geodesic_bt_setup(self.h, int(ptr32.shape[0] - 1), ptr32.ctypes.data, inv.ctypes.data,
+                                                    *(csr(hp) + csr(lp))))
+        elif dense:
             self._ck(self.lib.asb_geodesic_dense_setup(self.h))
         elif coarse is not None:
             agg, heat_c, lap_c, omega = coarse

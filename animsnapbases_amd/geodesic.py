@@ -103,6 +103,50 @@ def mesh_aggregates(A, passes=None):
     return agg, nc
 
 
+def bfs_slabs(A, target=1536):
+    """Breadth-first level sets of the graph of the sparse symmetric matrix A, grouped into slabs of at least ``target``
+    vertices: a vertex's neighbours lie in its own or an adjacent level, so in the returned numbering A is BLOCK TRIDIAGONAL
+    over the slabs (csrc/asb_geodesic.hip: the slab mode's direct factorisation).  The sweep starts at a pseudo-peripheral
+    vertex (the last level of a sweep from vertex 0: long, narrow level structure); further components of a disconnected
+    mesh follow as their own levels.  Returns (order (n,): permuted index -> vertex, ptr (nslab + 1,): slab boundaries)."""
+    n = A.shape[0]
+    indptr, indices = A.indptr, A.indices
+
+    def sweep(start, seen):
+        levels, cur = [], np.array([start], dtype=np.int64)
+        seen[start] = True
+        while cur.size:
+            levels.append(cur)
+            lo, hi = indptr[cur], indptr[cur + 1]
+            nb = np.concatenate([indices[a:b] for a, b in zip(lo.tolist(), hi.tolist())]) if cur.size < 64 else \
+                indices[np.concatenate([np.arange(a, b) for a, b in zip(lo.tolist(), hi.tolist())])]
+            nb = np.unique(nb)
+            nb = nb[~seen[nb]]
+            seen[nb] = True
+            cur = nb
+        return levels
+    seen = np.zeros(n, dtype=bool)
+    first = sweep(0, seen)
+    start = int(first[-1][0])
+    seen[:] = False
+    levels = sweep(start, seen)
+    while not seen.all():                                   # other connected components
+        levels += sweep(int(np.flatnonzero(~seen)[0]), seen)
+    order, ptr, size = [], [0], 0
+    for lv in levels:
+        order.append(np.sort(lv))
+        size += lv.size
+        if size >= target:
+            ptr.append(ptr[-1] + size)
+            size = 0
+    if size:
+        if len(ptr) > 1 and size < target // 4:             # a small tail joins the last slab
+            ptr[-1] += size
+        else:
+            ptr.append(ptr[-1] + size)
+    return np.concatenate(order), np.asarray(ptr, dtype=np.int64)
+
+
 def coarse_operators(A_heat, L, agg, nc):
     """Dense coarse matrices P^T (A - tL) P and P^T (-L) P + (gamma / nc) 1 1^T (the rank-one term fixes the constant null
     vector of the Laplacian, as in the dense mode), P = piecewise-constant prolongation of `agg`."""
@@ -135,7 +179,8 @@ class GeodesicDistanceComputation(object):
         self.cache_bytes = 2 << 30
         self._ready = False
 
-    _PREPARED = frozenset(("G", "D", "_A_heat", "_L", "_engine", "_heat", "_poisson", "n_aggregates", "_tol"))
+    _PREPARED = frozenset(("G", "D", "_A_heat", "_L", "_engine", "_heat", "_poisson", "n_aggregates", "_tol", "n_slabs",
+                           "largest_slab"))
 
     def __getattr__(self, name):            # only reached for attributes that are not set (yet)
         if name in GeodesicDistanceComputation._PREPARED and not self.__dict__.get("_ready", True) \
@@ -205,7 +250,12 @@ class GeodesicDistanceComputation(object):
         self._engine = None
         if engine is not None:          # device backend instead of the SuperLU factorisations
             coarse = None
-            if backend != "dense" and n >= 512:      # sparse mode: aggregates + dense coarse operators (two-level PCG)
+            slabs = None
+            if backend == "slab":                    # direct block-tridiagonal factorisation over breadth-first slabs
+                slabs = bfs_slabs(self._A_heat.tocsr())
+                self.n_slabs = int(slabs[1].shape[0] - 1)
+                self.largest_slab = int(np.diff(slabs[1]).max())
+            elif backend != "dense" and n >= 512:      # sparse mode: aggregates + dense coarse operators (two-level PCG)
                 agg, nc = mesh_aggregates(self._A_heat.tocsr())
                 Hc, Lc = coarse_operators(self._A_heat, L, agg, nc)
                 # damping of the heat step's Jacobi sweeps: 1 on diagonally dominant matrices (non-obtuse meshes), below
@@ -215,7 +265,7 @@ class GeodesicDistanceComputation(object):
                 omega = 1.0 if g <= 0.98 else min(1.0, 1.8 / (1.0 + g))
                 coarse = (agg, Hc, Lc, omega)
                 self.n_aggregates = nc
-            engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D, dense=(backend == "dense"), coarse=coarse)
+            engine.geodesic_setup(self._A_heat, (-L).tocsr(), self.G, self.D, dense=(backend == "dense"), coarse=coarse, slabs=slabs)
             self._engine = engine
             self._tol = tol
             return self

@@ -161,20 +161,21 @@ class posSnapshots:
         if self.tris is not None and self.verts is not None:
             shape0 = self.verts[0] if self.rest_shape == "first" else np.mean(self.verts, axis=0)
             # "dense" (default up to DENSE_GEODESIC_MAX_VERTS): both SPD systems inverted once on the device, a query =
-            # gather + one dense product; the N x N inverses cost 2 N^3 flop each and 8 N^2 bytes, so larger meshes take
-            # "device": sparse batched PCG with a two-level (Jacobi + aggregate coarse space) preconditioner.  Opt-in:
-            # ASB_GEODESIC=host (SciPy SuperLU, what the reference does).
+            # gather + one dense product; the N x N inverses cost N^3 flop each and 8 N^2 bytes, so larger meshes take
+            # "slab" (round 4): a DIRECT block-tridiagonal factorisation over breadth-first slabs of the mesh graph, robust
+            # on graded meshes.  Opt-in: "device" (round 2's sparse batched PCG with a two-level preconditioner + Jacobi-sweep
+            # heat step; refuses badly graded meshes), ASB_GEODESIC=host (SciPy SuperLU, what the reference does).
             mode = os.environ.get("ASB_GEODESIC", getattr(self, "geodesic_backend", "auto"))
             if mode == "auto":
                 if not hasattr(eng, "geodesic_setup"):          # CPU test double of the engine (tests only)
                     mode = "host"
                 elif self.nVerts <= DENSE_GEODESIC_MAX_VERTS:
                     mode = "dense"
-                else:                                           # two N x N inverses no longer fit / pay: sparse two-level PCG
-                    mode = "device"
+                else:                                           # two N x N inverses no longer fit / pay: the slab factorisation
+                    mode = "slab"
             self.compute_geodesic_distance = GeodesicDistanceComputation(
-                shape0, self.tris, engine=eng if mode in ("dense", "device") else None,
-                backend="dense" if mode == "dense" else "pcg")
+                shape0, self.tris, engine=eng if mode in ("dense", "device", "slab") else None,
+                backend={"dense": "dense", "slab": "slab"}.get(mode, "pcg"))
 
         if standarize:
             self.standarize(_local_sum=local_sum, _local_sumsq=local_sumsq)

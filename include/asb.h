@@ -387,6 +387,13 @@ int asb_geodesic_solve(asb_ctx* ctx, const int64_t* sources, int nsrc, double to
  * (A - tL) and the gauge-fixed -L once on the device (blocked Gauss-Jordan on f64 MFMA); asb_geodesic_solve then
  * needs no iteration: the heat step is a column gather, the Poisson step one dense product.  tol / iters unused. */
 int asb_geodesic_dense_setup(asb_ctx* ctx);
+/* Slab mode (round 4): a DIRECT factorisation of both systems as block-tridiagonal matrices over breadth-first slabs of the mesh
+ * graph -- what the reference's two splu factorisations (utils/support.py:170-171) are for meshes beyond the dense inverses'
+ * 46 000 vertices and for badly graded ones (no iteration, no convergence question).  slab_ptr (nslab + 1): slab boundaries in a
+ * PERMUTED numbering in which every edge joins vertices of the same or of adjacent slabs; perm_of_vertex (n): vertex ->
+ * permuted index; heat / lap: A - tL and -L as CSR in that numbering (host). */
+int asb_geodesic_bt_setup(asb_ctx* ctx, int nslab, const int* slab_ptr, const int* perm_of_vertex, const int* heat_rp,
+                          const int* heat_ci, const double* heat_v, const int* lap_rp, const int* lap_ci, const double* lap_v);
 /* support='local' step without a host round trip (posComponents.py:87-105, dense geodesics): reads the vertex
  * asb_deflate_pick chose for component k on the device, solves its distance field, forms
  * s = 1 - (clip(phi, dmin, dmax) - dmin) / (dmax - dmin) (:61-64) for this shard and applies the deflation. */
