@@ -848,6 +848,65 @@ class constraintsComponents:  # Components == bases
         self.geom_alpha_ranges = np.array(e_range)
         self.geom_interpol_verts = np.array(self.geom_interpol_verts)
 
+    # ------------------------------------------------------------------ diagnostics (host NumPy on the downloaded basis)
+    def is_utmu_orthogonal(self):
+        """constraintsComponents.py:452-461: prints True.. / False.. per coordinate for U^T M U = I."""
+        print('... testing M orthogonality, U^T M U = I (Kp x Kp) ...', end='', flush=True)
+        comps, mass = self.comps, self.nonlinearSnapshots.mass
+        for l in range(comps.shape[2]):
+            Mu_l = comps[:, :, l].T * mass[:, None]
+            utMu_l = np.dot(comps[:, :, l], Mu_l)
+            print('True..' if np.allclose(utMu_l, np.eye(comps.shape[0])) else "False..")
+
+    def matrix_properties_test(self, interpol_kp_blocks, precondition=False):
+        """constraintsComponents.py:463-487: per frame, coordinate and number of interpolation points i, the relative error of
+        reconstructing the frame from its values at the first (i + 1) p interpolation rows (LU of the square J V).  Returns
+        mat_e (F, points, 3).  The per-frame loop of the reference is one multi-right-hand-side solve here."""
+        from scipy.linalg import lu_factor, lu_solve
+        ns = self.nonlinearSnapshots
+        p = ns.constraintsSize
+        interpol_kp_blocks = np.asarray(interpol_kp_blocks)
+        num_interpol_points = interpol_kp_blocks.shape[0] // p
+        snap = ns.snapTensor
+        F = snap.shape[0]
+        bases = self.comps.swapaxes(0, 1)                       # (ep, Kp, d)
+        denom = ns.dim * F * num_interpol_points * p
+        mat_e = np.zeros((F, num_interpol_points, 3))
+        for l in range(ns.dim):
+            fn = np.linalg.norm(snap[:, :, l], axis=1)
+            for i in range(num_interpol_points):
+                points = interpol_kp_blocks[:(i + 1) * p]
+                JV = bases[points, :(i + 1) * p, l]
+                x = lu_solve(lu_factor(JV), snap[:, points, l].T)            # ((i + 1) p, F)
+                r = bases[:, :(i + 1) * p, l] @ x - snap[:, :, l].T
+                mat_e[:, i, l] = np.linalg.norm(r, axis=0) / denom / fn
+        return mat_e
+
+    @staticmethod
+    def frobenius_error(f, f_reconstructed):
+        """constraintsComponents.py:524-530."""
+        return np.linalg.norm(f - f_reconstructed)
+
+    @staticmethod
+    def relative_error_per_component(f, f_reconstructed):
+        """constraintsComponents.py:532-545."""
+        return [np.linalg.norm(f[:, :, i] - f_reconstructed[:, :, i]) / np.linalg.norm(f[:, :, i]) for i in range(3)]
+
+    @staticmethod
+    def max_pointwise_error(f, f_reconstructed):
+        """constraintsComponents.py:547-556."""
+        return np.max(np.abs(f - f_reconstructed)) / np.max(f)
+
+    def test_basesSingVals(self):
+        """constraintsComponents.py:558-570: per-coordinate singular values of the (Kp x ep) basis, normalised."""
+        from scipy.linalg import svd
+        bases = self.comps.copy()
+        s = np.empty((bases.shape[0], 3))
+        for i in range(3):
+            sing = svd(bases[:, :, i], full_matrices=False, compute_uv=False)
+            s[:, i] = sing / sing.max()
+        return s
+
     def _rank_diagnostic(self, expected):
         """test_linear_dependency(bases, 3, expected) of :801 / :630 / :742 -- from the device's Gram matrices when the
         basis lives there."""

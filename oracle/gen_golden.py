@@ -498,6 +498,47 @@ def _ingest(work):
     print("wrote ingest_small")
 
 
+def _diagnostics(work):
+    """The diagnostics of constraintsComponents (constraintsComponents.py:452-487, 524-570) run by the unmodified reference on the
+    small POD + DEIM case: matrix_properties_test on the DEIM points, test_basesSingVals, the printed verdicts of
+    is_utmu_orthogonal, the three error metrics on a perturbed copy of the snapshots."""
+    ref = import_reference.cache
+    constraintsComponents, nonlinearSnapshots = ref["constraintsComponents"], ref["nonlinearSnapshots"]
+    rng = np.random.default_rng(11)
+    ep, F, K = 120, 24, 8
+    modes = rng.normal(size=(10, ep, 3))
+    coef = rng.normal(size=(F, 10)) * (0.6 ** np.arange(10))[None]
+    frames = 0.3 + np.tensordot(coef, modes, (1, 0)) + 1e-5 * rng.normal(size=(F, ep, 3))          # = the pod_deim_small input
+    param = types.SimpleNamespace(constProj_standarize=True, constProj_massWeight=False, constProj_orthogonal=True,
+                                  deim_desired_num_components=K, constProj_output_directory=work)
+    ns = object.__new__(nonlinearSnapshots)
+    ns.param, ns.rest_shape, ns.dim, ns.frs, ns.constraintsSize = param, "first", 3, F, 1
+    ns.num_constained_elements = ep
+    ns.snapTensor = frames.copy()
+    ns.mean, ns.pre_scale_factor, ns.massL, ns.invMassL = None, 1, None, None
+    ns.mass = rng.uniform(0.5, 2.0, size=ep)
+    ns.standarize()
+    cc = object.__new__(constraintsComponents)
+    cc.param, cc.nonlinearSnapshots, cc.numComp, cc.comps, cc.geom_interpol_verts = param, ns, 0, None, []
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cc.compute_pod_for_vectorized_nonlinear_snapshots_tensor(types.SimpleNamespace(writerow=lambda r: None))
+        cc.post_process_components()
+        cc.deim()
+    with contextlib.redirect_stdout(buf):
+        cc.is_utmu_orthogonal()
+    mat_e = cc.matrix_properties_test(np.asarray(cc.geom_Pt))
+    sv = cc.test_basesSingVals()
+    rec = ns.snapTensor + 1e-3 * rng.normal(size=ns.snapTensor.shape)
+    np.savez_compressed(os.path.join(OUT, "constraints_diagnostics.npz"), frames=frames, mass=ns.mass, K=np.array(K),
+                        comps=cc.comps.copy(), Pt=np.asarray(cc.geom_Pt, dtype=np.int64), snapTensor=ns.snapTensor.copy(),
+                        mat_e=mat_e, bases_sing_vals=sv, utmu_stdout=np.array(buf.getvalue()), rec=rec,
+                        frobenius=np.float64(constraintsComponents.frobenius_error(ns.snapTensor, rec)),
+                        relative=np.array(constraintsComponents.relative_error_per_component(ns.snapTensor, rec)),
+                        max_pointwise=np.float64(constraintsComponents.max_pointwise_error(ns.snapTensor, rec)))
+    print("wrote constraints_diagnostics: mat_e", mat_e.shape, "utmu:", buf.getvalue().replace("\n", " | "))
+
+
 def _meshmass(work):
     """Element masses derived from a mesh -- the reference's OWN arithmetic (utils/support.py:12-76: `compute_lumped_mass_matrix`,
     `compute_tetMasses`, `compute_edgeMasses`, `compute_triMasses`) and its `.mesh` reader (utils/utils.py:325-389) run on a small
@@ -581,6 +622,8 @@ def main():
                 print("wrote", name, "idx", res["idx"].tolist())
             if only is not None and "meshmass" in only:
                 return _meshmass(work)
+            if only is not None and "diagnostics" in only:
+                return _diagnostics(work)
             if only is not None and "blocksdeim" in only:
                 return _blocksdeim(work)
             if only is not None and "recon" in only:
@@ -612,6 +655,7 @@ def main():
             _podslices(work)
             _withst(work)
             _meshmass(work)
+            _diagnostics(work)
             if np.lib.NumpyVersion(np.__version__) < '2.0.0':
                 _ingest(work)
         finally:

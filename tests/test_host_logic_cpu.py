@@ -272,3 +272,20 @@ def test_bin_readers_round_trip(tmp_path):
     assert St.shape == (rows, cols) and np.allclose(St.toarray(), dense, rtol=0, atol=1e-15)
     with pytest.raises(ValueError):
         read_sparse_matrix(st_file, ".txt")
+
+
+def test_constraints_diagnostics_against_the_reference(capsys):
+    """constraintsComponents' diagnostics (constraintsComponents.py:452-487, 524-570: host NumPy on the downloaded basis) against
+    what the unmodified reference returned / printed on the same basis (oracle/gen_golden.py diagnostics)."""
+    from animsnapbases_amd.constraints import constraintsComponents
+    g = np.load(os.path.join(GOLDEN, "constraints_diagnostics.npz"))
+    cc = constraintsComponents.__new__(constraintsComponents)
+    cc._comps, cc._comps_on_device = g["comps"].copy(), False
+    cc.nonlinearSnapshots = types.SimpleNamespace(mass=g["mass"], constraintsSize=1, dim=3, snapTensor=g["snapTensor"])
+    assert np.allclose(cc.matrix_properties_test(g["Pt"]), g["mat_e"], rtol=1e-9, atol=0)
+    assert np.allclose(cc.test_basesSingVals(), g["bases_sing_vals"], rtol=1e-12, atol=1e-15)
+    cc.is_utmu_orthogonal()
+    assert capsys.readouterr().out == str(g["utmu_stdout"])
+    assert abs(constraintsComponents.frobenius_error(g["snapTensor"], g["rec"]) - float(g["frobenius"])) < 1e-12 * float(g["frobenius"])
+    assert np.allclose(constraintsComponents.relative_error_per_component(g["snapTensor"], g["rec"]), g["relative"], rtol=1e-13)
+    assert abs(constraintsComponents.max_pointwise_error(g["snapTensor"], g["rec"]) - float(g["max_pointwise"])) < 1e-14
