@@ -603,6 +603,57 @@ __global__ __launch_bounds__(256) void k_bt_permute(const double* __restrict__ i
 }
 __global__ void k_add_one(double* __restrict__ p, double v) { *p += v; }
 
+// out (M x 64) = beta out + alpha A (M x Kc, ld lda) Z (Kc x 64): the product of a slab sweep.  The tiled GEMM of asb_dense.hip
+// makes 14 x 1 tiles of it (a 3-way split of the contraction + a finishing launch: ~90 us); here a block of four waves owns 16
+// rows of A, the waves take alternate 16-wide chunks of the contraction (A rows as 128-byte runs, Z from L2), f64 MFMA 16x16x4,
+// and meet through LDS in a fixed order: M / 16 blocks, one launch.  M, Kc multiples of 16.
+typedef double bt_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ A, long long lda, const double* __restrict__ Z,
+                                                     double* __restrict__ out, int M, int Kc, double alpha, double beta) {
+    __shared__ double red[3][4][4][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
+    const int r0 = blockIdx.x * 16;
+    bt_d4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (bt_d4){0.0, 0.0, 0.0, 0.0};
+    const double* arow = A + (long long)(r0 + i) * lda + 4 * g;
+    for (int c = w; c < Kc / 16; c += 4) {
+        const double4 a = *reinterpret_cast<const double4*>(arow + 16 * c);
+        const double* zr = Z + (long long)(16 * c + 4 * g) * GB + i;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, zr[0 * GB + 16 * ct], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, zr[1 * GB + 16 * ct], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, zr[2 * GB + 16 * ct], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, zr[3 * GB + 16 * ct], acc[ct], 0, 0, 0);
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[w - 1][ct][q][l] = acc[ct][q];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double s = ((acc[ct][q] + red[0][ct][q][l]) + red[1][ct][q][l]) + red[2][ct][q][l];
+                double* dst = out + (long long)(r0 + g + 4 * q) * GB + 16 * ct + i;      // C[row 4 q + g][column i] of the 16 x 16 tile
+                *dst = (beta == 0.0 ? 0.0 : beta * *dst) + alpha * s;
+            }
+    }
+    (void)M;
+}
+static int slab_gemm64(asb_ctx* ctx, const double* A, long long lda, const double* Z, double* out, int M, int Kc, double alpha, double beta) {
+    if ((M | Kc) & 15) ASB_FAIL(ctx, ASB_ERR_ARG, "slab_gemm64: %d x %d is not a multiple of 16", M, Kc);
+    hipLaunchKernelGGL(k_slab_gemm64, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta);
+    ASB_CHECK_LAUNCH(ctx);
+    return ASB_OK;
+}
+
 static int bt_factor(asb_ctx* ctx, asb_geo* G, asb_bt& bt, const int* rp, const int* ci, const double* va, const std::vector<int>& ptr,
                      int ground_row, double ground_val) {
     const int ns = (int)G->bt_sz.size();
@@ -739,14 +790,14 @@ static int bt_solve(asb_ctx* ctx, asb_geo* G, const asb_bt& bt, const double* b,
         double* zk = G->bt_z + (size_t)G->bt_off[k] * GB;
         if (k > 0) {
             const int spm = G->bt_sz[k - 1];
-            if ((rc = asb_gemm_nn(ctx, bt.E[k], spm, G->bt_z + (size_t)G->bt_off[k - 1] * GB, GB, zk, GB, sp, GB, spm, -1.0, 1.0))) return rc;
+            if ((rc = slab_gemm64(ctx, bt.E[k], spm, G->bt_z + (size_t)G->bt_off[k - 1] * GB, zk, sp, spm, -1.0, 1.0))) return rc;
         }
-        if ((rc = asb_gemm_nn(ctx, bt.Dinv[k], sp, zk, GB, G->bt_w + (size_t)G->bt_off[k] * GB, GB, sp, GB, sp, 1.0, 0.0))) return rc;
+        if ((rc = slab_gemm64(ctx, bt.Dinv[k], sp, zk, G->bt_w + (size_t)G->bt_off[k] * GB, sp, sp, 1.0, 0.0))) return rc;
     }
     for (int k = ns - 2; k >= 0; --k) {        // backward: w_k -= E_{k+1}^T w_{k+1}
         const int sp = G->bt_sz[k], spn = G->bt_sz[k + 1];
-        if ((rc = asb_gemm_nn(ctx, bt.Et[k + 1], spn, G->bt_w + (size_t)G->bt_off[k + 1] * GB, GB, G->bt_w + (size_t)G->bt_off[k] * GB, GB, sp, GB,
-                              spn, -1.0, 1.0))) return rc;
+        if ((rc = slab_gemm64(ctx, bt.Et[k + 1], spn, G->bt_w + (size_t)G->bt_off[k + 1] * GB, G->bt_w + (size_t)G->bt_off[k] * GB, sp, spn, -1.0,
+                              1.0))) return rc;
     }
     hipLaunchKernelGGL(k_bt_permute, dim3(grid), dim3(256), 0, ctx->stream, G->bt_w, G->bt_pos, n, x, 0);
     ASB_CHECK_LAUNCH(ctx);
