@@ -172,6 +172,9 @@ struct asb_ctx {
     int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
+    double* e_tmp4 = nullptr;              // k_check_tiles: tentative energies per tile (4 x n_loc)
+    double* chk_rec = nullptr;             // its per-tile block records: pmax | psum | colpart (4 x nblk_cap x (1 + 1 + 16))
+    long long* chk_idx = nullptr;
     long long* tile_res = nullptr;         // per tile: columns kept (-1: not reached); [ASB_MAX_SUB]: the chain flag
     int spec_w_rank = 24;                  // ASB_SPEC_W_RANK: blocks ranked below it publish their w ahead of the exchange (0: none)
     int spec_pass = 1;                     // ASB_SPEC_PASS=0: the read's pass is enqueued only once the host knows the sub-panels' counts

@@ -1220,11 +1220,15 @@ __global__ __launch_bounds__(64 * S, OCC) void k_project_l2w(
 // Everything else as in k_project_l2c: 8 waves = (row tile rt) x (frame half sub), X chunks in two register sets used
 // alternately, direct loads / LDS reads by hand so that the compiler counts one kind of pending load.
 // --------------------------------------------------------------------------------------
-template <int NCT, int P, int NTV, int SYNC, int NSB, int MODE, int XD>
+template <int NCT, int P, int NTV, int SYNC, int NSB, int MODE, int XDP>
 __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq,
                                          const double* __restrict__ wn2, const WideArgs& wa, double* __restrict__ comps,
                                          long long comp_stride, long long group0, double* lds, unsigned cnt_byte) {
     constexpr int RT = 4, NTM = 4, NI = 4 * P * NCT, PER = NI / (2 * RT), NS = NSB;
+    // XDP = XD + 10 BPF.  BPF (round 4): the weights of column tile ct + 1 are read from LDS while tile ct's 16 MFMAs issue (a second
+    // pair of operand registers), instead of read-and-wait in front of every tile: one exposed LDS latency per chunk instead of NCT
+    constexpr int XD = XDP % 10;
+    constexpr bool BPF = XDP >= 10;
     // SYNC: 0 = block barrier per stage (two buffers); 1 = arrival counters over all 8 waves; 5 = arrival counters PER FRAME-HALF
     // GROUP of four waves (each group stages the chunks only it reads: a slow wave holds up three others, not seven);
     // 2 / 3 = debugging forms (barrier with three buffers / counters and barrier)
@@ -1340,16 +1344,32 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
         bool issued = false;
         if (NTV > 0 && 2 * j + sub < nchunk) {
             const int cc = 2 * (j - s * P) + sub;
+            double2 bq[2][2];
+            auto b_addr = [&](int ct) {
+                return GRP ? (unsigned)((((s % NS) * 2 + sub) * (STAGE_D / 2) + (((j - s * P) * NCT + ct) * 2) * 128 + l * 2) * 8)
+                           : (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
+            };
+            if (BPF && MODE != 4)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(bq[0][0]), "=&v"(bq[0][1]) : "v"(b_addr(0)));
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 double2 b0, b1;
                 if (MODE == 4) {                                // probe: no LDS reads either
                     b0 = make_double2(cur[0].x, cur[0].y);
                     b1 = make_double2(cur[0].z, cur[0].w);
+                } else if (BPF) {
+                    // tile ct's operands were requested one tile earlier: request ct + 1's, then wait for everything but those
+                    // (LDS reads return in order; the in/out operands keep the MFMAs below behind this wait)
+                    if (ct + 1 < NCT)
+                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\ts_waitcnt lgkmcnt(2)"
+                                     : "=&v"(bq[(ct + 1) & 1][0]), "=&v"(bq[(ct + 1) & 1][1]), "+v"(bq[ct & 1][0]), "+v"(bq[ct & 1][1])
+                                     : "v"(b_addr(ct + 1)));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[ct & 1][0]), "+v"(bq[ct & 1][1]));
+                    b0 = bq[ct & 1][0];
+                    b1 = bq[ct & 1][1];
                 } else {
-                    const unsigned lds_addr = GRP
-                        ? (unsigned)((((s % NS) * 2 + sub) * (STAGE_D / 2) + (((j - s * P) * NCT + ct) * 2) * 128 + l * 2) * 8)
-                        : (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
+                    const unsigned lds_addr = b_addr(ct);
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));
                 }
@@ -1759,6 +1779,7 @@ template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
     if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage (two buffers)
     if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
+    if (variant == 52 && NCT == 4) return launch_l2d<4, 3, 1, 3, 11>(ctx, wa);  // + weights of the next column tile read ahead (BPF)
     if (variant == 51 && NCT == 4) return launch_l2d<4, 3, 5, 3>(ctx, wa);   // arrival counters per frame-half group of four waves (no gain: 1.43)
     // (round 2's variants -- one wave per tile, 32- / 48- / 96- / 128-row tiles, deeper prefetch, weights shared through LDS with a
     // barrier per chunk pair (k_project_l2b) or per stage from a tile queue (k_project_l2c) -- were measured and removed; their
@@ -3186,6 +3207,166 @@ __global__ __launch_bounds__(256) void k_apply_tmp(double* __restrict__ E, const
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) E[v] = Etmp[v];
 }
 
+// ---- the checks of ALL tiles of a read in ONE launch (round 4; k_correct_rows<true> x ntile -> k_check_tiles): with weights
+// orthogonalised before the pass a check is a streaming read of the tile's columns, and what a later tile sees of an earlier one
+// is only the energies it would have left -- so one thread per vertex walks the tiles in order, carrying the energy AS IF every
+// tile so far stood (the chain discards everything behind a tile that did not), and leaves per tile: the tentative energies,
+// the block records and column sums, and the first rejected step (atomicMin into the tile's PanelState).  The arithmetic per
+// tile is k_correct_rows<true>'s, term by term.  k_tiles_decide (one block) is k_tile_decide for all tiles in order;
+// k_apply_tiles adopts the energies and records of the LAST tile that stood in full.  Four tiles: 3 launches instead of 12.
+#define ASB_CHK_TILES 4
+struct CheckOut { double* etmp; double* pmax; long long* pidx; double* psum; double* colpart; };
+__global__ __launch_bounds__(256, 2) void k_check_tiles(const double* __restrict__ comps, long long comp_stride, long long n_vert, WideArgs wa,
+                                                     int ntile, const double* __restrict__ wn2t3, const double* __restrict__ E,
+                                                     const double* __restrict__ Ecl, const double* __restrict__ E2,
+                                                     const double* __restrict__ sc, PanelState* __restrict__ st, CheckOut out) {
+    __shared__ double sh[4 * 16];
+    __shared__ double sh_m[4];
+    __shared__ long long sh_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int viol[ASB_CHK_TILES];
+    double bmax[ASB_CHK_TILES], bsum[ASB_CHK_TILES], csum[ASB_CHK_TILES][16];
+    long long bidx[ASB_CHK_TILES];
+#pragma unroll
+    for (int ct = 0; ct < ASB_CHK_TILES; ++ct) {
+        viol[ct] = ASB_PANEL_COLS; bmax[ct] = -1.0; bsum[ct] = 0.0; bidx[ct] = 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) csum[ct][t] = 0.0;
+    }
+    for (long long v = (long long)blockIdx.x * 256 + tid; v < n_vert; v += (long long)gridDim.x * 256) {
+        double e = E[v];
+        const double es = Ecl ? Ecl[v] : e;
+        const bool outside = !(es > sc[SC_TAU]) && !(E2 && in_guess(es, E2[v], sc)) && !in_div(es, v, sc);
+#pragma unroll
+        for (int ct = 0; ct < ASB_CHK_TILES; ++ct) {
+            if (ct >= ntile) break;
+            const int ncols = wa.nc[ct];
+            const double* base = comps + wa.kb[ct] * comp_stride + 3 * v;
+            const PanelState* sp = st + ct;
+            const double margin = sp->margin;
+            const int proven = (int)sp->proven;
+            const double e_start = e;
+            double loss = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                // (eight columns' loads in flight at a time: 24 doubles per thread)
+                double c[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 8 * h + u;
+                    const bool on = t < ncols;
+                    c[u][0] = on ? base[(long long)t * comp_stride] : 0.0;
+                    c[u][1] = on ? base[(long long)t * comp_stride + 1] : 0.0;
+                    c[u][2] = on ? base[(long long)t * comp_stride + 2] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 8 * h + u;
+                    if (t < ncols) {
+                        if (outside && t >= proven && t < viol[ct] && !(sp->e_win[t] > e + margin)) viol[ct] = t;
+                        const double q = ((c[u][0] * c[u][0] + c[u][1] * c[u][1]) + c[u][2] * c[u][2]) * wn2t3[16 * ct + t];
+                        e -= q;
+                        loss += q;
+                        csum[ct][t] += q;
+                    }
+                }
+            }
+            double en = e_start - loss;                  // exactly k_commit_energy's arithmetic
+            if (en < 0.0) en = 0.0;
+            out.etmp[(long long)ct * n_vert + v] = en;
+            bsum[ct] += en;
+            if (am_better(en, v, bmax[ct], bidx[ct])) { bmax[ct] = en; bidx[ct] = v; }
+            e = en;                                      // what the next tile reads once this one has been adopted
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < ASB_CHK_TILES; ++ct) {
+        if (ct >= ntile) break;                          // (uniform)
+        int vl = viol[ct];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ov = __shfl_xor(vl, o, 64);
+            vl = ov < vl ? ov : vl;
+        }
+        if (lane == 0 && vl < ASB_PANEL_COLS) atomicMin(reinterpret_cast<long long*>(&st[ct].spec_ok), (long long)vl);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) csum[ct][t] = wave_sum(csum[ct][t]);
+        double bs = wave_sum(bsum[ct]), bm = bmax[ct];
+        long long bi = bidx[ct];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(bm, o, 64);
+            const long long oi = __shfl_xor(bi, o, 64);
+            if (am_better(om, oi, bm, bi)) { bm = om; bi = oi; }
+        }
+        __syncthreads();                                 // the previous tile's reads of sh are done
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sh[wv * 16 + t] = csum[ct][t];
+            sh_m[wv] = bm; sh_i[wv] = bi;
+        }
+        // (the block's sum of energies goes through the same LDS slots one tile later: a fifth array would do as well)
+        __syncthreads();
+        if (tid < 16)
+            out.colpart[((long long)ct * gridDim.x + blockIdx.x) * 16 + tid] = ((sh[tid] + sh[16 + tid]) + sh[32 + tid]) + sh[48 + tid];
+        if (tid == 64) {
+            double m = sh_m[0];
+            long long ix = sh_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (am_better(sh_m[w], sh_i[w], m, ix)) { m = sh_m[w]; ix = sh_i[w]; }
+            out.pmax[(long long)ct * gridDim.x + blockIdx.x] = m;
+            out.pidx[(long long)ct * gridDim.x + blockIdx.x] = ix;
+        }
+        __syncthreads();
+        if (lane == 0) sh[wv] = bs;
+        __syncthreads();
+        if (tid == 0) out.psum[(long long)ct * gridDim.x + blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    }
+}
+// res[ct] = columns of tile ct kept (-1: behind a tile that did not stand in full), res[ASB_MAX_SUB] = every tile stood in full,
+// res[ASB_MAX_SUB + 1] = L = tiles that stood in full from the front; column sums of those tiles into scal
+__global__ __launch_bounds__(1024) void k_tiles_decide(const double* __restrict__ colpart, int nblk, int ntile, WideArgs wa,
+                                                       double* __restrict__ scal, PanelState* __restrict__ st, long long* __restrict__ res) {
+    __shared__ int full_sh;
+    if (threadIdx.x == 0) {
+        bool chain = true;
+        int L = 0;
+        for (int ct = 0; ct < ntile; ++ct) {
+            const int ran = (int)st[ct].committed, ok = (int)(st[ct].spec_ok < st[ct].committed ? st[ct].spec_ok : st[ct].committed);
+            const bool full = chain && ok == ran;
+            res[ct] = chain ? ok : -1;
+            st[ct].committed = chain ? ok : 0;
+            if (full) L = ct + 1;
+            chain = full;
+        }
+        res[ASB_MAX_SUB] = chain ? 1 : 0;
+        res[ASB_MAX_SUB + 1] = L;
+        full_sh = L;
+    }
+    __syncthreads();
+    const int L = full_sh, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int p = w; p < L * 16; p += 16) {
+        const int ct = p >> 4, t = p & 15;
+        if (t >= wa.nc[ct]) continue;
+        double v = 0.0;
+        for (int b = lane; b < nblk; b += 64) v += colpart[((long long)ct * nblk + b) * 16 + t];
+        v = wave_sum(v);
+        if (lane == 0) scal[(wa.kb[ct] + t) * 4 + 3] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_apply_tiles(double* __restrict__ E, long long n, int nblk, CheckOut in, const long long* __restrict__ res,
+                                                     double* __restrict__ pmax, long long* __restrict__ pidx, double* __restrict__ psum) {
+    const int L = (int)res[ASB_MAX_SUB + 1];
+    if (L <= 0) return;
+    const double* src = in.etmp + (long long)(L - 1) * n;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) E[v] = src[v];
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < nblk; b += 256) {
+            pmax[b] = in.pmax[(long long)(L - 1) * nblk + b];
+            pidx[b] = in.pidx[(long long)(L - 1) * nblk + b];
+            psum[b] = in.psum[(long long)(L - 1) * nblk + b];
+        }
+}
+
 static int spec_tile_finish(asb_ctx* ctx, int ct, long long kb, int nc, PanelState* st, int64_t* kept) {
     const double* Wt = ctx->Wt3 + (size_t)ct * ctx->Fp * 16;
     const int pre = (ctx->pre_orth && ctx->correct_rows) ? 1 : 0;
@@ -3404,7 +3585,7 @@ static int multi_chain_run(asb_ctx* ctx, long long k, long long k1, int nsub_max
 static int tiles_enqueue(asb_ctx* ctx, int ntile, const long long* kb, const int* nc, PanelState* const* st, int* rgrid_out, int* cgrid_out) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->e_tmp, (size_t)ctx->n_loc))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 2))) return rc;
     long long cwr = (ctx->n_loc + 63) / 64;
     // (two blocks per CU, grid-strided: the one-block k_tile_decide sums a partial per block and column)
     static const int bpc = getenv("ASB_CHECK_BLOCKS_PER_CU") ? atoi(getenv("ASB_CHECK_BLOCKS_PER_CU")) : 2;
@@ -3412,6 +3593,31 @@ static int tiles_enqueue(asb_ctx* ctx, int ntile, const long long* kb, const int
     const int rgrid = (int)(cwr < rcap ? cwr : rcap);
     long long cw = (ctx->n_loc + 255) / 256;
     const int cgrid = (int)(cw < ctx->nblk_cap ? cw : ctx->nblk_cap);
+    static const int fused = getenv("ASB_CHECK_FUSED") ? atoi(getenv("ASB_CHECK_FUSED")) : 1;
+    if (fused && ntile <= ASB_CHK_TILES) {
+        long long cb = (ctx->n_loc + 255) / 256;
+        const int fgrid = (int)(cb < ctx->nblk_cap ? cb : ctx->nblk_cap);
+        if ((rc = asb_alloc(ctx, &ctx->e_tmp4, (size_t)ASB_CHK_TILES * ctx->n_loc))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->chk_rec, (size_t)ASB_CHK_TILES * ctx->nblk_cap * 18))) return rc;
+        if ((rc = asb_alloc(ctx, &ctx->chk_idx, (size_t)ASB_CHK_TILES * ctx->nblk_cap))) return rc;
+        CheckOut co{ctx->e_tmp4, ctx->chk_rec, ctx->chk_idx, ctx->chk_rec + (size_t)ASB_CHK_TILES * ctx->nblk_cap,
+                    ctx->chk_rec + (size_t)2 * ASB_CHK_TILES * ctx->nblk_cap};
+        WideArgs wa{};
+        for (int ct = 0; ct < ntile; ++ct) {
+            wa.kb[ct] = kb[ct];
+            wa.nc[ct] = nc[ct];
+            if (st[ct] != st[0] + ct) ASB_FAIL(ctx, ASB_ERR_ARG, "tiles_enqueue: the tiles' states are not contiguous");
+        }
+        hipLaunchKernelGGL(k_check_tiles, dim3(fgrid), dim3(256), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc), (long long)ctx->n_loc,
+                           wa, ntile, ctx->wn2t3, ctx->energy, ctx->e_class, ctx->sel_e2, ctx->scalar_dev, st[0], co);
+        hipLaunchKernelGGL(k_tiles_decide, dim3(1), dim3(1024), 0, ctx->stream, co.colpart, fgrid, ntile, wa, ctx->scal, st[0], ctx->tile_res);
+        hipLaunchKernelGGL(k_apply_tiles, dim3(cgrid), dim3(256), 0, ctx->stream, ctx->energy, (long long)ctx->n_loc, fgrid, co, ctx->tile_res,
+                           ctx->pmax, ctx->pidx, ctx->psum);
+        ASB_CHECK_LAUNCH(ctx);
+        *rgrid_out = fgrid;
+        *cgrid_out = cgrid;
+        return ASB_OK;
+    }
     for (int ct = 0; ct < ntile; ++ct) {
         hipLaunchKernelGGL(k_correct_rows<true>, dim3(rgrid), dim3(192), 0, ctx->stream, ctx->comps, (long long)(3 * ctx->n_loc),
                            (long long)ctx->n_loc, (int)kb[ct], nc[ct], ctx->gram_s, ctx->wn2t3 + 16 * ct, ctx->energy, ctx->pmax, ctx->pidx,
@@ -3809,7 +4015,7 @@ extern "C" int asb_panel_read_run(asb_ctx* ctx, int64_t k0, int64_t k1, int nsub
     if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->pstate2, (size_t)ASB_MAX_SUB))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->e_class, (size_t)ctx->n_loc))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 1))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_res, (size_t)ASB_MAX_SUB + 2))) return rc;
     ASB_HIP(ctx, hipMemcpyAsync(ctx->e_class, ctx->energy, (size_t)ctx->n_loc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     const int save_budget = ctx->spec_budget;
     int save_sub[8];

@@ -67,7 +67,7 @@ def cpu_baseline_c4(F, N, K, budget_s=18.0):
     streaming pass over the F x N x 3 residual) and the loop is linear in K.  Median of 3 runs of the sample."""
     from oracle import asb_oracle as orc
     cores, model = _cpu_info()
-    n_s = max(256, min(N, N // 10))
+    n_s = max(256, min(N, N // 4))          # (a tenth of the vertices under-rated the host by 1.46x: profiles/r04_cpu_full_config4.json)
     rng = np.random.default_rng(7)
     X = rng.uniform(-1, 1, size=(F, n_s, 3))
     X = orc.prepare_snapshots(X, "first", True)["snapTensor"]
@@ -77,7 +77,14 @@ def cpu_baseline_c4(F, N, K, budget_s=18.0):
     k_s = int(max(2, min(K, budget_s / 3.0 / max(t_one, 1e-3))))
     med, ts = _median3(lambda: orc.extract_k_components(X, k_s))
     per_comp_full = med / k_s * (N / n_s)
-    return dict(value=F / (per_comp_full * K), unit="snapshots/s", cores=cores, kind="port", cpu_model=model,
+    anchor = None
+    try:
+        a = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_full_config4.json")))
+        anchor = {"snapshots_per_s": a["snapshots_per_s"], "total_s": a["total_s"], "cores": a["cores"], "cpu_model": a["cpu_model"],
+                  "file": "profiles/r04_cpu_full_config4.json", "note": "ONE full un-sampled run of the same oracle on config 4 (recorded, not this run)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return dict(value=F / (per_comp_full * K), unit="snapshots/s", cores=cores, kind="port", cpu_model=model, full_run_recorded=anchor,
                 runs_s=[round(t, 3) for t in ts],
                 sample="NumPy oracle (oracle/asb_oracle.py, OpenBLAS threads = all %d host cores) on %d of %d vertices x %d "
                        "frames, %d of %d components; median of 3 runs (%.2f s); scaled linearly in N and K"
