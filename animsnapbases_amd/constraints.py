@@ -732,7 +732,7 @@ class constraintsComponents:  # Components == bases
             eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))
             self._comps_on_device = True
         if p.constProj_standarize:
-            eng.components_post(True, ns.pre_scale_factor, None)
+            eng.components_post(True, ns.pre_scale_factor, None, download=False)
             eng.snapshots_affine(1.0 / ns.pre_scale_factor, True, None)        # also restore the snapshots (:424-428)
             ns._snapTensor = None
         if p.constProj_orthogonal:
@@ -744,7 +744,7 @@ class constraintsComponents:  # Components == bases
                 eng.qr_apply(Gbuf.data_ptr() if Gbuf is not None else None)
         if p.constProj_massWeight:
             assert ns.frames_rows == ns.invMassL.shape[0]
-            eng.components_post(False, 1.0, ns.invMassL[v0:v0 + n_loc])
+            eng.components_post(False, 1.0, ns.invMassL[v0:v0 + n_loc], download=False)
             eng.snapshots_affine(1.0, False, ns.invMassL[v0:v0 + n_loc])
             ns._snapTensor = None
         self._comps = None

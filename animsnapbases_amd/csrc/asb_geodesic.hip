@@ -608,8 +608,11 @@ __global__ void k_add_one(double* __restrict__ p, double v) { *p += v; }
 // rows of A, the waves take alternate 16-wide chunks of the contraction (A rows as 128-byte runs, Z from L2), f64 MFMA 16x16x4,
 // and meet through LDS in a fixed order: M / 16 blocks, one launch.  M, Kc multiples of 16.
 typedef double bt_d4 __attribute__((ext_vector_type(4)));
+template <int NCT>
 __global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ A, long long lda, const double* __restrict__ Z,
                                                      double* __restrict__ out, int M, int Kc, double alpha, double beta) {
+    constexpr int nct = NCT;
+    // nct: column tiles of 16 that carry fields (a batch of nsrc <= 64 sources fills the first ceil(nsrc / 16)); the rest is left as it is
     __shared__ double red[3][4][4][64];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
     const int r0 = blockIdx.x * 16;
@@ -622,6 +625,7 @@ __global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ 
         const double* zr = Z + (long long)(16 * c + 4 * g) * GB + i;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
+            if (ct >= nct) break;
             acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, zr[0 * GB + 16 * ct], acc[ct], 0, 0, 0);
             acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, zr[1 * GB + 16 * ct], acc[ct], 0, 0, 0);
             acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, zr[2 * GB + 16 * ct], acc[ct], 0, 0, 0);
@@ -632,7 +636,8 @@ __global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[w - 1][ct][q][l] = acc[ct][q];
+            for (int q = 0; q < 4; ++q)
+                if (ct < nct) red[w - 1][ct][q][l] = acc[ct][q];
     }
     __syncthreads();
     if (w == 0) {
@@ -640,6 +645,7 @@ __global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ 
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (ct >= nct) continue;
                 const double s = ((acc[ct][q] + red[0][ct][q][l]) + red[1][ct][q][l]) + red[2][ct][q][l];
                 double* dst = out + (long long)(r0 + g + 4 * q) * GB + 16 * ct + i;      // C[row 4 q + g][column i] of the 16 x 16 tile
                 *dst = (beta == 0.0 ? 0.0 : beta * *dst) + alpha * s;
@@ -647,9 +653,15 @@ __global__ __launch_bounds__(256) void k_slab_gemm64(const double* __restrict__ 
     }
     (void)M;
 }
-static int slab_gemm64(asb_ctx* ctx, const double* A, long long lda, const double* Z, double* out, int M, int Kc, double alpha, double beta) {
+static int slab_gemm64(asb_ctx* ctx, const double* A, long long lda, const double* Z, double* out, int M, int Kc, double alpha, double beta,
+                       int nct = 4) {
     if ((M | Kc) & 15) ASB_FAIL(ctx, ASB_ERR_ARG, "slab_gemm64: %d x %d is not a multiple of 16", M, Kc);
-    hipLaunchKernelGGL(k_slab_gemm64, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta);
+    switch (nct < 1 ? 1 : (nct > 4 ? 4 : nct)) {
+        case 1: hipLaunchKernelGGL(k_slab_gemm64<1>, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta); break;
+        case 2: hipLaunchKernelGGL(k_slab_gemm64<2>, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta); break;
+        case 3: hipLaunchKernelGGL(k_slab_gemm64<3>, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta); break;
+        default: hipLaunchKernelGGL(k_slab_gemm64<4>, dim3(M / 16), dim3(256), 0, ctx->stream, A, lda, Z, out, M, Kc, alpha, beta); break;
+    }
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
 }
@@ -778,7 +790,7 @@ extern "C" int asb_geodesic_bt_setup(asb_ctx* ctx, int nslab, const int* slab_pt
 }
 
 // x (n x 64, vertex order) <- A^-1 b for a factorised matrix
-static int bt_solve(asb_ctx* ctx, asb_geo* G, const asb_bt& bt, const double* b, double* x) {
+static int bt_solve(asb_ctx* ctx, asb_geo* G, const asb_bt& bt, const double* b, double* x, int nct) {
     const int ns = (int)G->bt_sz.size(), n = G->n;
     int rc;
     const int grid = (n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048;
@@ -790,14 +802,14 @@ static int bt_solve(asb_ctx* ctx, asb_geo* G, const asb_bt& bt, const double* b,
         double* zk = G->bt_z + (size_t)G->bt_off[k] * GB;
         if (k > 0) {
             const int spm = G->bt_sz[k - 1];
-            if ((rc = slab_gemm64(ctx, bt.E[k], spm, G->bt_z + (size_t)G->bt_off[k - 1] * GB, zk, sp, spm, -1.0, 1.0))) return rc;
+            if ((rc = slab_gemm64(ctx, bt.E[k], spm, G->bt_z + (size_t)G->bt_off[k - 1] * GB, zk, sp, spm, -1.0, 1.0, nct))) return rc;
         }
-        if ((rc = slab_gemm64(ctx, bt.Dinv[k], sp, zk, G->bt_w + (size_t)G->bt_off[k] * GB, sp, sp, 1.0, 0.0))) return rc;
+        if ((rc = slab_gemm64(ctx, bt.Dinv[k], sp, zk, G->bt_w + (size_t)G->bt_off[k] * GB, sp, sp, 1.0, 0.0, nct))) return rc;
     }
     for (int k = ns - 2; k >= 0; --k) {        // backward: w_k -= E_{k+1}^T w_{k+1}
         const int sp = G->bt_sz[k], spn = G->bt_sz[k + 1];
         if ((rc = slab_gemm64(ctx, bt.Et[k + 1], spn, G->bt_w + (size_t)G->bt_off[k + 1] * GB, G->bt_w + (size_t)G->bt_off[k] * GB, sp, spn, -1.0,
-                              1.0))) return rc;
+                              1.0, nct))) return rc;
     }
     hipLaunchKernelGGL(k_bt_permute, dim3(grid), dim3(256), 0, ctx->stream, G->bt_w, G->bt_pos, n, x, 0);
     ASB_CHECK_LAUNCH(ctx);
@@ -817,7 +829,7 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     } else if (G->bt) {
         ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
-        if ((rc = bt_solve(ctx, G, G->Hbt, G->b, G->x))) return rc;
+        if ((rc = bt_solve(ctx, G, G->Hbt, G->b, G->x, (nsrc + 15) / 16))) return rc;
     } else {
         ASB_HIP(ctx, hipMemsetAsync(G->b, 0, (size_t)n * GB * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_set_sources, dim3(1), dim3(GB), 0, ctx->stream, G->b, src_dev, nsrc);
@@ -835,11 +847,12 @@ static int geodesic_solve_dev(asb_ctx* ctx, const long long* src_dev, int nsrc, 
     ASB_CHECK_LAUNCH(ctx);
     // Poisson step: L phi = div  <=>  (-L) phi = -div ; solve (-L) y = div and negate through the min shift (phi = -y)
     if (G->dense) {        // y = (-L + gamma/n 1 1^T)^-1 div : one (np x np) by (np x 64) product
-        if ((rc = asb_gemm_nn(ctx, G->Pinv, G->np, G->b, GB, G->x, GB, G->np, GB, G->np, 1.0, 0.0))) return rc;
+        // (16 rows of the inverse per block, 925 blocks at 14 800 vertices: the 128 x 128 tiles of asb_gemm_nn made 116 blocks of it -- 0.98 ms)
+        if ((rc = slab_gemm64(ctx, G->Pinv, G->np, G->b, G->x, G->np, G->np, 1.0, 0.0, (nsrc + 15) / 16))) return rc;
     } else if (G->bt) {    // the grounded Laplacian, factorised: an exact solution of the singular system for the consistent div X
         if ((rc = asb_alloc(ctx, &G->z, (size_t)n * GB))) return rc;
         ASB_HIP(ctx, hipMemcpyAsync(G->z, G->b, (size_t)n * GB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        if ((rc = bt_solve(ctx, G, G->Pbt, G->z, G->x))) return rc;
+        if ((rc = bt_solve(ctx, G, G->Pbt, G->z, G->x, (nsrc + 15) / 16))) return rc;
     } else {
         hipLaunchKernelGGL(k_remove_mean, dim3(GB), dim3(256), 0, ctx->stream, G->b, n);
         if ((rc = cg64(ctx, G, G->lap, G->dlap, G->b, G->x, nsrc, tol, 8000, &it2, G->coarse ? G->AcP : nullptr))) return rc;

@@ -1344,35 +1344,11 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
         bool issued = false;
         if (NTV > 0 && 2 * j + sub < nchunk) {
             const int cc = 2 * (j - s * P) + sub;
-            double2 bq[2][2];
             auto b_addr = [&](int ct) {
                 return GRP ? (unsigned)((((s % NS) * 2 + sub) * (STAGE_D / 2) + (((j - s * P) * NCT + ct) * 2) * 128 + l * 2) * 8)
                            : (unsigned)(((s % NS) * STAGE_D + ((cc * NCT + ct) * 2) * 128 + l * 2) * 8);
             };
-            if (BPF && MODE != 4)
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(bq[0][0]), "=&v"(bq[0][1]) : "v"(b_addr(0)));
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                double2 b0, b1;
-                if (MODE == 4) {                                // probe: no LDS reads either
-                    b0 = make_double2(cur[0].x, cur[0].y);
-                    b1 = make_double2(cur[0].z, cur[0].w);
-                } else if (BPF) {
-                    // tile ct's operands were requested one tile earlier: request ct + 1's, then wait for everything but those
-                    // (LDS reads return in order; the in/out operands keep the MFMAs below behind this wait)
-                    if (ct + 1 < NCT)
-                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\ts_waitcnt lgkmcnt(2)"
-                                     : "=&v"(bq[(ct + 1) & 1][0]), "=&v"(bq[(ct + 1) & 1][1]), "+v"(bq[ct & 1][0]), "+v"(bq[ct & 1][1])
-                                     : "v"(b_addr(ct + 1)));
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[ct & 1][0]), "+v"(bq[ct & 1][1]));
-                    b0 = bq[ct & 1][0];
-                    b1 = bq[ct & 1][1];
-                } else {
-                    const unsigned lds_addr = b_addr(ct);
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));
-                }
+            auto mfma16 = [&](int ct, const auto& b0, const auto& b1) {
 #pragma unroll
                 for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].x, b0.x, acc[m][ct], 0, 0, 0);
 #pragma unroll
@@ -1383,6 +1359,40 @@ __device__ __forceinline__ void l2d_tile(const double* __restrict__ X, long long
                 for (int m = 0; m < NTA; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[m].w, b1.y, acc[m][ct], 0, 0, 0);
                 // the next stage's direct loads go out BEHIND the wait for the current X chunk (the first MFMAs above)
                 if (ct == 0 && j == s * P && s + DIST < nstage) { issue_stage(s + DIST); issued = true; }
+            };
+            if (BPF && MODE != 4) {
+                // tile ct's operands are requested one tile earlier: request ct + 1's, then wait for everything but those (LDS
+                // reads return in order; the in/out operands keep the tile's MFMAs behind the wait) -- two operand pairs, A and B
+                typedef double d2v __attribute__((ext_vector_type(2)));      // (a native vector: in/out asm operands of a struct type are not supported)
+                d2v pa0, pa1, pb0, pb1;
+                auto ahead = [&](int ct, d2v& n0, d2v& n1, d2v& c0, d2v& c1) {
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\ts_waitcnt lgkmcnt(2)"
+                                 : "=&v"(n0), "=&v"(n1), "+v"(c0), "+v"(c1) : "v"(b_addr(ct + 1)));
+                };
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(pa0), "=&v"(pa1) : "v"(b_addr(0)));
+                static_assert(!BPF || NCT == 4, "operands read ahead: written out for four column tiles");
+                ahead(0, pb0, pb1, pa0, pa1);
+                mfma16(0, pa0, pa1);
+                ahead(1, pa0, pa1, pb0, pb1);
+                mfma16(1, pb0, pb1);
+                ahead(2, pb0, pb1, pa0, pa1);
+                mfma16(2, pa0, pa1);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb0), "+v"(pb1));
+                mfma16(3, pb0, pb1);
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    double2 b0, b1;
+                    if (MODE == 4) {                            // probe: no LDS reads either
+                        b0 = make_double2(cur[0].x, cur[0].y);
+                        b1 = make_double2(cur[0].z, cur[0].w);
+                    } else {
+                        const unsigned lds_addr = b_addr(ct);
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(b0), "=&v"(b1) : "v"(lds_addr));
+                    }
+                    mfma16(ct, b0, b1);
+                }
             }
         }
         if (!issued && j == s * P && s + DIST < nstage) issue_stage(s + DIST);

@@ -783,8 +783,10 @@ class HipEngine(object):
     def orth_refine(self, G_dev_ptr=None):
         self._ck(self.lib.asb_orth_refine(self.h, ctypes.c_void_p(G_dev_ptr) if G_dev_ptr else None))
 
-    def components_post(self, unscale, pre_scale_factor, invMassL_loc=None):
-        out = np.empty((self.K, self.n_loc, 3))
+    def components_post(self, unscale, pre_scale_factor, invMassL_loc=None, download=True):
+        """``download=False``: the basis stays on the device (a later step changes or reads it there): no 8 K n_loc 3 bytes
+        through a pageable buffer (config 5: 307 MB, 25 ms)."""
+        out = np.empty((self.K, self.n_loc, 3)) if download else None
         if invMassL_loc is not None:
             invMassL_loc = np.ascontiguousarray(invMassL_loc, dtype=np.float64)
         self._ck(self.lib.asb_components_post(self.h, int(bool(unscale)), float(pre_scale_factor), ptr(invMassL_loc),

@@ -335,7 +335,8 @@ class posComponents:  # Components == bases
                 raise ValueError("no components: run compute_components_store_singvalues first")
             eng.components_upload(np.ascontiguousarray(self._comps[:, v0:v0 + n_loc, :]))      # caller-assigned comps
             self._comps_on_device = True
-        loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None)
+        later = bool(self.param.q_orthogonal or self.param.q_massWeight)       # (the basis is downloaded once, behind the last step)
+        loc = eng.components_post(self.param.q_standarize, snaps.pre_scale_factor, None, download=not later)
         if self.param.q_orthogonal:
             K = self.numComp
             # Gram -> K x K Jacobi eigen-solver -> U = A V S^-1, all on the device (any K)

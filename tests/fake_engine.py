@@ -131,14 +131,14 @@ class FakeEngine(object):
     def download_residual(self):
         return self.R.copy()
 
-    def components_post(self, unscale, psf, invMassL_loc=None):
+    def components_post(self, unscale, psf, invMassL_loc=None, download=True):
         c = self.C.copy()
         if unscale:
             c = c / psf + self.mean[None]
         if invMassL_loc is not None:
             c = c * invMassL_loc[None, :, None]
         self.C = c
-        return c.copy()
+        return c.copy() if download else None
 
     def deflate_stats(self):
         return dict(panels=0, refreshes=0)
