@@ -192,7 +192,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, i
 // decomposition, so that even the 128 MB start matrix gives every SIMD several waves and the sweep runs at the rate of the
 // Infinity Cache instead of one wave's latency chain per four rows.
 #define TD_CW 1024
-template <int R>
+template <int R, int CU = 2>
 __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n, int r1, int update,
                                                   const double* __restrict__ vcur, const double* __restrict__ w,
                                                   const double* __restrict__ vnext, const double* __restrict__ tau_next,
@@ -214,28 +214,32 @@ __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n
             acc[q] = 0.0;
             rowp[q] = A + (long long)i * n;
         }
-        for (int c = c_lo + lane; c < c_hi; c += 128) {       // two column positions per lane in flight
-            const int c2 = c + 64;
-            const bool on2 = c2 < c_hi;
-            const double vc = update ? vcur[c] : 0.0, wc = update ? w[c] : 0.0, vn = vnext[c];
-            const double vc2 = (update && on2) ? vcur[c2] : 0.0, wc2 = (update && on2) ? w[c2] : 0.0, vn2 = on2 ? vnext[c2] : 0.0;
-            double a[R], b[R];
+        for (int c = c_lo + lane; c < c_hi; c += 64 * CU) {   // CU column positions per lane in flight (x R rows)
+            double vc[CU], wc[CU], vn[CU], a[CU][R];
+            bool on[CU];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                a[q] = rowp[q][c];
-                b[q] = on2 ? rowp[q][c2] : 0.0;
+            for (int u = 0; u < CU; ++u) {
+                const int cu = c + 64 * u;
+                on[u] = cu < c_hi;
+                vc[u] = (update && on[u]) ? vcur[cu] : 0.0;
+                wc[u] = (update && on[u]) ? w[cu] : 0.0;
+                vn[u] = on[u] ? vnext[cu] : 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) a[u][q] = on[u] ? rowp[q][cu] : 0.0;
             }
+            // (the sums keep round 3's order for CU = 2: a[0] vn[0] + a[1] vn[1] per step)
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                if (update) {
-                    a[q] -= vi[q] * wc + wi[q] * vc;
-                    b[q] -= vi[q] * wc2 + wi[q] * vc2;
-                    if (i0 + q < n) {
-                        rowp[q][c] = a[q];
-                        if (on2) rowp[q][c2] = b[q];
+                double s = 0.0;
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    if (update) {
+                        a[u][q] -= vi[q] * wc[u] + wi[q] * vc[u];
+                        if (i0 + q < n && on[u]) rowp[q][c + 64 * u] = a[u][q];
                     }
+                    s = u == 0 ? a[u][q] * vn[u] : s + a[u][q] * vn[u];
                 }
-                acc[q] += a[q] * vn + b[q] * vn2;
+                acc[q] += s;
             }
         }
 #pragma unroll
@@ -337,6 +341,11 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
             long long gridl = (items + 3) / 4;
             int grid = (int)(gridl > 4096 ? 4096 : gridl);
             if (grid < 1) grid = 1;
+            static const int tdv = getenv("ASB_TD_VARIANT") ? atoi(getenv("ASB_TD_VARIANT")) : 1;
+            if (tdv == 1)          // four column positions per lane in flight (round 4: POD 237 -> 233 ms on one box; 0: two)
+                hipLaunchKernelGGL((k_td_update<R, 4>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
+                                   tau + (j + 1), p, nch);
+            else
             hipLaunchKernelGGL((k_td_update<R>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
                                tau + (j + 1), p, nch);
             nch_prev = nch;
