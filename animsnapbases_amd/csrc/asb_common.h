@@ -251,6 +251,8 @@ struct asb_ctx {
     int* la_status = nullptr;
     double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
+    double* td_panel = nullptr;                   // k_td_panel: x | z partials | V | W | p, q
+    unsigned long long* td_rec = nullptr;         // its exchange words (ring of three) and the abort flag
     double* td_ppart = nullptr;                   // partial mat-vec vectors of the tridiagonalisation (one per column chunk)
     double *td_work = nullptr, *td_z = nullptr;   // asb_eig.hip: Householder work vectors / tau / d / e; Z and Q Z
     int64_t td_n = 0;

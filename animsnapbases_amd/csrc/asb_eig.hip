@@ -24,13 +24,15 @@
 __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n, int j, const double* __restrict__ p, int nch,
                                                   const double* __restrict__ vcur, double* __restrict__ w,
                                                   double* __restrict__ vnext, double* __restrict__ xbuf,
-                                                  double* __restrict__ tau, double* __restrict__ d, double* __restrict__ e) {
+                                                  double* __restrict__ tau, double* __restrict__ d, double* __restrict__ e, int fresh = 0) {
+    // fresh: the matrix is explicitly up to date from row j + 1 on (behind the panel kernels): no reflector j to finish
     __shared__ double sh[TD_T / 64 * 2];
     __shared__ double bc[4];
     const int tid = threadIdx.x;
+    const bool have = j >= 0 && !fresh;
     const int r0 = j + 1;                       // first row of the current trailing block
     double wfirst = 0.0;
-    if (j >= 0) {
+    if (have) {
         double acc[1] = {0.0};
         for (int r = r0 + tid; r < n; r += TD_T) {
             double pr = p[r];
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
     double acc2[1] = {0.0};
     for (int c = r0 + tid; c < n; c += TD_T) {
         double x = row[c];
-        if (j >= 0) x -= w[c] + wfirst * vcur[c];
+        if (have) x -= w[c] + wfirst * vcur[c];
         xbuf[c] = x;
         if (c == r0) bc[1] = x;                 // the new diagonal entry
         if (c == r0 + 1) bc[2] = x;             // alpha
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small(double* __restrict__ A, int n
             tau[r0] = 0.0;
             // d[n-1] = A[n-1][n-1] - 2 v[n-1] w[n-1]
             double last = A[(long long)(n - 1) * n + (n - 1)];
-            if (j >= 0) last -= 2.0 * vcur[n - 1] * w[n - 1];
+            if (have) last -= 2.0 * vcur[n - 1] * w[n - 1];
             d[n - 1] = last;
         }
         return;
@@ -100,10 +102,11 @@ template <int EPT>
 __global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, int n, int j, const double* __restrict__ p, int nch,
                                                       const double* __restrict__ vcur, double* __restrict__ w,
                                                       double* __restrict__ vnext, double* __restrict__ tau, double* __restrict__ d,
-                                                      double* __restrict__ e) {
+                                                      double* __restrict__ e, int fresh = 0) {
     __shared__ double sh[TD_T / 64 * 2];
     __shared__ double bc[4];
     const int tid = threadIdx.x;
+    const bool have = j >= 0 && !fresh;
     const int r0 = j + 1;
     const double* row = A + (long long)r0 * n;
     double pr[EPT], vc[EPT], x[EPT];
@@ -112,16 +115,16 @@ __global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, i
         const int r = r0 + tid + q * TD_T;
         const bool on = r < n;
         x[q] = on ? row[r] : 0.0;
-        vc[q] = (on && j >= 0) ? vcur[r] : 0.0;
+        vc[q] = (on && have) ? vcur[r] : 0.0;
         double s = 0.0;
-        if (on && j >= 0) {
+        if (on && have) {
             s = p[r];
             for (int c = 1; c < nch; ++c) s += p[(long long)c * n + r];
         }
         pr[q] = s;
     }
     double wfirst = 0.0;
-    if (j >= 0) {
+    if (have) {
         double acc[1] = {0.0};
 #pragma unroll
         for (int q = 0; q < EPT; ++q) acc[0] += pr[q] * vc[q];
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, i
     for (int q = 0; q < EPT; ++q) {
         const int c = r0 + tid + q * TD_T;
         if (c < n) {
-            if (j >= 0) x[q] -= pr[q] + wfirst * vc[q];
+            if (have) x[q] -= pr[q] + wfirst * vc[q];
             if (c == r0) bc[1] = x[q];
             if (c == r0 + 1) bc[2] = x[q];
             if (c >= r0 + 2) acc2[0] += x[q] * x[q];
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(TD_T) void k_td_small_reg(double* __restrict__ A, i
             e[r0] = alpha;
             tau[r0] = 0.0;
             double last = A[(long long)(n - 1) * n + (n - 1)];
-            if (j >= 0) last -= 2.0 * vcur[n - 1] * w[n - 1];
+            if (have) last -= 2.0 * vcur[n - 1] * w[n - 1];
             d[n - 1] = last;
         }
         return;
@@ -250,6 +253,269 @@ __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_td_panel (round 4): TDP_NB reflectors per LAUNCH of one co-resident grid, the trailing block only READ.
+// The two-launch step above moves 16 m^2 bytes per reflector (read + write of the trailing block, 340 GB in all for n = 4000:
+// 77 of the 104 ms, at the 4.4 TB/s the Infinity Cache gives a read/write mix).  LAPACK's dlatrd form defers the writes: inside a
+// panel the matrix stays as it is and every use of it is corrected by the panel's reflectors so far,
+//     A_cur = A - sum_k (v_k w_k^T + w_k v_k^T),
+// the rank-2 TDP_NB update being applied once per panel (k_td_rank2k).  Per reflector that needs three grid-wide steps -- the
+// corrected row and its norm, the mat-vec with the dots W^T v, V^T v, the new w -- which as launches would cost what they
+// save; here they are phases of ONE kernel with two exchanges per reflector:
+//   phase I  (by index slices): w of the previous reflector for the slice, then row r of A_cur for the slice -> x, |x|^2 partial
+//   -- exchange A (one word per block: the partial) -> sigma, the reflector's beta / tau / scale, identically on every block
+//   phase II (2-D items, as k_td_update): z[chunk][i] = sum_c A[i][c] v[c] (v in LDS), v^T A v partial; one wave per dot
+//            p_k = W_k . v, q_k = V_k . v; v -> row r of A (the back-transformation reads it there) and V[jj]
+//   -- exchange B (one word per block: the v^T A v partial) -> y . v = v^T A v - 2 p . q
+// Exchanges as in k_panel_multi (asb_project.hip): agent-scope (write-through) stores and loads, self-validating words in a ring
+// of three, no cache maintenance; every vector another block reads (x, z, p, q, V, W) goes through the same stores / loads.
+// All sums in a fixed order: every rank of a multi-GPU run gets the same T.  A spin limit turns a lost block into an error flag.
+#define TDP_NB 32
+#define TDP_T 512
+#define TDP_SENT 0xFFFFFFFFFFFFFFFFull
+struct TdpBuf { double* x; double* zp; double* pq; double* V; double* W; unsigned long long* rec; unsigned* flags; };
+__device__ __forceinline__ void tdp_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double tdp_load(const double* p) {
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every block: the ordered sum of all blocks' words of generation `gen` (-> LDS red[0]); false: timed out / aborted
+__device__ __forceinline__ bool tdp_exchange(const TdpBuf& B, int G, int gen, double mine, double* red, int* dead_sh) {
+    const int tid = threadIdx.x;
+    __builtin_amdgcn_s_waitcnt(0);               // this wave's write-through stores of the phase are acknowledged
+    __syncthreads();
+    unsigned long long* ring = B.rec + (size_t)(gen % 3) * G;
+    if (tid == 0) {
+        __hip_atomic_store(ring + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dead_sh = 0;
+    }
+    __syncthreads();
+    double v = 0.0;
+    if (tid < G) {
+        long long spins = 0;
+        for (;;) {
+            const unsigned long long w = __hip_atomic_load(ring + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w != TDP_SENT) { v = __longlong_as_double((long long)w); break; }
+            if ((++spins & 255) == 0 && (spins > (1LL << 24) || __hip_atomic_load(B.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(B.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *dead_sh = 1;
+                break;
+            }
+        }
+    }
+    red[tid] = v;
+    __syncthreads();
+    // Everybody has posted generation `gen`, so everybody is past its poll of generation gen - 1: this block's word of that
+    // generation goes back to "not written" (its slot is written again at gen + 2, behind the drain in front of gen + 1's post)
+    if (tid == 0 && *dead_sh == 0)
+        __hip_atomic_store(B.rec + (size_t)((gen + 2) % 3) * G + blockIdx.x, TDP_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = TDP_T / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    return *dead_sh == 0;
+}
+__global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, int n, int j0, int nb, TdpBuf B, double* __restrict__ tau,
+                                                       double* __restrict__ d, double* __restrict__ e) {
+    extern __shared__ double tdp_lds[];
+    double* v_sh = tdp_lds;                       // n doubles: the current reflector (0 below its support)
+    double* red = tdp_lds + n;                    // TDP_T
+    double* pq_sh = red + TDP_T;                  // 2 TDP_NB: p_k = W_k . v, q_k = V_k . v
+    double* rowk = pq_sh + 2 * TDP_NB;            // 2 TDP_NB: V_k[r], W_k[r] of the current row
+    __shared__ int dead_sh;
+    __shared__ double bc[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, G = gridDim.x, b = blockIdx.x;
+    constexpr int NWB = TDP_T / 64;
+    const long long gw = (long long)b * NWB + wv, NW = (long long)G * NWB;
+    const int sl0 = (int)((long long)n * b / G), sl1 = (int)((long long)n * (b + 1) / G);      // this block's index slice
+    const int half = lane >> 5, kl = lane & 31;   // phase I: half a wave per index, lane <-> reflector of the panel
+    int gen = 0;
+    double t_prev = 0.0, yv_prev = 0.0;
+    const int nch_all = (n + TD_CW - 1) / TD_CW;
+    for (int jj = 0; jj <= nb; ++jj) {
+        const int r = j0 + jj;                    // the reflector built in this round (jj == nb: only the last w is finished)
+        // ---- phase I
+        // w_{r-1}[r], needed by every block for the row: from z[.][r], the panel's rows at r and p, q
+        if (jj > 0) {
+            if (tid < 2 * TDP_NB) {
+                const int k = tid & (TDP_NB - 1);
+                rowk[tid] = (k < jj - 1) ? tdp_load((tid < TDP_NB ? B.V : B.W) + (size_t)k * n + r) : 0.0;
+            }
+            __syncthreads();
+            if (wv == 0) {
+                const int rp = r - 1, nch = (n - (rp + 1) + TD_CW - 1) / TD_CW;
+                double y = 0.0;
+                if (lane == 0) {
+                    for (int c = 0; c < nch; ++c) y += tdp_load(B.zp + (size_t)c * n + r);
+                }
+                double corr = (lane < jj - 1 && lane < TDP_NB) ? rowk[lane] * pq_sh[lane] + rowk[TDP_NB + lane] * pq_sh[TDP_NB + lane] : 0.0;
+                for (int o = 16; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
+                if (lane == 0) {
+                    y -= corr;
+                    const double wr = t_prev * (y - 0.5 * t_prev * yv_prev * 1.0);      // v_{r-1}[r] = 1
+                    bc[0] = wr;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { rowk[jj - 1] = 1.0; rowk[TDP_NB + jj - 1] = bc[0]; }
+            __syncthreads();
+        }
+        double sig_part = 0.0;
+        for (int i0 = sl0; i0 < sl1; i0 += 2 * NWB) {
+            const int i = i0 + 2 * wv + half;
+            const bool on = i < sl1 && i >= r && i < n;
+            // lane kl: reflector k = kl of the panel (k < jj - 1 from memory; k = jj - 1 is the one being finished)
+            double vk = 0.0, wk = 0.0;
+            if (on && kl < jj - 1) {
+                vk = tdp_load(B.V + (size_t)kl * n + i);
+                wk = tdp_load(B.W + (size_t)kl * n + i);
+            }
+            double s3 = (kl < jj - 1) ? vk * pq_sh[kl] + wk * pq_sh[TDP_NB + kl] : 0.0;
+            double s1 = (kl < jj - 1) ? rowk[kl] * wk + rowk[TDP_NB + kl] * vk : 0.0;
+            for (int o = 16; o > 0; o >>= 1) { s3 += __shfl_xor(s3, o, 64); s1 += __shfl_xor(s1, o, 64); }
+            if (kl == 0 && on) {
+                double xi = (jj < nb) ? A[(size_t)r * n + i] : 0.0;
+                if (jj > 0) {
+                    const int rp = r - 1, nch = (n - (rp + 1) + TD_CW - 1) / TD_CW;
+                    double y = 0.0;
+                    for (int c = 0; c < nch; ++c) y += tdp_load(B.zp + (size_t)c * n + i);
+                    y -= s3;
+                    const double vi = v_sh[i];
+                    const double wi = t_prev * (y - 0.5 * t_prev * yv_prev * vi);
+                    tdp_store(B.W + (size_t)(jj - 1) * n + i, wi);
+                    xi -= s1 + (1.0 * wi + bc[0] * vi);       // k = jj - 1: V[r] = 1, W[r] = w_{r-1}[r]
+                }
+                if (jj < nb) {
+                    tdp_store(B.x + i, xi);
+                    if (i >= r + 2) sig_part += xi * xi;
+                }
+            }
+        }
+        if (jj == nb) break;                       // (the kernel's end publishes the last w)
+        // block partial of sigma, fixed order: lanes 0 / 32 of each wave hold one
+        red[tid] = sig_part;
+        __syncthreads();
+        if (tid == 0) {
+            double sacc = 0.0;
+            for (int q = 0; q < TDP_T; q += 32) sacc += red[q];
+            bc[1] = sacc;
+        }
+        __syncthreads();
+        if (!tdp_exchange(B, G, gen++, bc[1], red, &dead_sh)) return;
+        const double sigma = red[0];
+        __syncthreads();
+        if (tid == 0) { bc[2] = tdp_load(B.x + r); bc[3] = tdp_load(B.x + r + 1); }
+        __syncthreads();
+        const double diag = bc[2], alpha = bc[3];
+        double beta, t, scale;
+        if (sigma == 0.0) { beta = alpha; t = 0.0; scale = 0.0; }
+        else {
+            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+            t = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (b == 0 && tid == 0) { d[r] = diag; e[r] = beta; tau[r] = t; }
+        // ---- phase II
+        for (int c = tid; c < n; c += TDP_T) v_sh[c] = (c <= r) ? 0.0 : (c == r + 1 ? 1.0 : tdp_load(B.x + c) * scale);
+        __syncthreads();
+        for (int i = sl0 + tid; i < sl1; i += TDP_T)
+            if (i >= r + 1) {
+                tdp_store(B.V + (size_t)jj * n + i, v_sh[i]);
+                A[(size_t)r * n + i] = v_sh[i];
+            }
+        const int r1 = r + 1, rows = n - r1;
+        const int nch = (rows + TD_CW - 1) / TD_CW, ngroups = (rows + 3) / 4;
+        double vav = 0.0;
+        for (long long item = gw; item < (long long)ngroups * nch; item += NW) {
+            const int i0 = r1 + (int)(item / nch) * 4, cc = (int)(item % nch);
+            const int c_lo = r1 + cc * TD_CW, c_hi = (c_lo + TD_CW < n) ? c_lo + TD_CW : n;
+            const double* rowp[4];
+            double acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (i0 + q < n) ? i0 + q : n - 1;
+                rowp[q] = A + (size_t)i * n;
+                acc[q] = 0.0;
+            }
+            for (int c = c_lo + lane; c < c_hi; c += 256) {
+                double a[4][4], vn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cu = c + 64 * u;
+                    const bool on = cu < c_hi;
+                    vn[u] = on ? v_sh[cu] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[u][q] = on ? rowp[q][cu] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double sq = a[0][q] * vn[0];
+#pragma unroll
+                    for (int u = 1; u < 4; ++u) sq += a[u][q] * vn[u];
+                    acc[q] += sq;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double sq = wave_sum(acc[q]);
+                if (lane == 0 && i0 + q < n) {
+                    tdp_store(B.zp + (size_t)cc * n + i0 + q, sq);
+                    vav += v_sh[i0 + q] * sq;
+                }
+            }
+        }
+        // the dots with the panel so far, one wave each, from the far end of the grid
+        for (int q = (int)(NW - 1 - gw); q < 2 * jj; q += (int)NW) {
+            const int k = q >> 1;
+            const double* src = ((q & 1) ? B.V : B.W) + (size_t)k * n;
+            double sdot = 0.0;
+            for (int c = r1 + lane; c < n; c += 64) sdot += tdp_load(src + c) * v_sh[c];
+            sdot = wave_sum(sdot);
+            if (lane == 0) tdp_store(B.pq + (q & 1) * TDP_NB + k, sdot);
+        }
+        red[tid] = (lane == 0) ? vav : 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            double sacc = 0.0;
+            for (int q = 0; q < TDP_T; q += 64) sacc += red[q];
+            bc[1] = sacc;
+        }
+        __syncthreads();
+        if (!tdp_exchange(B, G, gen++, bc[1], red, &dead_sh)) return;
+        const double vAv = red[0];
+        __syncthreads();
+        if (tid < 2 * TDP_NB) pq_sh[tid] = ((tid & (TDP_NB - 1)) < jj) ? tdp_load(B.pq + tid) : 0.0;
+        __syncthreads();
+        double pqs = 0.0;
+        for (int k = 0; k < jj; ++k) pqs += pq_sh[k] * pq_sh[TDP_NB + k];
+        t_prev = t;
+        yv_prev = vAv - 2.0 * pqs;
+    }
+}
+// the panel's rank-2 nb update of the trailing block (rows, columns >= j1), both triangles: A -= sum_k v_k w_k^T + w_k v_k^T;
+// each term as (v_i w_c) + (w_i v_c) with both products rounded, so that the two triangles stay mirror images bit for bit
+__global__ __launch_bounds__(256) void k_td_rank2k(double* __restrict__ A, int n, int j1, const double* __restrict__ V,
+                                                   const double* __restrict__ W, int nb) {
+    __shared__ double Vi[TDP_NB][64], Wi[TDP_NB][64], Vc[TDP_NB][64], Wc[TDP_NB][64];
+    const int ti = j1 + blockIdx.y * 64, tc = j1 + blockIdx.x * 64, tid = threadIdx.x;
+    for (int q = tid; q < nb * 64; q += 256) {
+        const int k = q >> 6, o = q & 63;
+        const int i = ti + o, c = tc + o;
+        Vi[k][o] = i < n ? V[(size_t)k * n + i] : 0.0;
+        Wi[k][o] = i < n ? W[(size_t)k * n + i] : 0.0;
+        Vc[k][o] = c < n ? V[(size_t)k * n + c] : 0.0;
+        Wc[k][o] = c < n ? W[(size_t)k * n + c] : 0.0;
+    }
+    __syncthreads();
+    const int cx = tid & 63, iy = tid >> 6;      // thread: column cx, rows iy, iy + 4, ...
+    for (int q = 0; q < 16; ++q) {
+        const int io = iy + 4 * q, i = ti + io, c = tc + cx;
+        if (i >= n || c >= n) continue;
+        double s = 0.0;
+        for (int k = 0; k < nb; ++k) s = __dadd_rn(s, __dadd_rn(__dmul_rn(Vi[k][io], Wc[k][cx]), __dmul_rn(Wi[k][io], Vc[k][cx])));
+        A[(size_t)i * n + c] -= s;
+    }
+}
+
 // Z (n x k, row-major) <- Q Z with Q = H_0 H_1 ... H_{n-3}: one WAVE per column, the column in LDS,
 // reflectors applied last to first; v_j is read from row j of A (shared by all waves through L2).
 __global__ __launch_bounds__(256) void k_td_back(const double* __restrict__ A, const double* __restrict__ tau, int n,
@@ -322,18 +588,61 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
     ASB_HIP(ctx, hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     constexpr int R = 4;
     int nch_prev = 1;
-    for (int j = -1; j <= n - 3; ++j) {
+    // panels of TDP_NB reflectors in one co-resident launch each (k_td_panel) while the trailing block is large; the
+    // two-launch loop below finishes from the first column they left (js), on the explicitly updated matrix
+    int js = 0;
+    {
+        static const int panel_min = getenv("ASB_TD_PANEL_MIN") ? atoi(getenv("ASB_TD_PANEL_MIN")) : 1536;
+        static const int panel_tail = getenv("ASB_TD_PANEL_TAIL") ? atoi(getenv("ASB_TD_PANEL_TAIL")) : 512;
+        const size_t lds = ((size_t)n + TDP_T + 4 * TDP_NB) * sizeof(double);
+        if (panel_min > 0 && n >= panel_min && lds <= 150 * 1024) {
+            int per_cu = 0;
+            ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_td_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ASB_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_td_panel, TDP_T, lds));
+            int G = per_cu >= 1 ? ctx->n_cu : 0;
+            if (G > TDP_T) G = TDP_T;
+            if (G >= 16) {
+                const size_t nd = (size_t)n * (1 + nch_max + 2 * TDP_NB) + 2 * TDP_NB;
+                if ((rc = asb_alloc(ctx, &ctx->td_panel, nd))) return rc;
+                if ((rc = asb_alloc(ctx, &ctx->td_rec, (size_t)3 * TDP_T + 16))) return rc;
+                TdpBuf B;
+                B.x = ctx->td_panel;
+                B.zp = B.x + n;
+                B.V = B.zp + (size_t)nch_max * n;
+                B.W = B.V + (size_t)TDP_NB * n;
+                B.pq = B.W + (size_t)TDP_NB * n;
+                B.rec = ctx->td_rec;
+                B.flags = reinterpret_cast<unsigned*>(ctx->td_rec + 3 * TDP_T);
+                ASB_HIP(ctx, hipMemsetAsync(B.flags, 0, 16 * sizeof(unsigned long long) / 2, ctx->stream));
+                const int tail = panel_tail < 64 ? 64 : panel_tail;
+                while (n - js > tail + TDP_NB) {
+                    ASB_HIP(ctx, hipMemsetAsync(B.rec, 0xFF, (size_t)3 * TDP_T * sizeof(unsigned long long), ctx->stream));
+                    hipLaunchKernelGGL(k_td_panel, dim3(G), dim3(TDP_T), lds, ctx->stream, A, n, js, TDP_NB, B, tau, d, e);
+                    const int j1 = js + TDP_NB, tiles = (n - j1 + 63) / 64;
+                    hipLaunchKernelGGL(k_td_rank2k, dim3(tiles, tiles), dim3(256), 0, ctx->stream, A, n, j1, B.V, B.W, TDP_NB);
+                    js = j1;
+                }
+                ASB_CHECK_LAUNCH(ctx);
+                unsigned fl = 0;
+                ASB_HIP(ctx, hipMemcpyAsync(&fl, B.flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+                ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (fl) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: the panel kernel's grid exchange timed out (ASB_TD_PANEL_MIN=0 takes the two-launch loop)");
+            }
+        }
+    }
+    for (int j = js - 1; j <= n - 3; ++j) {
+        const int fresh = (js > 0 && j == js - 1) ? 1 : 0;
         double* vcur = (j & 1) ? vb1 : vb0;          // j = -1 -> vb1 (unused)
         double* vnext = ((j + 1) & 1) ? vb1 : vb0;
         // k_td_small(j) writes d[j+1]; for j = -1 it would overwrite d[0] with the same value A[0][0]
         static const int reg = getenv("ASB_TD_SMALL_REG") ? atoi(getenv("ASB_TD_SMALL_REG")) : 1;
         const int rows_left = n - (j + 1);
         if (reg && rows_left <= 4 * TD_T)
-            hipLaunchKernelGGL((k_td_small_reg<4>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e);
+            hipLaunchKernelGGL((k_td_small_reg<4>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e, fresh);
         else if (reg && rows_left <= 8 * TD_T)
-            hipLaunchKernelGGL((k_td_small_reg<8>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e);
+            hipLaunchKernelGGL((k_td_small_reg<8>), dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, tau, d, e, fresh);
         else
-            hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, xbuf, tau, d, e);
+            hipLaunchKernelGGL(k_td_small, dim3(1), dim3(TD_T), 0, ctx->stream, A, n, j, p, nch_prev, vcur, w, vnext, xbuf, tau, d, e, fresh);
         if (j + 1 <= n - 3) {
             const int r1 = j + 2, rows = n - r1;
             const int nch = (rows + TD_CW - 1) / TD_CW;
@@ -343,10 +652,10 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
             if (grid < 1) grid = 1;
             static const int tdv = getenv("ASB_TD_VARIANT") ? atoi(getenv("ASB_TD_VARIANT")) : 1;
             if (tdv == 1)          // four column positions per lane in flight (round 4: POD 237 -> 233 ms on one box; 0: two)
-                hipLaunchKernelGGL((k_td_update<R, 4>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
+                hipLaunchKernelGGL((k_td_update<R, 4>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, (j >= 0 && !fresh) ? 1 : 0, vcur, w, vnext,
                                    tau + (j + 1), p, nch);
             else
-            hipLaunchKernelGGL((k_td_update<R>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, j >= 0 ? 1 : 0, vcur, w, vnext,
+            hipLaunchKernelGGL((k_td_update<R>), dim3(grid), dim3(256), 0, ctx->stream, A, n, r1, (j >= 0 && !fresh) ? 1 : 0, vcur, w, vnext,
                                tau + (j + 1), p, nch);
             nch_prev = nch;
         }
