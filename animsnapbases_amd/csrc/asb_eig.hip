@@ -273,22 +273,28 @@ __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n
 #define TDP_NB 32
 #define TDP_T 512
 #define TDP_SENT 0xFFFFFFFFFFFFFFFFull
-struct TdpBuf { double* x; double* zp; double* pq; double* V; double* W; unsigned long long* rec; unsigned* flags; };
+struct TdpBuf { double* x; double* zp; double* pq; double* V; double* W; unsigned long long* rec; unsigned* flags; unsigned long long* tlog; };
+#define TDP_STAMP(slot) do { if (B.tlog && b == 0 && tid == 0) B.tlog[(size_t)jj * 8 + (slot)] = wall_clock64_td(); } while (0)
+__device__ __forceinline__ unsigned long long wall_clock64_td() { return wall_clock64(); }      // 100 MHz
 __device__ __forceinline__ void tdp_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double tdp_load(const double* p) {
     return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// every block: the ordered sum of all blocks' words of generation `gen` (-> LDS red[0]); false: timed out / aborted
-__device__ __forceinline__ bool tdp_exchange(const TdpBuf& B, int G, int gen, double mine, double* red, int* dead_sh) {
-    const int tid = threadIdx.x;
+// every block: the ordered sum of all blocks' words of generation `gen` (-> LDS red[0]); false: timed out / aborted.
+// Two halves, so that loads which do not depend on the exchange can be put in flight between them.
+__device__ __forceinline__ void tdp_post(const TdpBuf& B, int G, int gen, double mine, int* dead_sh) {
     __builtin_amdgcn_s_waitcnt(0);               // this wave's write-through stores of the phase are acknowledged
     __syncthreads();
-    unsigned long long* ring = B.rec + (size_t)(gen % 3) * G;
-    if (tid == 0) {
-        __hip_atomic_store(ring + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(B.rec + (size_t)(gen % 3) * G + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
         *dead_sh = 0;
     }
     __syncthreads();
+}
+__device__ __forceinline__ bool tdp_poll(const TdpBuf& B, int G, int gen, double* red, int* dead_sh) {
+    const int tid = threadIdx.x;
+    unsigned long long* ring = B.rec + (size_t)(gen % 3) * G;
     double v = 0.0;
     if (tid < G) {
         long long spins = 0;
@@ -314,6 +320,10 @@ __device__ __forceinline__ bool tdp_exchange(const TdpBuf& B, int G, int gen, do
     }
     return *dead_sh == 0;
 }
+__device__ __forceinline__ bool tdp_exchange(const TdpBuf& B, int G, int gen, double mine, double* red, int* dead_sh) {
+    tdp_post(B, G, gen, mine, dead_sh);
+    return tdp_poll(B, G, gen, red, dead_sh);
+}
 __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, int n, int j0, int nb, TdpBuf B, double* __restrict__ tau,
                                                        double* __restrict__ d, double* __restrict__ e) {
     extern __shared__ double tdp_lds[];
@@ -330,9 +340,9 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
     const int half = lane >> 5, kl = lane & 31;   // phase I: half a wave per index, lane <-> reflector of the panel
     int gen = 0;
     double t_prev = 0.0, yv_prev = 0.0;
-    const int nch_all = (n + TD_CW - 1) / TD_CW;
     for (int jj = 0; jj <= nb; ++jj) {
         const int r = j0 + jj;                    // the reflector built in this round (jj == nb: only the last w is finished)
+        TDP_STAMP(0);
         // ---- phase I
         // w_{r-1}[r], needed by every block for the row: from z[.][r], the panel's rows at r and p, q
         if (jj > 0) {
@@ -345,7 +355,13 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
                 const int rp = r - 1, nch = (n - (rp + 1) + TD_CW - 1) / TD_CW;
                 double y = 0.0;
                 if (lane == 0) {
-                    for (int c = 0; c < nch; ++c) y += tdp_load(B.zp + (size_t)c * n + r);
+                    for (int c0 = 0; c0 < nch; c0 += 8) {
+                        double zz[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) zz[u] = c0 + u < nch ? tdp_load(B.zp + (size_t)(c0 + u) * n + r) : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) y += zz[u];
+                    }
                 }
                 double corr = (lane < jj - 1 && lane < TDP_NB) ? rowk[lane] * pq_sh[lane] + rowk[TDP_NB + lane] * pq_sh[TDP_NB + lane] : 0.0;
                 for (int o = 16; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
@@ -377,7 +393,13 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
                 if (jj > 0) {
                     const int rp = r - 1, nch = (n - (rp + 1) + TD_CW - 1) / TD_CW;
                     double y = 0.0;
-                    for (int c = 0; c < nch; ++c) y += tdp_load(B.zp + (size_t)c * n + i);
+                    for (int c0 = 0; c0 < nch; c0 += 8) {
+                        double zz[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) zz[u] = c0 + u < nch ? tdp_load(B.zp + (size_t)(c0 + u) * n + i) : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) y += zz[u];
+                    }
                     y -= s3;
                     const double vi = v_sh[i];
                     const double wi = t_prev * (y - 0.5 * t_prev * yv_prev * vi);
@@ -400,11 +422,34 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
             bc[1] = sacc;
         }
         __syncthreads();
-        if (!tdp_exchange(B, G, gen++, bc[1], red, &dead_sh)) return;
+        TDP_STAMP(1);
+        // the matrix rows of this wave's FIRST mat-vec item do not depend on the exchange: requested behind the post, they travel
+        // while the words do (at n = 4000 a wave has one or two items: up to the whole mat-vec's memory time is hidden)
+        const int r1 = r + 1, rows = n - r1;
+        const int nch = (rows + TD_CW - 1) / TD_CW, ngroups = (rows + 3) / 4;
+        const long long n_items = (long long)ngroups * nch;
+        double a_pre[8][4];
+        tdp_post(B, G, gen, bc[1], &dead_sh);
+        if (gw < n_items) {
+            const int i0 = r1 + (int)(gw / nch) * 4, cc = (int)(gw % nch);
+            const int c_lo = r1 + cc * TD_CW, c_hi = (c_lo + TD_CW < n) ? c_lo + TD_CW : n;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = c_lo + lane + 64 * u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = (i0 + q < n) ? i0 + q : n - 1;
+                    a_pre[u][q] = cu < c_hi ? A[(size_t)i * n + cu] : 0.0;
+                }
+            }
+        }
+        if (!tdp_poll(B, G, gen++, red, &dead_sh)) return;
+        TDP_STAMP(2);
         const double sigma = red[0];
         __syncthreads();
         if (tid == 0) { bc[2] = tdp_load(B.x + r); bc[3] = tdp_load(B.x + r + 1); }
         __syncthreads();
+        double vav = 0.0;
         const double diag = bc[2], alpha = bc[3];
         double beta, t, scale;
         if (sigma == 0.0) { beta = alpha; t = 0.0; scale = 0.0; }
@@ -415,17 +460,60 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
         }
         if (b == 0 && tid == 0) { d[r] = diag; e[r] = beta; tau[r] = t; }
         // ---- phase II
-        for (int c = tid; c < n; c += TDP_T) v_sh[c] = (c <= r) ? 0.0 : (c == r + 1 ? 1.0 : tdp_load(B.x + c) * scale);
+        for (int c0 = 0; c0 < n; c0 += 8 * TDP_T) {             // (eight loads per thread in flight)
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + tid + u * TDP_T;
+                xv[u] = (c >= r + 2 && c < n) ? tdp_load(B.x + c) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + tid + u * TDP_T;
+                if (c < n) v_sh[c] = (c <= r) ? 0.0 : (c == r + 1 ? 1.0 : xv[u] * scale);
+            }
+        }
         __syncthreads();
         for (int i = sl0 + tid; i < sl1; i += TDP_T)
             if (i >= r + 1) {
                 tdp_store(B.V + (size_t)jj * n + i, v_sh[i]);
                 A[(size_t)r * n + i] = v_sh[i];
             }
-        const int r1 = r + 1, rows = n - r1;
-        const int nch = (rows + TD_CW - 1) / TD_CW, ngroups = (rows + 3) / 4;
-        double vav = 0.0;
-        for (long long item = gw; item < (long long)ngroups * nch; item += NW) {
+        TDP_STAMP(3);
+        // the dots with the panel so far, one BLOCK each from the far end of the grid (all loads of a thread in flight at once; a
+        // wave walking a vector alone was 60 dependent round trips at n = 4000)
+        for (int q = G - 1 - b; q < 2 * jj; q += G) {
+            const int k = q >> 1;
+            const double* src = ((q & 1) ? B.V : B.W) + (size_t)k * n;
+            double sdot = 0.0;
+            for (int c0 = r1; c0 < n; c0 += 8 * TDP_T) {
+                double xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + tid + u * TDP_T;
+                    xv[u] = c < n ? tdp_load(src + c) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + tid + u * TDP_T;
+                    if (c < n) sdot += xv[u] * v_sh[c];
+                }
+            }
+            red[tid] = sdot;
+            __syncthreads();
+            for (int o = TDP_T / 2; o > 0; o >>= 1) {
+                if (tid < o) red[tid] += red[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) tdp_store(B.pq + (q & 1) * TDP_NB + k, red[0]);
+            __syncthreads();
+        }
+        TDP_STAMP(4);
+        // items of 4 rows x TD_CW columns, round-robin over the waves of the grid (a wave's first batch of 32 loads is in registers).
+        // Measured and rejected: items of 4 x 256 columns (no faster, and 12 - 16 partial sums per index double phase I); one wave
+        // per SIMD with 3 or 5 items of 4 x 512 requested ahead (99.8 / 103.4 ms against 93.1: the requests delay the poll behind
+        // them, and finishing an item -- four wave sums -- is 1.7 us of its own)
+        for (long long item = gw; item < n_items; item += NW) {
             const int i0 = r1 + (int)(item / nch) * 4, cc = (int)(item % nch);
             const int c_lo = r1 + cc * TD_CW, c_hi = (c_lo + TD_CW < n) ? c_lo + TD_CW : n;
             const double* rowp[4];
@@ -436,21 +524,22 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
                 rowp[q] = A + (size_t)i * n;
                 acc[q] = 0.0;
             }
-            for (int c = c_lo + lane; c < c_hi; c += 256) {
-                double a[4][4], vn[4];
+            for (int c = c_lo + lane; c < c_hi; c += 512) {
+                double a[8][4], vn[8];
+                const bool pre = item == gw && c == c_lo + lane;      // (wave-uniform: the batch requested behind exchange A's post)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int cu = c + 64 * u;
                     const bool on = cu < c_hi;
                     vn[u] = on ? v_sh[cu] : 0.0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a[u][q] = on ? rowp[q][cu] : 0.0;
+                    for (int q = 0; q < 4; ++q) a[u][q] = pre ? a_pre[u][q] : (on ? rowp[q][cu] : 0.0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     double sq = a[0][q] * vn[0];
 #pragma unroll
-                    for (int u = 1; u < 4; ++u) sq += a[u][q] * vn[u];
+                    for (int u = 1; u < 8; ++u) sq += a[u][q] * vn[u];
                     acc[q] += sq;
                 }
             }
@@ -463,15 +552,7 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
                 }
             }
         }
-        // the dots with the panel so far, one wave each, from the far end of the grid
-        for (int q = (int)(NW - 1 - gw); q < 2 * jj; q += (int)NW) {
-            const int k = q >> 1;
-            const double* src = ((q & 1) ? B.V : B.W) + (size_t)k * n;
-            double sdot = 0.0;
-            for (int c = r1 + lane; c < n; c += 64) sdot += tdp_load(src + c) * v_sh[c];
-            sdot = wave_sum(sdot);
-            if (lane == 0) tdp_store(B.pq + (q & 1) * TDP_NB + k, sdot);
-        }
+        TDP_STAMP(5);
         red[tid] = (lane == 0) ? vav : 0.0;
         __syncthreads();
         if (tid == 0) {
@@ -481,6 +562,7 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
         }
         __syncthreads();
         if (!tdp_exchange(B, G, gen++, bc[1], red, &dead_sh)) return;
+        TDP_STAMP(6);
         const double vAv = red[0];
         __syncthreads();
         if (tid < 2 * TDP_NB) pq_sh[tid] = ((tid & (TDP_NB - 1)) < jj) ? tdp_load(B.pq + tid) : 0.0;
@@ -491,8 +573,8 @@ __global__ __launch_bounds__(TDP_T, 2) void k_td_panel(double* __restrict__ A, i
         yv_prev = vAv - 2.0 * pqs;
     }
 }
-// the panel's rank-2 nb update of the trailing block (rows, columns >= j1), both triangles: A -= sum_k v_k w_k^T + w_k v_k^T;
-// each term as (v_i w_c) + (w_i v_c) with both products rounded, so that the two triangles stay mirror images bit for bit
+// the panel's rank-2 nb update of the trailing block (rows, columns >= j1), both triangles: A -= sum_k v_k w_k^T + w_k v_k^T
+// (like k_td_update, the two triangles agree to rounding, not bit for bit: the mat-vec reads whole rows)
 __global__ __launch_bounds__(256) void k_td_rank2k(double* __restrict__ A, int n, int j1, const double* __restrict__ V,
                                                    const double* __restrict__ W, int nb) {
     __shared__ double Vi[TDP_NB][64], Wi[TDP_NB][64], Vc[TDP_NB][64], Wc[TDP_NB][64];
@@ -506,13 +588,22 @@ __global__ __launch_bounds__(256) void k_td_rank2k(double* __restrict__ A, int n
         Wc[k][o] = c < n ? W[(size_t)k * n + c] : 0.0;
     }
     __syncthreads();
-    const int cx = tid & 63, iy = tid >> 6;      // thread: column cx, rows iy, iy + 4, ...
-    for (int q = 0; q < 16; ++q) {
-        const int io = iy + 4 * q, i = ti + io, c = tc + cx;
-        if (i >= n || c >= n) continue;
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s = __dadd_rn(s, __dadd_rn(__dmul_rn(Vi[k][io], Wc[k][cx]), __dmul_rn(Wi[k][io], Vc[k][cx])));
-        A[(size_t)i * n + c] -= s;
+    const int cx = tid & 63, iy = tid >> 6;      // thread: column cx, rows iy, iy + 4, ... (a wave shares its rows: broadcast reads)
+    const int c = tc + cx;
+    double s[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s[q] = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const double wc = Wc[k][cx], vc = Vc[k][cx];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[q] = fma(Wi[k][iy + 4 * q], vc, fma(Vi[k][iy + 4 * q], wc, s[q]));
+    }
+    if (c < n) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = ti + iy + 4 * q;
+            if (i < n) A[(size_t)i * n + c] -= s[q];
+        }
     }
 }
 
@@ -602,21 +693,26 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
             int G = per_cu >= 1 ? ctx->n_cu : 0;
             if (G > TDP_T) G = TDP_T;
             if (G >= 16) {
-                const size_t nd = (size_t)n * (1 + nch_max + 2 * TDP_NB) + 2 * TDP_NB;
+                const int nch_p = nch_max;
+                const size_t nd = (size_t)n * (1 + nch_p + 2 * TDP_NB) + 2 * TDP_NB;
                 if ((rc = asb_alloc(ctx, &ctx->td_panel, nd))) return rc;
                 if ((rc = asb_alloc(ctx, &ctx->td_rec, (size_t)3 * TDP_T + 16))) return rc;
                 TdpBuf B;
                 B.x = ctx->td_panel;
                 B.zp = B.x + n;
-                B.V = B.zp + (size_t)nch_max * n;
+                B.V = B.zp + (size_t)nch_p * n;
                 B.W = B.V + (size_t)TDP_NB * n;
                 B.pq = B.W + (size_t)TDP_NB * n;
                 B.rec = ctx->td_rec;
                 B.flags = reinterpret_cast<unsigned*>(ctx->td_rec + 3 * TDP_T);
+                B.tlog = nullptr;
+                static unsigned long long* tlog_dev = nullptr;
+                if (getenv("ASB_DEBUG_TD") && !tlog_dev) (void)hipMalloc((void**)&tlog_dev, (TDP_NB + 1) * 8 * sizeof(unsigned long long));
                 ASB_HIP(ctx, hipMemsetAsync(B.flags, 0, 16 * sizeof(unsigned long long) / 2, ctx->stream));
                 const int tail = panel_tail < 64 ? 64 : panel_tail;
                 while (n - js > tail + TDP_NB) {
                     ASB_HIP(ctx, hipMemsetAsync(B.rec, 0xFF, (size_t)3 * TDP_T * sizeof(unsigned long long), ctx->stream));
+                    B.tlog = (tlog_dev && js == 1024) ? tlog_dev : nullptr;
                     hipLaunchKernelGGL(k_td_panel, dim3(G), dim3(TDP_T), lds, ctx->stream, A, n, js, TDP_NB, B, tau, d, e);
                     const int j1 = js + TDP_NB, tiles = (n - j1 + 63) / 64;
                     hipLaunchKernelGGL(k_td_rank2k, dim3(tiles, tiles), dim3(256), 0, ctx->stream, A, n, j1, B.V, B.W, TDP_NB);
@@ -626,6 +722,14 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
                 unsigned fl = 0;
                 ASB_HIP(ctx, hipMemcpyAsync(&fl, B.flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
                 ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (tlog_dev) {
+                    unsigned long long h[(TDP_NB + 1) * 8];
+                    (void)hipMemcpy(h, tlog_dev, sizeof(h), hipMemcpyDeviceToHost);
+                    for (int jj = 0; jj < TDP_NB; jj += 5)
+                        fprintf(stderr, "[asb] panel at 1024, reflector %2d (10 ns ticks): phase I %llu | exchange A %llu | stage v %llu | dots %llu | mat-vec %llu | exchange B %llu | round %llu\n", jj,
+                                h[jj * 8 + 1] - h[jj * 8], h[jj * 8 + 2] - h[jj * 8 + 1], h[jj * 8 + 3] - h[jj * 8 + 2], h[jj * 8 + 4] - h[jj * 8 + 3],
+                                h[jj * 8 + 5] - h[jj * 8 + 4], h[jj * 8 + 6] - h[jj * 8 + 5], h[(jj + 1) * 8] - h[jj * 8]);
+                }
                 if (fl) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: the panel kernel's grid exchange timed out (ASB_TD_PANEL_MIN=0 takes the two-launch loop)");
             }
         }
