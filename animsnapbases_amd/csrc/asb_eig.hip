@@ -288,9 +288,8 @@ __device__ __forceinline__ void tdp_post(const TdpBuf& B, int G, int gen, double
     if (threadIdx.x == 0) {
         __hip_atomic_store(B.rec + (size_t)(gen % 3) * G + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        *dead_sh = 0;
+        *dead_sh = 0;                            // (read behind the poll's barrier; a timed-out poller sets it to 1 after this)
     }
-    __syncthreads();
 }
 __device__ __forceinline__ bool tdp_poll(const TdpBuf& B, int G, int gen, double* red, int* dead_sh) {
     const int tid = threadIdx.x;
@@ -308,17 +307,21 @@ __device__ __forceinline__ bool tdp_poll(const TdpBuf& B, int G, int gen, double
             }
         }
     }
-    red[tid] = v;
+    // the sum in a fixed order: lane butterflies inside each wave, then the waves in turn (the same on every block); ONE barrier
+    const double wsum = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = wsum;
     __syncthreads();
     // Everybody has posted generation `gen`, so everybody is past its poll of generation gen - 1: this block's word of that
     // generation goes back to "not written" (its slot is written again at gen + 2, behind the drain in front of gen + 1's post)
     if (tid == 0 && *dead_sh == 0)
         __hip_atomic_store(B.rec + (size_t)((gen + 2) % 3) * G + blockIdx.x, TDP_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int o = TDP_T / 2; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    return *dead_sh == 0;
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < TDP_T / 64; ++q) sacc += red[q];
+    const bool ok = *dead_sh == 0;
+    __syncthreads();                             // (red and dead_sh are free again)
+    red[0] = sacc;                               // every thread the same value: callers read red[0] behind their next barrier
+    return ok;
 }
 __device__ __forceinline__ bool tdp_exchange(const TdpBuf& B, int G, int gen, double mine, double* red, int* dead_sh) {
     tdp_post(B, G, gen, mine, dead_sh);
