@@ -172,6 +172,7 @@ struct asb_ctx {
     int double_panels = 1;                 // two sub-panels per read of X (ASB_DOUBLE_PANELS=0: one)
     double* e_class = nullptr;             // energies at the start of a double panel: who was a candidate (both tiles' checks)
     double* e_tmp = nullptr;               // energies as if a tile stood in full (k_correct_rows<true> -> k_apply_tmp)
+    double* wide_out = nullptr;            // asb_project_columns_wide: where the multi-tile pass writes (default: comps)
     double* e_tmp4 = nullptr;              // k_check_tiles: tentative energies per tile (4 x n_loc)
     double* chk_rec = nullptr;             // its per-tile block records: pmax | psum | colpart (4 x nblk_cap x (1 + 1 + 16))
     long long* chk_idx = nullptr;

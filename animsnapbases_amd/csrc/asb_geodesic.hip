@@ -1022,11 +1022,13 @@ extern "C" int asb_geodesic_cache_add(asb_ctx* ctx, const int64_t* sources, int 
     ASB_HIP(ctx, hipMemcpyAsync(ctx->geo_src, sources, (size_t)nsrc * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
     if ((rc = geodesic_solve_dev(ctx, ctx->geo_src, nsrc, tol, nullptr, nullptr))) return rc;
     const size_t n = (size_t)G->n;
-    for (int c = 0; c < nsrc; ++c) {
+    for (int c = 0; c < nsrc;) {                 // consecutive slots of one slab are consecutive rows: one copy per slab touched
         const long long q = G->cached + c;
         if ((rc = asb_alloc(ctx, &G->slab[q / GB], (size_t)GB * n))) return rc;      // keeps an existing slab (same size)
-        ASB_HIP(ctx, hipMemcpyAsync(G->slab[q / GB] + (size_t)(q % GB) * n, ctx->geo_out + (size_t)c * n, n * sizeof(double),
+        const int room = (int)(GB - q % GB), cnt = nsrc - c < room ? nsrc - c : room;
+        ASB_HIP(ctx, hipMemcpyAsync(G->slab[q / GB] + (size_t)(q % GB) * n, ctx->geo_out + (size_t)c * n, (size_t)cnt * n * sizeof(double),
                                     hipMemcpyDeviceToDevice, ctx->stream));
+        c += cnt;
     }
     *slot0 = G->cached;
     G->cached += nsrc;

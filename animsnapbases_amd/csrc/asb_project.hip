@@ -1765,7 +1765,7 @@ static int launch_l2w_cfg(asb_ctx* ctx, const WideArgs& wa, int blocks_per_cu) {
     }
     const long long cap = (long long)blocks_per_cu * ctx->n_cu;
     hipLaunchKernelGGL((k_project_l2w<NT, G, S, NCT, OCC, PD>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * S), lds, ctx->stream,
-                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, ctx->comps, rows, ctx->tile_counter);
+                       ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa, (ctx->wide_out ? ctx->wide_out : ctx->comps), rows, ctx->tile_counter);
     return ASB_OK;
 }
 template <int NCT, int P, int SYNC, int NSB = (SYNC ? 3 : 2), int XD = 1>
@@ -1782,7 +1782,7 @@ static int launch_l2d(asb_ctx* ctx, const WideArgs& wa) {
     // one block per CU, each with its own contiguous share of the 16-row groups (no work queue)
     const long long nb = ngroups < ctx->n_cu ? ngroups : ctx->n_cu;
     hipLaunchKernelGGL((k_project_l2d<NCT, P, SYNC, NSB, 0, XD>), dim3((unsigned)nb), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3,
-                       ctx->wn2t3, wa, ctx->comps, rows);
+                       ctx->wn2t3, wa, (ctx->wide_out ? ctx->wide_out : ctx->comps), rows);
     return ASB_OK;
 }
 template <int NCT>
@@ -1808,7 +1808,7 @@ static int launch_wide(asb_ctx* ctx, int ntile, const WideArgs& wa) {
     if (ntile == 1) {                 // one tile: the single-panel kernel on the tile's operands
         const long long ntiles = (rows + 63) / 64;
         hipLaunchKernelGGL((k_project_l2s<4, 2, 2, 1>), dim3((unsigned)(ntiles < 4 * ctx->n_cu ? ntiles : 4 * ctx->n_cu)), dim3(128), 0, ctx->stream,
-                           ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa.nc[0], ctx->comps + (size_t)wa.kb[0] * rows, rows, ctx->tile_counter);
+                           ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa.nc[0], (ctx->wide_out ? ctx->wide_out : ctx->comps) + (size_t)wa.kb[0] * rows, rows, ctx->tile_counter);
     } else {
         switch (ntile) {
             case 2: rc = launch_l2w<2>(ctx, variant, wa); break;
@@ -1942,6 +1942,31 @@ int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0
     launch_project(ctx, ncols, out_rows);
     ASB_CHECK_LAUNCH(ctx);
     return ASB_OK;
+}
+
+__global__ void k_build_wq_tiles(const double* __restrict__ Wt3, int Fp, double* __restrict__ Wq3, unsigned* __restrict__ tile_counter);
+// the same product for up to 64 columns in ONE pass over X (the four-tile kernels of the panel reads; SPLOCS' c = W^T X took four
+// 16-column passes): out_rows[(k0 + j) - k0] for j < ncols, ncols <= 64
+int asb_project_columns_wide(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows, const double* col_scale) {
+    if (ncols < 1 || ncols > 64) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_project_columns_wide: %d columns", ncols);
+    int rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wt3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->Wq3, (size_t)ASB_MAX_SUB * ctx->Fp * 16))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->wn2t3, (size_t)16 * ASB_MAX_SUB))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->tile_counter, (size_t)16))) return rc;
+    const int ntile = (ncols + 15) / 16;
+    WideArgs wa{};
+    for (int ct = 0; ct < ntile; ++ct) {
+        wa.kb[ct] = 16 * ct;
+        wa.nc[ct] = ncols - 16 * ct < 16 ? ncols - 16 * ct : 16;
+        hipLaunchKernelGGL(k_build_wt_fk, dim3(64), dim3(256), 0, ctx->stream, Wfk, (long long)ldw, (long long)(k0 + 16 * ct), wa.nc[ct], (int)ctx->F,
+                           (int)ctx->Fp, ctx->Wt3 + (size_t)ct * ctx->Fp * 16, ctx->wn2t3 + 16 * ct, col_scale);
+    }
+    hipLaunchKernelGGL(k_build_wq_tiles, dim3(64, ntile), dim3(256), 0, ctx->stream, ctx->Wt3, (int)ctx->Fp, ctx->Wq3, ctx->tile_counter);
+    ctx->wide_out = out_rows;
+    rc = launch_wide(ctx, ntile, wa);
+    ctx->wide_out = nullptr;
+    return rc;
 }
 
 // start of a run on a tensor whose initial energies are known (E0): scal <- 0, hist <- 0, energy <- E0, range scalars restored --

@@ -17,6 +17,7 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // defined in asb_project.hip
+int asb_project_columns_wide(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows, const double* col_scale);
 int asb_project_columns(asb_ctx* ctx, const double* Wfk, int64_t ldw, int64_t k0, int ncols, double* out_rows,
                         const double* col_scale);
 
@@ -520,9 +521,13 @@ static int splocs_admm_run(asb_ctx* ctx, double rho, int n_iter) {
     asb_splocs* s = ctx->splocs;
     const int64_t K = s->K, n3 = 3 * ctx->n_loc, kn = K * ctx->n_loc;
     // c = W^T X  (K x 3n): the deflation's projection kernel, 16 columns per pass over X
-    for (int64_t k0 = 0; k0 < K; k0 += 16) {
-        const int nc = (int)((K - k0) < 16 ? (K - k0) : 16);
-        int rc = asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3, nullptr);
+    // (round 4: 64 columns per pass through the panel reads' four-tile kernel; config 3: 4 x 89 us + 8 small launches -> one pass)
+    static const int wide = getenv("ASB_SPLOCS_WIDE") ? atoi(getenv("ASB_SPLOCS_WIDE")) : 1;
+    const int step = wide ? 64 : 16;
+    for (int64_t k0 = 0; k0 < K; k0 += step) {
+        const int nc = (int)((K - k0) < step ? (K - k0) : step);
+        int rc = wide ? asb_project_columns_wide(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3, nullptr)
+                      : asb_project_columns(ctx, s->Wfk, K, k0, nc, s->c + (size_t)k0 * n3, nullptr);
         if (rc) return rc;
     }
     if (!s->defer_status) ASB_HIP(ctx, hipMemsetAsync(s->status, 0, 4 * sizeof(int), ctx->stream));
