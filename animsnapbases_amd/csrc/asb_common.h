@@ -59,6 +59,7 @@ struct asb_ctx {
     double* scm = nullptr;
     bool hist6_clear = false;
     double* mean_part = nullptr;      // per-block partials of that energy
+    double ev_cv2 = 0.0;            // squared coefficient of variation of EV over the vertices (asb_snapshots_scale)
     double mean_frac = 0.0, mean_energy = 0.0, prep_normx2 = 0.0;     // share / energy along that direction, |X|^2 (host)
     int64_t m_target_eff = 0;   // != 0 while a guessed panel is being selected: the (smaller) target of the energies proper
     int first_panel_mean = 1;   // ASB_FIRST_PANEL_MEAN=0: first panel from the initial energies alone

@@ -65,6 +65,15 @@ __device__ __forceinline__ bool in_guess(double e, double ev, const double* __re
 // data sets) with weights e, 19 / 35 with e^(1/2), 37 with e^(1/4).  Computed on
 // the fly from the energy at the start of the read and the vertex's index, by the compaction and by the pass's check alike;
 // off while sc[SC_TAU_DIV] is "infinite".  Like every other family it only names candidates: nothing rests on it.
+// WHEN: the family pays where the energy is unevenly spread over the vertices -- localised modes: the largest energies all lie in
+// one or two of them -- and costs a read or two where it is not (global modes: rank 50 + noise 13.1 -> 14.9 ms, a slowly decaying
+// spectrum 17.8 -> 21.0 ms with it, 50 bumps 34.2 -> 16.9 ms).  The squared coefficient of variation of the per-vertex energies
+// outside the constant direction, a by-product of the standardisation sweep, separates the two by orders of magnitude (0.02 - 0.07
+// for global modes, 0 for noise, 3.6 for the bumps): the family is on above ASB_DIVERSE_CV2 (0.5).
+static inline bool diverse_on(const asb_ctx* ctx) {
+    static const double thr = getenv("ASB_DIVERSE_CV2") ? atof(getenv("ASB_DIVERSE_CV2")) : 0.5;
+    return ctx->diverse && (!ctx->ev_valid || ctx->ev_cv2 > thr);
+}
 #define ASB_DIV_Q (ASB_NG + 1)              // its slot among the thresholds of a multi-score selection
 #define ASB_NQ (ASB_NG + 2)
 __device__ __forceinline__ double div_key(double e, long long i, double seed_bits) {
@@ -3920,7 +3929,7 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
     // (only where a predicted read is what the rating wants next and there is no sketch to predict it from -- too few rejected
     // columns, or a probe of the other kind in between: on data where plain reads rate better, e.g. a slowly decaying spectrum, a
     // diverse read would only be a dearer plain read: 27.5 against 17.5 ms when every rejection was answered by one)
-    if (ctx->diverse && want_replay && ctx->sketch && rejected && !ctx->sketch_valid && !ctx->sketch_run_off && total > 0 && k + total < k1) {
+    if (diverse_on(ctx) && want_replay && ctx->sketch && rejected && !ctx->sketch_valid && !ctx->sketch_run_off && total > 0 && k + total < k1) {
         ctx->diverse_next = true;
         ctx->sub_cur = nsub_lim;
         for (int sp = 0; sp < 8; ++sp) ctx->sub_budget[sp] = ASB_PANEL_COLS;
@@ -4211,7 +4220,7 @@ static int guess_thresholds(asb_ctx* ctx, int world, bool with_energy) {
     // the diversity family (in_div; single rank): the guess fills ~740 of the 1024 candidate slots of the panel kernel; ~190
     // energy-weighted random vertices beside them cost the random tensor nothing (their rows ride along) and give a first read
     // on LOCALISED data weight vectors that span all its modes instead of the strongest one or two (the sketch of the next read)
-    const long long md = (with_energy && ctx->diverse) ? 190 * ctx->m_target / 768 : 0;
+    const long long md = (with_energy && diverse_on(ctx)) ? 190 * ctx->m_target / 768 : 0;
     gt.g[ASB_DIV_Q] = gt.h[ASB_DIV_Q] = 0.0;
     gt.m_target[ASB_DIV_Q] = md;
     gt.m_cap[ASB_DIV_Q] = md + md / 8;
@@ -4307,11 +4316,11 @@ static int panel_candidates(asb_ctx* ctx, long long k, int stalled) {
     ctx->sketch_valid = false;
     ctx->read_by_score = by_score;
     // diversity (in_div): half of a plain read's candidates behind a rejection, an eighth beside the predicted ones
-    const bool div_plain = ctx->diverse && ctx->diverse_next && stalled == 0 && k > 0 && ctx->n_loc > 4 * ctx->m_cap;
+    const bool div_plain = diverse_on(ctx) && ctx->diverse_next && stalled == 0 && k > 0 && ctx->n_loc > 4 * ctx->m_cap;
     ctx->diverse_next = false;
     ctx->read_diverse = false;
     if (by_score) {
-        if ((rc = score_thresholds(ctx, true, ctx->diverse ? ctx->m_target / 8 : 0))) return rc;
+        if ((rc = score_thresholds(ctx, true, diverse_on(ctx) ? ctx->m_target / 8 : 0))) return rc;
         ctx->sel_e2 = ctx->sk_score;
         ctx->n_sketch_reads++;
     } else if (guess) {

@@ -244,6 +244,24 @@ __global__ __launch_bounds__(256) void k_e0_finish(const double* __restrict__ ps
     }
 }
 
+// out[0] = sum EV, out[1] = sum EV^2 (one block: n values from L2): how unevenly the energy outside the constant direction is
+// spread over the vertices -- localised data (a few regions carry it all) against global modes
+__global__ __launch_bounds__(1024) void k_ev_moments(const double* __restrict__ EV, long long n, double* __restrict__ out) {
+    __shared__ double sh[2 * 16];
+    double v[2] = {0.0, 0.0};
+    for (long long i = threadIdx.x; i < n; i += 1024) { const double e = EV[i]; v[0] += e; v[1] += e * e; }
+    v[0] = wave_sum(v[0]);
+    v[1] = wave_sum(v[1]);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = v[0]; sh[16 + (threadIdx.x >> 6)] = v[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < 16; ++q) { a += sh[q]; b += sh[16 + q]; }
+        out[0] = a;
+        out[1] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, int n, double* __restrict__ out) {
     __shared__ double sh[4];
     double v[1] = {0.0};
@@ -560,7 +578,7 @@ extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->E0, (size_t)ctx->n_loc))) return rc;
     if ((rc = asb_alloc(ctx, &ctx->EV, (size_t)ctx->n_loc))) return rc;
-    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)4))) return rc;
+    if ((rc = asb_alloc(ctx, &ctx->e0_sc, (size_t)8))) return rc;
     long long want = (ctx->n_loc + 3) / 4;
     const int grid = (int)(want < ctx->nblk_cap ? want : ctx->nblk_cap);
     if ((rc = asb_alloc(ctx, &ctx->mean_part, (size_t)ctx->nblk_cap))) return rc;
@@ -572,9 +590,14 @@ extern "C" int asb_snapshots_scale(asb_ctx* ctx, double a) {
     ctx->e0_valid = true;
     ctx->ev_valid = true;
     // share of |X|^2 along the constant-in-time direction (this sweep is part of the preparation, not of a deflation step)
-    double h[3];
+    hipLaunchKernelGGL(k_ev_moments, dim3(1), dim3(1024), 0, ctx->stream, ctx->EV, (long long)ctx->n_loc, ctx->e0_sc + 4);
+    ASB_CHECK_LAUNCH(ctx);
+    double h[6];
     ASB_HIP(ctx, hipMemcpyAsync(h, ctx->e0_sc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     ASB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // squared coefficient of variation of the per-vertex energies outside the constant direction
+    ctx->ev_cv2 = (h[4] > 0.0 && ctx->n_loc > 1) ? (double)ctx->n_loc * h[5] / (h[4] * h[4]) - 1.0 : 0.0;
+    if (getenv("ASB_DEBUG_PANELS")) fprintf(stderr, "[asb] energies outside the constant direction: squared coefficient of variation %.3f over %lld vertices\n", ctx->ev_cv2, (long long)ctx->n_loc);
     ctx->mean_frac = h[0] > 0.0 ? h[2] / h[0] : 0.0;
     ctx->mean_energy = h[2];
     ctx->prep_normx2 = h[0];
