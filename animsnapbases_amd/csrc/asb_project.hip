@@ -3883,7 +3883,8 @@ static int double_panel(asb_ctx* ctx, long long k, long long k1, int64_t* done_o
         long long ncols = 0;
         for (int ct = 0; ct < ntile; ++ct) ncols += nc[ct];
         const long long left = ncols - total;
-        if (left >= 8 && ctx->n_loc > ctx->m_cap) {        // (above one co-resident launch the replay runs on the largest energies)
+        static const int sk_min_cols = getenv("ASB_SKETCH_MIN_COLS") ? atoi(getenv("ASB_SKETCH_MIN_COLS")) : 8;
+        if (left >= sk_min_cols && ctx->n_loc > ctx->m_cap) {        // (above one co-resident launch the replay runs on the largest energies)
             const long long ks = k + total, todo = k1 - ks;
             const int r = (int)(left < 64 ? left : 64), steps = (int)(todo < 64 ? todo : 64);
             const auto t_rep0 = std::chrono::steady_clock::now();
