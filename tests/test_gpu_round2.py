@@ -281,7 +281,14 @@ def test_reads_finished_on_the_device_match_the_step_by_step_path(kind, monkeypa
         comp, st = _run(verts, K)
         _check(comp, d, tol=1e-9 if kind == "uniform" else 1e-8)
         outs[chain] = (comp.comps.copy(), comp.weigs.copy(), comp.measures_at_largeDeforVerts.copy(), st[0])
-    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    # The same components from the same reads.  Bit for bit where both paths run the same kernels on the same tile counts (every
+    # tile stands); where reads are cut short the chained path has its pass enqueued on the EXPECTED counts (the four-tile kernel)
+    # and the step-by-step path on the counts reached (possibly the three- or two-tile kernel: another summation order): rounding.
+    rc, rw = relerr(outs["1"][0], outs["0"][0]), relerr(outs["1"][1], outs["0"][1])
+    print("chained against step by step:", rc, rw)
+    if kind == "uniform":
+        assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert rc < 1e-13 and rw < 1e-13
     assert relerr(outs["1"][2][:, 1:], outs["0"][2][:, 1:]) < 1e-12          # (column sums: other block partials)
     assert outs["1"][3]["panels"] == outs["0"][3]["panels"]
     if kind == "uniform":
