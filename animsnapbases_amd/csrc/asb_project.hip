@@ -1475,6 +1475,125 @@ __global__ __launch_bounds__(512, 2) void k_project_l2d(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// k_project_l2e (round 4): the 64-column pass WITHOUT any synchronisation between waves.  k_project_l2d shares one staged copy of
+// the weights among the 8 waves of a block and pays for it with a stage protocol (arrival counters; 0.11 of its 1.41 ms) and a
+// cross-wave reduction.  A lane reads back from LDS exactly the 32 bytes per column tile it loaded itself (Wq is in MFMA lane
+// order), so LDS is only a register-free FIFO: here every wave keeps a PRIVATE ring of two chunks (2 x 8 KB; 8 waves = 128 KB) that
+// it fills itself with direct loads, one chunk ahead, next to its own X chunk -- 8x the L2 traffic for the weights (4.8 GB per
+// launch, 13 % of what the L2s deliver), no barrier, no counters, no reduction: a wave owns its rows for all frames.
+// All loads by hand (asm) so that every wait is a counted one: per chunk 2 NCT weight loads + NTV X loads.
+// --------------------------------------------------------------------------------------
+template <int NCT, int NTV, int DBG>
+__device__ __forceinline__ void l2e_rows(const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq,
+                                         const double* __restrict__ wn2, const WideArgs& wa, double* __restrict__ comps,
+                                         long long comp_stride, long long group0, unsigned lds_byte0) {
+    static_assert(NTV >= 1 && NTV <= 4, "row groups per wave");
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+    const int nchunk = Fp / 16;
+    const long long base = group0 * 16;
+    const double4* xp[NTV];                                     // chunk c: xp[m][4 * c]
+#pragma unroll
+    for (int m = 0; m < NTV; ++m) {
+        long long r = base + 16 * m + i;
+        if (r >= rows) r = rows - 1;
+        xp[m] = reinterpret_cast<const double4*>(X + r * Fp + 4 * g);
+    }
+    d4 acc[NTV][NCT];
+#pragma unroll
+    for (int m = 0; m < NTV; ++m)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+    double4 a0[NTV], a1[NTV];
+    // the weights of chunk c into ring slot c & 1 (asm: the compiler counts only the X loads; the hardware retires both kinds in
+    // the order issued, so the compiler's wait for the X chunk issued BEHIND these covers them -- as in k_project_l2d)
+    auto issue_w = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 2 * NCT; ++q) {
+            const int ct = q >> 1, h = q & 1;
+            const double* src = Wq + (long long)ct * Fp * 16 + (long long)c * 256 + l * 4 + h * 2;
+            const unsigned lds_byte = __builtin_amdgcn_readfirstlane(lds_byte0 + (unsigned)(((c & 1) * 2 * NCT + q) * 128 * 8));
+            unsigned m0_keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_keep) : "v"(src), "s"(lds_byte) : "memory");
+        }
+    };
+    auto load_x = [&](int c, double4 (&a)[NTV]) {
+        const int cc = c < nchunk ? c : nchunk - 1;            // (behind the end: the last chunk once more -- the same loads on every path)
+#pragma unroll
+        for (int m = 0; m < NTV; ++m) a[m] = xp[m][4 * cc];
+    };
+    auto compute = [&](int c, double4 (&a)[NTV]) {
+        // this chunk's weights have landed once everything but the X chunk requested last (2 NTV loads) is back
+        if (NTV == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (NTV == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (NTV == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            d2v b0, b1;
+            const unsigned addr = lds_byte0 + (unsigned)((((c & 1) * 2 * NCT + 2 * ct) * 128 + l * 2) * 8);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(addr));
+#pragma unroll
+            for (int m = 0; m < NTV; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b0.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NTV; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b0.y, acc[m][ct], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NTV; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].z, b1.x, acc[m][ct], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NTV; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].w, b1.y, acc[m][ct], 0, 0, 0);
+            // the next chunk's weights go out BEHIND the wait for this chunk's X (the first MFMAs above): they have this chunk's
+            // remaining 48 MFMAs and the other wave's 64 to arrive, and the next chunk's X wait (issued behind them) covers them
+            if (ct == 0 && c + 1 < nchunk) issue_w(c + 1);
+        }
+    };
+    load_x(0, a0);
+    issue_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // first chunk of the rows: one exposed latency
+    for (int c = 0; c < nchunk; c += 2) {
+        load_x(c + 1, a1);
+        compute(c, a0);
+        load_x(c + 2, a0);
+        if (c + 1 < nchunk) compute(c + 1, a1);
+    }
+    (void)DBG;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (i < wa.nc[ct]) {
+            const double inv = wn2[16 * ct + i];
+            double* dst = comps + (wa.kb[ct] + i) * comp_stride + base + g;
+#pragma unroll
+            for (int m = 0; m < NTV; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (base + 16 * m + g + 4 * q < rows) dst[16 * m + 4 * q] = acc[m][ct][q] / inv;
+        }
+    }
+}
+template <int NCT, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void k_project_l2e(const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq,
+                                                        const double* __restrict__ wn2, WideArgs wa, double* __restrict__ comps,
+                                                        long long comp_stride) {
+    extern __shared__ double l2e_lds[];
+    const int w = threadIdx.x >> 6;
+    const unsigned lds_byte0 = (unsigned)(w * 2 * 2 * NCT * 128 * 8);        // this wave's ring: 2 chunks x 2 NCT KB
+    const long long ngroups = (rows + 15) / 16;
+    const long long g0 = ngroups * blockIdx.x / gridDim.x, g1 = ngroups * (blockIdx.x + 1) / gridDim.x;
+    // the block's groups in contiguous shares per wave (9 or 10 of 73 - 74 at config 4), each share in turns of at most four
+    const long long n = g1 - g0, w0 = g0 + n * w / 8, w1 = g0 + n * (w + 1) / 8;
+    for (long long gr = w0; gr < w1; gr += 4) {
+        const int ntv = (int)(w1 - gr < 4 ? w1 - gr : 4);
+        switch (ntv) {
+            case 4: l2e_rows<NCT, 4, DBG>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, gr, lds_byte0); break;
+            case 3: l2e_rows<NCT, 3, DBG>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, gr, lds_byte0); break;
+            case 2: l2e_rows<NCT, 2, DBG>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, gr, lds_byte0); break;
+            default: l2e_rows<NCT, 1, DBG>(X, rows, Fp, Wq, wn2, wa, comps, comp_stride, gr, lds_byte0); break;
+        }
+    }
+    (void)l2e_lds;
+}
+
 // scal[(k0+t)*4+3] = sum over blocks of colpart[b][t]  (= |w_t|^2 |c_t|_F^2 on this shard)
 // scal[(k0 + t) * 4 + 3] = sum over the blocks' partial column sums; one wave per column (launch with 1024 threads)
 __global__ __launch_bounds__(1024) void k_colsum(const double* __restrict__ colpart, int nblk, int ncols, long long k0,
@@ -1794,8 +1913,26 @@ static int launch_l2d(asb_ctx* ctx, const WideArgs& wa) {
                        ctx->wn2t3, wa, (ctx->wide_out ? ctx->wide_out : ctx->comps), rows);
     return ASB_OK;
 }
+template <int DBG>
+static int launch_l2e(asb_ctx* ctx, const WideArgs& wa) {
+    const long long rows = 3 * ctx->n_loc, ngroups = (rows + 15) / 16;
+    const size_t lds = (size_t)8 * 2 * 2 * 4 * 128 * sizeof(double);
+    static bool attr_set_dev[64] = {false};
+    bool& attr_set = attr_set_dev[ctx->dev & 63];
+    if (!attr_set) {
+        ASB_HIP(ctx, hipFuncSetAttribute((const void*)k_project_l2e<4, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long nb = ngroups < ctx->n_cu ? ngroups : ctx->n_cu;
+    hipLaunchKernelGGL((k_project_l2e<4, DBG>), dim3((unsigned)nb), dim3(512), lds, ctx->stream, ctx->X, rows, (int)ctx->Fp, ctx->Wq3, ctx->wn2t3, wa,
+                       (ctx->wide_out ? ctx->wide_out : ctx->comps), rows);
+    return ASB_OK;
+}
 template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
+    if (variant == 60 && NCT == 4) return launch_l2e<0>(ctx, wa);
+    if (variant == 61 && NCT == 4) return launch_l2e<1>(ctx, wa);                // (debug: X by plain loads, full waits)
+    if (variant == 62 && NCT == 4) return launch_l2e<2>(ctx, wa);                // (debug: asm loads, full waits)                // no synchronisation between waves (private weight rings)
     if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage (two buffers)
     if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
     if (variant == 52 && NCT == 4) return launch_l2d<4, 3, 1, 3, 11>(ctx, wa);  // + weights of the next column tile read ahead (BPF)
