@@ -1482,7 +1482,9 @@ __global__ __launch_bounds__(512, 2) void k_project_l2d(
 // order), so LDS is only a register-free FIFO: here every wave keeps a PRIVATE ring of two chunks (2 x 8 KB; 8 waves = 128 KB) that
 // it fills itself with direct loads, one chunk ahead, next to its own X chunk -- 8x the L2 traffic for the weights (4.8 GB per
 // launch, 13 % of what the L2s deliver), no barrier, no counters, no reduction: a wave owns its rows for all frames.
-// All loads by hand (asm) so that every wait is a counted one: per chunk 2 NCT weight loads + NTV X loads.
+// MEASURED (round 4, ASB_WIDE_VARIANT=60; parity green): 1.456 - 1.475 ms per launch against 1.400 - 1.408 for k_project_l2d on the
+// same box -- and 1.372 - 1.388 with the wait for the weights left out (wrong results): the stage protocol is not what k_project_l2d
+// loses; a wave that waits for its own weights chunk by chunk loses more than eight waves sharing a stage.  Kept as a variant.
 // --------------------------------------------------------------------------------------
 template <int NCT, int NTV, int DBG>
 __device__ __forceinline__ void l2e_rows(const double* __restrict__ X, long long rows, int Fp, const double* __restrict__ Wq,
@@ -1930,9 +1932,7 @@ static int launch_l2e(asb_ctx* ctx, const WideArgs& wa) {
 }
 template <int NCT>
 static int launch_l2w(asb_ctx* ctx, int variant, const WideArgs& wa) {
-    if (variant == 60 && NCT == 4) return launch_l2e<0>(ctx, wa);
-    if (variant == 61 && NCT == 4) return launch_l2e<1>(ctx, wa);                // (debug: X by plain loads, full waits)
-    if (variant == 62 && NCT == 4) return launch_l2e<2>(ctx, wa);                // (debug: asm loads, full waits)                // no synchronisation between waves (private weight rings)
+    if (variant == 60 && NCT == 4) return launch_l2e<0>(ctx, wa);                // no synchronisation between waves (private weight rings): slower
     if (variant == 45 && NCT == 4) return launch_l2d<4, 3, 0>(ctx, wa);      // balanced partition, barrier per stage (two buffers)
     if (variant == 47 && NCT == 4) return launch_l2d<4, 2, 1>(ctx, wa);      // shorter stages
     if (variant == 52 && NCT == 4) return launch_l2d<4, 3, 1, 3, 11>(ctx, wa);  // + weights of the next column tile read ahead (BPF)
