@@ -253,6 +253,7 @@ struct asb_ctx {
     int* la_status = nullptr;
     double* dn_sym = nullptr;                     // symmetric Gauss-Jordan: pivot row panel, D x panel, signed transpose, pivot block
     double *dn_work = nullptr, *dn_test = nullptr;   // asb_dense.hip: Gauss-Jordan panels; test matrix
+    double* td_backup = nullptr;                  // the matrix before the panels (restored if a panel's exchange times out)
     double* td_panel = nullptr;                   // k_td_panel: x | z partials | V | W | p, q
     unsigned long long* td_rec = nullptr;         // its exchange words (ring of three) and the abort flag
     double* td_ppart = nullptr;                   // partial mat-vec vectors of the tridiagonalisation (one per column chunk)

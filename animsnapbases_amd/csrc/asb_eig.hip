@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_td_update(double* __restrict__ A, int n
 #define TDP_NB 32
 #define TDP_T 512
 #define TDP_SENT 0xFFFFFFFFFFFFFFFFull
-struct TdpBuf { double* x; double* zp; double* pq; double* V; double* W; unsigned long long* rec; unsigned* flags; unsigned long long* tlog; };
+struct TdpBuf { double* x; double* zp; double* pq; double* V; double* W; unsigned long long* rec; unsigned* flags; unsigned long long* tlog; int test_stall; };
 #define TDP_STAMP(slot) do { if (B.tlog && b == 0 && tid == 0) B.tlog[(size_t)jj * 8 + (slot)] = wall_clock64_td(); } while (0)
 __device__ __forceinline__ unsigned long long wall_clock64_td() { return wall_clock64(); }      // 100 MHz
 __device__ __forceinline__ void tdp_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -286,6 +286,7 @@ __device__ __forceinline__ void tdp_post(const TdpBuf& B, int G, int gen, double
     __builtin_amdgcn_s_waitcnt(0);               // this wave's write-through stores of the phase are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (!(B.test_stall && (int)blockIdx.x == G - 1))        // (tests: the last block never signals)
         __hip_atomic_store(B.rec + (size_t)(gen % 3) * G + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         *dead_sh = 0;                            // (read behind the poll's barrier; a timed-out poller sets it to 1 after this)
@@ -300,7 +301,7 @@ __device__ __forceinline__ bool tdp_poll(const TdpBuf& B, int G, int gen, double
         for (;;) {
             const unsigned long long w = __hip_atomic_load(ring + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (w != TDP_SENT) { v = __longlong_as_double((long long)w); break; }
-            if ((++spins & 255) == 0 && (spins > (1LL << 24) || __hip_atomic_load(B.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if ((++spins & 255) == 0 && (spins > (B.test_stall ? (1LL << 12) : (1LL << 24)) || __hip_atomic_load(B.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(B.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *dead_sh = 1;
                 break;
@@ -710,6 +711,10 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
                 B.rec = ctx->td_rec;
                 B.flags = reinterpret_cast<unsigned*>(ctx->td_rec + 3 * TDP_T);
                 B.tlog = nullptr;
+                B.test_stall = getenv("ASB_TD_TEST_STALL") ? atoi(getenv("ASB_TD_TEST_STALL")) : 0;
+                // the matrix as it is now, for the case that a panel's exchange times out: the two-launch loop then starts over on it
+                if ((rc = asb_alloc(ctx, &ctx->td_backup, (size_t)n * n))) return rc;
+                ASB_HIP(ctx, hipMemcpyAsync(ctx->td_backup, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
                 static unsigned long long* tlog_dev = nullptr;
                 if (getenv("ASB_DEBUG_TD") && !tlog_dev) (void)hipMalloc((void**)&tlog_dev, (TDP_NB + 1) * 8 * sizeof(unsigned long long));
                 ASB_HIP(ctx, hipMemsetAsync(B.flags, 0, 16 * sizeof(unsigned long long) / 2, ctx->stream));
@@ -734,7 +739,16 @@ static int sym_tridiag(asb_ctx* ctx, double* A_dev, int64_t n64, double* d_host,
                                 h[jj * 8 + 1] - h[jj * 8], h[jj * 8 + 2] - h[jj * 8 + 1], h[jj * 8 + 3] - h[jj * 8 + 2], h[jj * 8 + 4] - h[jj * 8 + 3],
                                 h[jj * 8 + 5] - h[jj * 8 + 4], h[jj * 8 + 6] - h[jj * 8 + 5], h[(jj + 1) * 8] - h[jj * 8]);
                 }
-                if (fl) ASB_FAIL(ctx, ASB_ERR_LIMIT, "asb_sym_tridiag: the panel kernel's grid exchange timed out (ASB_TD_PANEL_MIN=0 takes the two-launch loop)");
+                if (fl) {
+                    // a block of some panel never arrived (not co-resident, or lost): nothing of the panels is trusted
+                    ASB_HIP(ctx, hipMemcpyAsync(A, ctx->td_backup, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                    ASB_HIP(ctx, hipMemsetAsync(ctx->td_work, 0, (size_t)8 * n * sizeof(double), ctx->stream));
+                    ASB_HIP(ctx, hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                    js = 0;
+                    ctx->n_coop_fallbacks++;
+                    if (getenv("ASB_DEBUG_TD") || B.test_stall)
+                        fprintf(stderr, "[asb] tridiagonalisation: the panel kernel's grid exchange timed out; two-launch loop from the first column\n");
+                }
             }
         }
     }

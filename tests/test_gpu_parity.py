@@ -795,6 +795,29 @@ def test_device_symmetric_eigensolver(n, k):
     e.close()
 
 
+def test_tridiagonalisation_panel_exchange_timeout_falls_back(monkeypatch):
+    """k_td_panel's grid exchange forced to time out (one block never posts its word): the matrix is restored from its copy and
+    the two-launch loop does the whole reduction -- same spectrum, one fall-back counted."""
+    import torch
+    from scipy.linalg import eigh_tridiagonal
+    from animsnapbases_amd import HipEngine
+    n = 1700
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(n, 300))
+    A = B @ B.T + 1e-3 * np.diag(rng.uniform(size=n))
+    A = 0.5 * (A + A.T)
+    lam_ref = np.linalg.eigvalsh(A)
+    monkeypatch.setenv("ASB_TD_TEST_STALL", "1")
+    e = HipEngine(0, stream=0)
+    Ad = torch.from_numpy(A.copy()).cuda()
+    d, off = e.sym_tridiag(n, Ad.data_ptr())
+    fb = e.deflate_stats()["coop_fallbacks"]
+    e.close()
+    assert fb >= 1
+    lam = eigh_tridiagonal(d, off, eigvals_only=True)
+    assert np.allclose(lam, lam_ref, rtol=0, atol=1e-12 * abs(lam_ref).max())
+
+
 @pytest.mark.parametrize("ep,F", [(5, 3), (211, 130), (777, 300), (1501, 517)])
 def test_pod_gram_mfma_tiles(ep, F):
     """G = A^T A from the LDS-tiled f64-MFMA kernel (128 x 128 tiles above the diagonal, mirrored; split over row
