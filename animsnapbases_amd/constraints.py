@@ -760,12 +760,36 @@ class constraintsComponents:  # Components == bases
         eng, comm = ns._engine, ns._comm
         p_size = ns.constraintsSize
         K = self.numComp
-        self._rank_diagnostic(K)
-        if not comm.multi and self._comps_on_device and hasattr(eng, "deim_run") and \
-                os.environ.get("ASB_DEIM", getattr(self, "deim_backend", "device")) == "device":
+        on_device = not comm.multi and self._comps_on_device and hasattr(eng, "deim_run") and \
+            os.environ.get("ASB_DEIM", getattr(self, "deim_backend", "device")) == "device"
+        if not (on_device and hasattr(eng, "orth_gram_get")):
+            self._rank_diagnostic(K)
+        if on_device:
             # single rank: the whole loop on the device (bordered inverse of the k x k systems carried there, verified
             # per step); one host synchronisation.  A failed verification falls through to the lstsq loop below.
-            Pt_d, maxabs, bad = eng.deim_run()
+            # The printed rank check (:801) needs the eigenvalues of three K x K Gram matrices -- 7 ms of LAPACK on the host at
+            # K = 256: the device loop is started on a worker thread (one C call, the interpreter lock released for all of it) and
+            # the eigenvalues are computed here meanwhile; the check's line is printed first, as in the reference.
+            if hasattr(eng, "orth_gram_get"):
+                import threading
+                G = summed_grams(eng, comm, K)
+                box = {}
+
+                def _loop():
+                    try:
+                        box["out"] = eng.deim_run()
+                    except BaseException as exc:      # (re-raised on the calling thread)
+                        box["exc"] = exc
+                th = threading.Thread(target=_loop)
+                th.start()
+                lams = [np.linalg.eigvalsh(G[j]) for j in range(3)]
+                th.join()
+                if "exc" in box:
+                    raise box["exc"]
+                Pt_d, maxabs, bad = box["out"]
+                test_linear_dependency_grams(G, K, lambda j: self.comps[:, :, j].T, lams=lams)
+            else:
+                Pt_d, maxabs, bad = eng.deim_run()
             if bad and os.environ.get("ASB_DEBUG_DEIM"):
                 print("[asb] DEIM: the device loop's verification failed at a step: host loop", file=sys.stderr)
             if not bad:

@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256) void k_deim_pick(const double* __restrict__ pm
 extern "C" int asb_deim_run(asb_ctx* ctx, int64_t* Pt_out, double* maxabs_out, int* solve_failed) {
     if (!ctx || !ctx->comps || !Pt_out || !maxabs_out || !solve_failed) return ASB_ERR_ARG;
     if (ctx->n_loc != ctx->N_glob) ASB_FAIL(ctx, ASB_ERR_ARG, "asb_deim_run needs all rows on one rank");
+    ASB_HIP(ctx, hipSetDevice(ctx->dev));         // (the host mirror calls this from a worker thread, beside its LAPACK rank check)
     const int K = (int)ctx->K;
     int rc;
     if ((rc = asb_alloc(ctx, &ctx->deim_m, (size_t)12 * K * K + 4 * (size_t)K + 2048 * 2))) return rc;

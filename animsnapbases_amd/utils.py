@@ -159,12 +159,13 @@ def test_linear_dependency(mat, test_dim_range, expected_rank):
             print("... not linear independent, with rank: " + str(rk) + " != " + str(expected_rank) + ".")
 
 
-def test_linear_dependency_grams(G, expected_rank, host_slice):
+def test_linear_dependency_grams(G, expected_rank, host_slice, lams=None):
     """The same printed check from the per-dimension Gram matrices G (3, K, K) of a device-resident basis (one MFMA
     product on the GPU instead of a host product over all rows): clear-cut cases by the rule of ``_rank``; anything
-    closer is decided on the host, ``host_slice(j)`` supplying the (rows, K) slice."""
+    closer is decided on the host, ``host_slice(j)`` supplying the (rows, K) slice.  ``lams``: the eigenvalues of the G[j], if the
+    caller has them already (constraintsComponents.deim computes them beside the device loop)."""
     for j in range(G.shape[0]):
-        lam = np.linalg.eigvalsh(G[j])
+        lam = lams[j] if lams is not None else np.linalg.eigvalsh(G[j])
         if np.all(np.isfinite(lam)) and lam[-1] > 0 and lam[0] > 1e-12 * lam[-1]:
             rk = G.shape[1]
         else:
