@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the snapshot-reduction hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5        (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
