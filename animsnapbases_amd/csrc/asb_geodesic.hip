@@ -925,14 +925,18 @@ __global__ __launch_bounds__(256) void k_symv_tiles(const double* __restrict__ P
             a[q] = ok ? *reinterpret_cast<const double2*>(P + (long long)r * np + c) : make_double2(0.0, 0.0);
             bi[q] = r < np ? b[r] : 0.0;
         }
+        double sr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sr[q] = a[q].x * bj0 + a[q].y * bj1;
+            ca0 += a[q].x * bi[q];
+            ca1 += a[q].y * bi[q];
+        }
+        wave_sum_dpp<4>(sr);                      // (four row sums per turn through the DPP / permlane tree: no LDS crossbar)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = i0 + (rr + q) * 4 + wid;
-            double s = a[q].x * bj0 + a[q].y * bj1;
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0 && r < np) prow[(long long)jb * np + r] = s;
-            ca0 += a[q].x * bi[q];
-            ca1 += a[q].y * bi[q];
+            if (lane == 0 && r < np) prow[(long long)jb * np + r] = sr[q];
         }
     }
     if (ib == jb) return;
