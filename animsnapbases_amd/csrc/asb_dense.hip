@@ -20,8 +20,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // (the callers pad to 16).  S > 1: the slab's product goes to part[z] (M x N, ld N) and k_gemm_finish combines.
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A, long long lda, const double* __restrict__ B,
                                                    long long ldb, double* __restrict__ C, long long ldc, int M, int N, int Kc,
-                                                   double alpha, double beta, int slab, double* __restrict__ part, int tri) {
+                                                   double alpha, double beta, int slab, double* __restrict__ part, int tri, int cinit) {
     // tri: only the tiles on and above the diagonal (a symmetric rank-k update of the upper triangle)
+    // cinit (C -= A B, one slab): the accumulators START as the C tile -- its loads travel beside the first operand stage -- and A is
+    // negated on its way into LDS: the epilogue only stores (the rank-256 updates of the Gauss-Jordan inverse: 16 stages per tile,
+    // where a read-modify-write epilogue is a fifth of the tile's time)
     if (tri && (int)blockIdx.x < (int)blockIdx.y) return;
     __shared__ double As[2][DG_BM][DG_SA];
     __shared__ double Bs[2][DG_KC][DG_SB];
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&As[buf][ar][ak + 2 * q]) = ra[q];
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<double2*>(&As[buf][ar][ak + 2 * q]) = cinit ? make_double2(-ra[q].x, -ra[q].y) : ra[q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&Bs[buf][wave + 4 * q][2 * lane]) = rb[q];
     };
@@ -59,6 +63,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+    if (cinit) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oi = i0 + wi * 64 + x * 16 + g + 4 * q, oj = j0 + wj * 64 + y * 16 + li;
+                    if (oi < M && oj < N) acc[x][y][q] = C[(long long)oi * ldc + oj];
+                }
+    }
     if (k_begin < k_end) {
         fetch(k_begin);
         stash(0);
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const double* __restrict__ A
                 const int oi = i0 + wi * 64 + x * 16 + g + 4 * q, oj = j0 + wj * 64 + y * 16 + li;
                 if (oi < M && oj < N) {
                     double* dst = o + (long long)oi * ldo + oj;
-                    if (split) *dst = acc[x][y][q];
+                    if (split || cinit) *dst = acc[x][y][q];
                     else *dst = (beta == 0.0 ? 0.0 : beta * *dst) + alpha * acc[x][y][q];
                 }
             }
@@ -138,8 +153,10 @@ int asb_gemm_nn(asb_ctx* ctx, const double* A, long long lda, const double* B, l
             ctx->la_part_cap = need;
         }
     }
+    static const int cinit_on = getenv("ASB_GEMM_CINIT") ? atoi(getenv("ASB_GEMM_CINIT")) : 1;
+    const int cinit = (cinit_on && S == 1 && alpha == -1.0 && beta == 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_gemm_nn, dim3(tn, tm, S), dim3(256), 0, ctx->stream, A, lda, B, ldb, C, ldc, M, N, Kc, alpha, beta, slab,
-                       ctx->la_part, tri);
+                       ctx->la_part, tri, cinit);
     if (S > 1) {
         const long long total = (long long)M * N;
         const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
