@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor spec; the guide lists no f64 row; tools/probe_mfma_f64: 70 measured)
-PMC_PROFILE = os.path.join("profiles", "r04d_pmc_traffic.json")      # offline rocprofv3 --pmc passes of THIS build
+PMC_PROFILE = os.path.join("profiles", "r04e_pmc_traffic.json")      # offline rocprofv3 --pmc passes of THIS build
 
 
 def _cpu_info():
